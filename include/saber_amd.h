@@ -1,0 +1,124 @@
+/* saber_amd.h - C-ABI of the MI355X-native slice-wise SAM2 engine.
+ *
+ * Drop-in boundary for the hot path of chanzuckerberg/saber.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference tree):
+ *
+ *   saber_engine_create / set_weight / finalize
+ *       <- build_sam2(cfg, ckpt, device, apply_postprocessing=True)   saber/adapters/sam2/automask.py:61-63
+ *          get_sam2_checkpoint(cfg)                                   saber/pretrained_weights.py:174-202
+ *   saber_prepare
+ *       <- prep.prepare(image, to_rgb=True)                           saber/utils/preprocessing.py:67-80
+ *          (contrast :4-18, normalize :20-37)
+ *   saber_encode
+ *       <- SAM2ImagePredictor.set_image(crop)  (third-party sam2; call site automask.py:66 / predictor.py:70)
+ *   saber_decode_points
+ *       <- SAM2ImagePredictor._predict(points, labels, mask_input, multimask_output, return_logits=True)
+ *   saber_amg_generate
+ *       <- FilteredSAM2MaskGenerator.generate -> SAM2AutomaticMaskGenerator.generate
+ *                                                                     saber/adapters/sam2/amg.py:161-183
+ *                                                                     saber/adapters/sam2/predictor.py:70
+ *   saber_label_plane
+ *       <- the paint loop of propagationSegmenter.slice_by_slice      saber/segmenters/propagation.py:185-186
+ *
+ * Conventions: plain pointers and sizes only; every *_dev pointer is device memory owned by the
+ * caller (e.g. a PyTorch-ROCm tensor's data_ptr()); `stream` is a hipStream_t (NULL = default
+ * stream).  Every function returns 0 on success or a negative saber_status; the message is kept
+ * per handle (saber_last_error).  Nothing aborts or exits.  A handle is bound to one device and
+ * must not be used concurrently from two threads; different handles are independent
+ * (reference threading contract: saber/utils/parallelization.py:100-135).
+ */
+#ifndef SABER_AMD_H
+#define SABER_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct saber_engine saber_engine;
+
+enum saber_status {
+    SABER_OK = 0,
+    SABER_ERR_INVALID = -1,   /* bad argument / unsupported configuration (ValueError in the reference) */
+    SABER_ERR_STATE = -2,     /* call order violated (RuntimeError in the reference)                    */
+    SABER_ERR_HIP = -3,       /* HIP runtime failure                                                     */
+    SABER_ERR_CAPACITY = -4   /* caller-provided output capacity exceeded                                */
+};
+
+enum saber_dtype { SABER_U16 = 0, SABER_F32 = 1 };
+
+/* cfgAMG (saber/adapters/sam2/amg.py:7-17) + the un-passed upstream defaults of
+ * SAM2AutomaticMaskGenerator (mask_threshold 0.0, crop_nms_thresh 0.7, crop_overlap_ratio 512/1500). */
+typedef struct saber_amg_params {
+    int points_per_side;
+    int points_per_batch;
+    float pred_iou_thresh;
+    float stability_score_thresh;
+    float stability_score_offset;
+    float mask_threshold;
+    float box_nms_thresh;
+    int crop_n_layers;
+    float crop_nms_thresh;
+    float crop_overlap_ratio;
+    int crop_n_points_downscale_factor;
+    int use_m2m;
+    int multimask_output;
+} saber_amg_params;
+
+/* One AMG record: the non-array fields of the SAM-AMG dict consumed downstream
+ * (saber/segmenters/base.py:128-133, saber/segmenters/utils.py:36-39,70). */
+typedef struct saber_mask_meta {
+    int32_t area;
+    float bbox_xywh[4];
+    float predicted_iou;
+    float stability_score;
+    float point_xy[2];
+    float crop_box_xywh[4];
+} saber_mask_meta;
+
+/* trunk: "large" (Hiera-L).  max_images: crops encoded per batched pass / feature slots kept resident.
+ * max_prompts: prompts decoded per batched pass. */
+int saber_engine_create(int device_id, const char* trunk, int max_images, int max_prompts, saber_engine** out);
+void saber_engine_destroy(saber_engine* e);
+/* e == NULL returns the calling thread's last create-time error. */
+const char* saber_last_error(const saber_engine* e);
+
+/* Upload one fp32 tensor under its upstream checkpoint key (e.g. "image_encoder.trunk.blocks.0.attn.qkv.weight"). */
+int saber_engine_set_weight(saber_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* Check completeness, build bf16 / fused tables.  Must precede any compute call. */
+int saber_engine_finalize(saber_engine* e);
+
+/* K0.  img_dev: (H,W) uint16 or float32.  out_dev: (H,W) float32 in [0,1]. */
+int saber_prepare(saber_engine* e, const void* img_dev, int dtype, int H, int W, float* out_dev, void* stream);
+
+/* Encode n crops of one image.  img_dev: (H,W) [channels==1] or (H,W,3) float32 in [0,1];
+ * crop_boxes_host: n x [x0,y0,x1,y1].  Features stay resident in slots slot0..slot0+n-1. */
+int saber_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crop_boxes_host, int n,
+                 int slot0, void* stream);
+/* Copy a slot's features out as NCHW fp32: image_embed (256,64,64), feat_s0 (32,256,256), feat_s1 (64,128,128).
+ * Any pointer may be NULL. */
+int saber_get_features(saber_engine* e, int slot, float* image_embed_dev, float* feat_s0_dev, float* feat_s1_dev, void* stream);
+
+/* Decode n point prompts against a slot.  pts_dev: (n,2) in model pixels (0..1024); labels_dev: (n) or NULL (=1).
+ * mask_in_dev: (n,256,256) low-res logits or NULL.  multimask: 3 masks per prompt, else 1 (dynamic selection).
+ * Outputs: lowres (n,M,256,256), iou (n,M), obj (n) - any may be NULL. */
+int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
+                        const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream);
+
+/* Automatic mask generation for one image.  out_bits_dev: (max_masks, H, ceil(W/32)) uint32, bit b of word w of row y
+ * = pixel (y, 32w+b).  out_meta_host: max_masks records.  Synchronises the stream before returning (a count is returned). */
+int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* params,
+                       uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta_host, int* out_count, void* stream);
+
+/* plane[y][x] = (position in order_host)+1 of the LAST mask covering the pixel, 0 if none. */
+int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, const int* order_host, int n, int H, int W,
+                      uint16_t* plane_dev, void* stream);
+
+/* Algorithmic work counters (FLOPs per call) for roofline reporting. */
+double saber_encoder_flops(const saber_engine* e);
+double saber_decoder_flops_per_prompt(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

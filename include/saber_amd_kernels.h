@@ -1,0 +1,52 @@
+/* saber_amd_kernels.h - kernel-level C-ABI (plain device pointers, no engine handle).
+ *
+ * These expose the individual gfx950 kernels so that parity tests can check each one against the
+ * CPU oracle in isolation, and so that an integrator can reuse e.g. the GEMM or the K0/K8 kernels.
+ * Each returns 0 or -1; on -1 saber_k_last_error() holds the message (thread-local).
+ * The torch ops they stand in for (executed by the third-party sam2 package under the reference
+ * call site saber/adapters/sam2/predictor.py:70) are named per function; see SURVEY.md 8a.
+ */
+#ifndef SABER_AMD_KERNELS_H
+#define SABER_AMD_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* saber_k_last_error(void);
+/* must be called once per device before the first kernel call (sets large-LDS attributes) */
+int saber_k_init(int device_id);
+
+/* nn.Linear / 1x1 conv:  C = epi(A[M,K] . W[N,K]^T + bias); A, W bf16 (uint16 storage), bias/res fp32.
+ * act: 0 none, 1 GELU(erf), 2 ReLU, 3 sigmoid.  out_f32 / out_bf16 / bias / res may be NULL.
+ * pool4: rows 4q..4q+3 max-pooled into row q. res_shift / res_mod: residual row = (row >> res_shift) % res_mod. */
+int saber_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, const float* res, float* out_f32, uint16_t* out_bf16,
+                 int M, int N, int K, int act, int act_last, int pool4, int res_shift, int res_mod, void* stream);
+
+/* nn.LayerNorm over the last dim; fp32 in, fp32 and/or bf16 out. */
+int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,
+                      int rows, int C, int act, void* stream);
+
+/* Hiera MultiScaleAttention core on contiguous windows (head_dim 72): qkv bf16 [tokens][3*heads*72]
+ * -> out bf16 [tokens_q][heads*72]; nk keys per window, q_pool: queries max-pooled over 4 consecutive rows. */
+int saber_k_hiera_attention(const uint16_t* qkv, uint16_t* out, int n_windows, int nk, int heads, int q_pool, void* stream);
+
+/* two-way-transformer attention (fp32 in, bf16 out), contiguous [B][n][heads*hd]. */
+int saber_k_dec_attention(const float* q, const float* k, const float* v, uint16_t* out, int B, int nq, int nk, int heads, int hd,
+                          int k_shared, void* stream);
+
+/* K0: prep.prepare on a (H,W) slice; ws_dev: 4*H*W floats of scratch, minmax_dev: 2 uint32 */
+int saber_k_prepare(const void* img, int dtype, int H, int W, float* out, float* ws_dev, uint32_t* minmax_dev, void* stream);
+
+/* K8: upsample n low-res (256x256) logit maps to a crop, counts / bbox / bit-pack.  stats: n x 8 int32
+ * (area, inter, union, x0, y0, x1, y1, pad). bits: n x H x ceil(W/32). */
+int saber_k_mask_post(const float* lowres, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H, int W, float thr,
+                      float offset, uint32_t* bits, int32_t* stats, void* stream);
+
+/* engine token order helpers (DESIGN.md "token order") */
+int saber_k_perm_index(int y, int x, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""ctypes binding of libsaber_amd.so (the C-ABI declared in include/saber_amd.h and
+include/saber_amd_kernels.h).  The product path has no CPU fallback: if the HIP extension is
+missing the import of this module raises, loudly."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsaber_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class SaberAmdError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into saber_amd/libsaber_amd.so (in-tree)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SaberAmdError("building libsaber_amd.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+class AmgParams(C.Structure):
+    _fields_ = [("points_per_side", C.c_int), ("points_per_batch", C.c_int), ("pred_iou_thresh", C.c_float),
+                ("stability_score_thresh", C.c_float), ("stability_score_offset", C.c_float), ("mask_threshold", C.c_float),
+                ("box_nms_thresh", C.c_float), ("crop_n_layers", C.c_int), ("crop_nms_thresh", C.c_float),
+                ("crop_overlap_ratio", C.c_float), ("crop_n_points_downscale_factor", C.c_int), ("use_m2m", C.c_int),
+                ("multimask_output", C.c_int)]
+
+
+class MaskMeta(C.Structure):
+    _fields_ = [("area", C.c_int32), ("bbox_xywh", C.c_float * 4), ("predicted_iou", C.c_float),
+                ("stability_score", C.c_float), ("point_xy", C.c_float * 2), ("crop_box_xywh", C.c_float * 4)]
+
+
+# name -> (restype, argtypes); mirrors include/*.h one-to-one (tests/test_abi.py checks the symbol list)
+_vp, _i, _f, _i64p = C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_int64)
+SIGNATURES = {
+    "saber_engine_create": (_i, [_i, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "saber_engine_destroy": (None, [_vp]),
+    "saber_last_error": (C.c_char_p, [_vp]),
+    "saber_engine_set_weight": (_i, [_vp, C.c_char_p, _vp, _i64p, _i]),
+    "saber_engine_finalize": (_i, [_vp]),
+    "saber_prepare": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "saber_encode": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _i, _i, _vp]),
+    "saber_get_features": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "saber_decode_points": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),
+    "saber_label_plane": (_i, [_vp, _vp, C.POINTER(_i), _i, _i, _i, _vp, _vp]),
+    "saber_encoder_flops": (C.c_double, [_vp]),
+    "saber_decoder_flops_per_prompt": (C.c_double, []),
+    "saber_k_last_error": (C.c_char_p, []),
+    "saber_k_init": (_i, [_i]),
+    "saber_k_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "saber_k_layernorm": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
+    "saber_k_hiera_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "saber_k_dec_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "saber_k_prepare": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "saber_k_mask_post": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "saber_k_perm_index": (_i, [_i, _i, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (idempotent).  Raises SaberAmdError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SaberAmdError(f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
+                            f"(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,282 @@
+// Automatic mask generation driver (host control flow + small device helpers).
+// Replaces SAM2AutomaticMaskGenerator.generate as the reference drives it
+// (saber/adapters/sam2/predictor.py:70 -> saber/adapters/sam2/amg.py:161-183; parameters
+// saber/adapters/sam2/automask.py:66-78).  Semantics restated from upstream sam2
+// (automatic_mask_generator.py, utils/amg.py) - see SURVEY.md 3.3 / 8a b11-b12:
+//   crops -> per-crop encode -> point grid decode (+ m2m refinement) -> pred_iou filter ->
+//   stability filter -> threshold + bbox -> near-crop-edge filter -> per-crop NMS -> cross-crop NMS.
+// Device work: encode/decode (engine.hip), K8 mask_post (decoder_ops.hip).  The host only sees
+// per-mask scalars (iou, counts, boxes); masks stay bit-packed on the device.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+#include "engine.h"
+
+#define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
+
+__global__ __launch_bounds__(256) void clamp_kernel(float* x, int64_t n, float lo, float hi) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+struct Cand {
+    float box[4];       // xyxy in full-image coordinates (inclusive max edge, upstream batched_mask_to_box)
+    float iou, stab;
+    float pt[2];
+    int crop[4];
+    int area;
+    size_t bits_slot;   // index into the accumulated bit-mask buffer
+};
+
+static std::vector<int> nms_host(const std::vector<Cand>& c, const std::vector<float>& scores, float thr) {
+    // torchvision.ops.nms: stable sort by descending score, suppress IoU > thr (fp32 arithmetic)
+    const int n = (int)c.size();
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+    std::vector<char> sup(n, 0);
+    std::vector<int> keep;
+    for (int _i = 0; _i < n; ++_i) {
+        const int i = order[_i];
+        if (sup[i]) continue;
+        keep.push_back(i);
+        const float* bi = c[i].box;
+        const float iarea = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+        for (int _j = _i + 1; _j < n; ++_j) {
+            const int j = order[_j];
+            if (sup[j]) continue;
+            const float* bj = c[j].box;
+            const float xx1 = std::max(bi[0], bj[0]), yy1 = std::max(bi[1], bj[1]);
+            const float xx2 = std::min(bi[2], bj[2]), yy2 = std::min(bi[3], bj[3]);
+            const float w = std::max(0.0f, xx2 - xx1), h = std::max(0.0f, yy2 - yy1);
+            const float inter = w * h;
+            const float jarea = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+            const float ovr = inter / (iarea + jarea - inter);
+            if (ovr > thr) sup[j] = 1;
+        }
+    }
+    return keep;
+}
+
+static void gen_crop_boxes(int H, int W, int n_layers, float overlap_ratio, std::vector<std::array<int, 4>>& boxes, std::vector<int>& layers) {
+    boxes.push_back({0, 0, W, H});
+    layers.push_back(0);
+    const int short_side = std::min(H, W);
+    auto crop_len = [](int orig, int n, int overlap) { return (int)std::ceil((double)(overlap * (n - 1) + orig) / n); };
+    for (int l = 0; l < n_layers; ++l) {
+        const int ns = 1 << (l + 1);
+        const int overlap = (int)((double)overlap_ratio * short_side * (2.0 / ns));
+        const int cw = crop_len(W, ns, overlap), ch = crop_len(H, ns, overlap);
+        for (int ix = 0; ix < ns; ++ix)        // itertools.product(x0s, y0s): x outer, y inner
+            for (int iy = 0; iy < ns; ++iy) {
+                const int x0 = (cw - overlap) * ix, y0 = (ch - overlap) * iy;
+                boxes.push_back({x0, y0, std::min(x0 + cw, W), std::min(y0 + ch, H)});
+                layers.push_back(l + 1);
+            }
+    }
+}
+
+extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* prm,
+                                  uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta, int* out_count, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (!img_dev || !prm || !out_count || H <= 0 || W <= 0 || max_masks < 0 || (max_masks > 0 && (!out_bits_dev || !out_meta)))
+        return eng_fail(e, SABER_ERR_INVALID, "amg_generate: bad argument");
+    if (prm->points_per_side <= 0 || prm->points_per_batch <= 0 || prm->crop_n_layers < 0 || prm->crop_n_layers > 4 ||
+        prm->crop_n_points_downscale_factor <= 0)
+        return eng_fail(e, SABER_ERR_INVALID, "amg_generate: bad cfgAMG value");
+    ENG_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    *out_count = 0;
+    const int W32 = (W + 31) >> 5;
+    const size_t mask_words = (size_t)H * W32;
+    const int M = prm->multimask_output ? 3 : 1;
+
+    std::vector<std::array<int, 4>> crops;
+    std::vector<int> layers;
+    gen_crop_boxes(H, W, prm->crop_n_layers, prm->crop_overlap_ratio, crops, layers);
+    // point grids per layer (numpy float64 linspace semantics)
+    std::vector<std::vector<double>> grids(prm->crop_n_layers + 1);
+    std::vector<int> grid_n(prm->crop_n_layers + 1);
+    for (int l = 0; l <= prm->crop_n_layers; ++l) {
+        const int n = (int)((double)prm->points_per_side / std::pow((double)prm->crop_n_points_downscale_factor, l));
+        if (n <= 0) return eng_fail(e, SABER_ERR_INVALID, "amg_generate: point grid of a crop layer is empty");
+        grid_n[l] = n;
+        const double off = 1.0 / (2.0 * n);
+        grids[l].resize(n);
+        for (int i = 0; i < n; ++i) grids[l][i] = n == 1 ? off : off + (1.0 - 2.0 * off) * (double)i / (double)(n - 1);
+    }
+    const size_t max_pts = (size_t)grid_n[0] * grid_n[0];
+    const size_t max_prompts = max_pts * M;
+    if (e->amg_prompts_cap < max_prompts) {
+        TRY(eng_alloc(e, &e->amg_pts, max_pts * 2));
+        TRY(eng_alloc(e, &e->amg_pts2, max_prompts * 2));
+        TRY(eng_alloc(e, &e->amg_low1, max_prompts * 65536));
+        TRY(eng_alloc(e, &e->amg_iou1, max_prompts));
+        TRY(eng_alloc(e, &e->amg_low2, max_prompts * 65536));
+        TRY(eng_alloc(e, &e->amg_iou2, max_prompts));
+        e->amg_prompts_cap = max_prompts;
+    }
+    if (e->amg_stats_cap < max_prompts) {
+        TRY(eng_alloc(e, &e->amg_stats, max_prompts));
+        TRY(eng_alloc(e, &e->amg_idx, max_prompts));
+        e->amg_stats_cap = max_prompts;
+    }
+
+    std::vector<Cand> all;            // accumulated over crops (after per-crop NMS)
+    size_t acc_used = 0;              // masks stored in the persistent accumulation buffer e->amg_bits
+    auto acc_reserve = [&](size_t need) -> int {
+        if (need * mask_words <= e->amg_bits_words) return SABER_OK;
+        const size_t ncap = std::max<size_t>(need, std::max<size_t>(64, 2 * (e->amg_bits_words / mask_words)));
+        uint32_t* nb = nullptr;
+        TRY(eng_alloc(e, &nb, ncap * mask_words));
+        if (acc_used) ENG_HIP(e, hipMemcpyAsync(nb, e->amg_bits, acc_used * mask_words * 4, hipMemcpyDeviceToDevice, s));
+        ENG_HIP(e, hipStreamSynchronize(s));
+        eng_free(e, e->amg_bits);
+        e->amg_bits = nb; e->amg_bits_words = ncap * mask_words;
+        return SABER_OK;
+    };
+    auto crop_reserve = [&](size_t need) -> int {  // scratch for one crop's pred_iou survivors
+        if (need * mask_words <= e->amg_crop_words) return SABER_OK;
+        ENG_HIP(e, hipStreamSynchronize(s));
+        eng_free(e, e->amg_crop_bits);
+        e->amg_crop_bits = nullptr; e->amg_crop_words = 0;
+        TRY(eng_alloc(e, &e->amg_crop_bits, need * mask_words));
+        e->amg_crop_words = need * mask_words;
+        return SABER_OK;
+    };
+    std::vector<float> h_iou;
+    std::vector<MaskStats> h_stats;
+    std::vector<int> h_idx;
+    std::vector<float> h_pts, h_pts2;
+
+    const int nc = (int)crops.size();
+    for (int c0 = 0; c0 < nc; c0 += e->max_images) {
+        const int ncb = std::min(e->max_images, nc - c0);
+        std::vector<int> cb(4 * ncb);
+        for (int i = 0; i < ncb; ++i) for (int k = 0; k < 4; ++k) cb[4 * i + k] = crops[c0 + i][k];
+        TRY(eng_encode(e, img_dev, H, W, channels, cb.data(), ncb, 0, s));
+        for (int ci = 0; ci < ncb; ++ci) {
+            const auto& box = crops[c0 + ci];
+            const int layer = layers[c0 + ci];
+            const int cw = box[2] - box[0], chh = box[3] - box[1];
+            const int gn = grid_n[layer];
+            const int np = gn * gn;
+            h_pts.resize((size_t)np * 2);
+            std::vector<float> crop_pts((size_t)np * 2);
+            for (int iy = 0; iy < gn; ++iy)
+                for (int ix = 0; ix < gn; ++ix) {
+                    const float px = (float)(grids[layer][ix] * (double)cw), py = (float)(grids[layer][iy] * (double)chh);
+                    const size_t k = (size_t)iy * gn + ix;
+                    crop_pts[2 * k] = px; crop_pts[2 * k + 1] = py;
+                    h_pts[2 * k] = (px / (float)cw) * 1024.0f;
+                    h_pts[2 * k + 1] = (py / (float)chh) * 1024.0f;
+                }
+            ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * np, hipMemcpyHostToDevice, s));
+            TRY(eng_decode(e, ci, e->amg_pts, nullptr, np, prm->multimask_output, nullptr, e->amg_low1, e->amg_iou1, nullptr, s));
+            const int nm = np * M;
+            const float* masks = e->amg_low1;
+            const float* ious = e->amg_iou1;
+            if (prm->use_m2m) {
+                hipLaunchKernelGGL(clamp_kernel, dim3(2048), dim3(256), 0, s, e->amg_low1, (int64_t)nm * 65536, -32.0f, 32.0f);
+                h_pts2.resize((size_t)nm * 2);
+                for (int k = 0; k < np; ++k)
+                    for (int m = 0; m < M; ++m) { h_pts2[2 * ((size_t)k * M + m)] = h_pts[2 * k]; h_pts2[2 * ((size_t)k * M + m) + 1] = h_pts[2 * k + 1]; }
+                ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * nm, hipMemcpyHostToDevice, s));
+                TRY(eng_decode(e, ci, e->amg_pts2, nullptr, nm, 0, e->amg_low1, e->amg_low2, e->amg_iou2, nullptr, s));
+                masks = e->amg_low2;
+                ious = e->amg_iou2;
+            }
+            h_iou.resize(nm);
+            ENG_HIP(e, hipMemcpyAsync(h_iou.data(), ious, sizeof(float) * nm, hipMemcpyDeviceToHost, s));
+            ENG_HIP(e, hipStreamSynchronize(s));
+            h_idx.clear();
+            for (int k = 0; k < nm; ++k)
+                if (!(prm->pred_iou_thresh > 0.0f) || h_iou[k] > prm->pred_iou_thresh) h_idx.push_back(k);
+            const int ns = (int)h_idx.size();
+            if (ns == 0) continue;
+            TRY(crop_reserve((size_t)ns));
+            uint32_t* crop_bits = e->amg_crop_bits;
+            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
+            ENG_K(e, launch_mask_post(masks, e->amg_idx, ns, box[0], box[1], cw, chh, H, W, prm->mask_threshold, prm->stability_score_offset,
+                                      crop_bits, e->amg_stats, s));
+            h_stats.resize(ns);
+            ENG_HIP(e, hipMemcpyAsync(h_stats.data(), e->amg_stats, sizeof(MaskStats) * ns, hipMemcpyDeviceToHost, s));
+            ENG_HIP(e, hipStreamSynchronize(s));
+            std::vector<Cand> cand;
+            std::vector<int> cand_src;  // index into crop_bits
+            for (int k = 0; k < ns; ++k) {
+                const MaskStats& st = h_stats[k];
+                const float stab = (float)st.inter / (float)st.uni;  // 0/0 -> nan fails the filter like upstream
+                if (prm->stability_score_thresh > 0.0f && !(stab >= prm->stability_score_thresh)) continue;
+                Cand cd;
+                if (st.area > 0) { cd.box[0] = (float)st.x0; cd.box[1] = (float)st.y0; cd.box[2] = (float)st.x1; cd.box[3] = (float)st.y1; }
+                else { cd.box[0] = (float)box[0]; cd.box[1] = (float)box[1]; cd.box[2] = (float)box[0]; cd.box[3] = (float)box[1]; }
+                // is_box_near_crop_edge(atol=20): near a crop edge that is not also an image edge
+                const float cbx[4] = {(float)box[0], (float)box[1], (float)box[2], (float)box[3]};
+                const float obx[4] = {0.f, 0.f, (float)W, (float)H};
+                bool near = false;
+                for (int q = 0; q < 4; ++q) {
+                    const bool nc_ = std::fabs(cd.box[q] - cbx[q]) <= 20.0f, ni = std::fabs(cd.box[q] - obx[q]) <= 20.0f;
+                    near = near || (nc_ && !ni);
+                }
+                if (near) continue;
+                const int src = h_idx[k];
+                cd.iou = h_iou[src];
+                cd.stab = stab;
+                const int pk = src / M;
+                cd.pt[0] = crop_pts[2 * pk] + (float)box[0];
+                cd.pt[1] = crop_pts[2 * pk + 1] + (float)box[1];
+                for (int q = 0; q < 4; ++q) cd.crop[q] = box[q];
+                cd.area = st.area;
+                cd.bits_slot = 0;
+                cand.push_back(cd);
+                cand_src.push_back(k);
+            }
+            if (cand.empty()) continue;
+            std::vector<float> sc(cand.size());
+            for (size_t k = 0; k < cand.size(); ++k) sc[k] = cand[k].iou;
+            const std::vector<int> keep = nms_host(cand, sc, prm->box_nms_thresh);
+            TRY(acc_reserve(acc_used + keep.size()));
+            for (int k : keep) {
+                ENG_HIP(e, hipMemcpyAsync(e->amg_bits + acc_used * mask_words, crop_bits + (size_t)cand_src[k] * mask_words, mask_words * 4,
+                                          hipMemcpyDeviceToDevice, s));
+                Cand cd = cand[k];
+                cd.bits_slot = acc_used++;
+                all.push_back(cd);
+            }
+        }
+    }
+    std::vector<int> final_order(all.size());
+    std::iota(final_order.begin(), final_order.end(), 0);
+    if (nc > 1 && !all.empty()) {
+        std::vector<float> sc(all.size());
+        for (size_t k = 0; k < all.size(); ++k) {
+            const float a = (float)(all[k].crop[2] - all[k].crop[0]) * (float)(all[k].crop[3] - all[k].crop[1]);
+            sc[k] = 1.0f / a;
+        }
+        final_order = nms_host(all, sc, prm->crop_nms_thresh);
+    }
+    const int nf = (int)final_order.size();
+    if (nf > max_masks) {
+        *out_count = nf;
+        return eng_fail(e, SABER_ERR_CAPACITY, "amg_generate: " + std::to_string(nf) + " masks exceed max_masks=" + std::to_string(max_masks));
+    }
+    for (int k = 0; k < nf; ++k) {
+        const Cand& cd = all[final_order[k]];
+        ENG_HIP(e, hipMemcpyAsync(out_bits_dev + (size_t)k * mask_words, e->amg_bits + cd.bits_slot * mask_words, mask_words * 4, hipMemcpyDeviceToDevice, s));
+        saber_mask_meta& m = out_meta[k];
+        m.area = cd.area;
+        m.bbox_xywh[0] = cd.box[0]; m.bbox_xywh[1] = cd.box[1]; m.bbox_xywh[2] = cd.box[2] - cd.box[0]; m.bbox_xywh[3] = cd.box[3] - cd.box[1];
+        m.predicted_iou = cd.iou;
+        m.stability_score = cd.stab;
+        m.point_xy[0] = cd.pt[0]; m.point_xy[1] = cd.pt[1];
+        m.crop_box_xywh[0] = (float)cd.crop[0]; m.crop_box_xywh[1] = (float)cd.crop[1];
+        m.crop_box_xywh[2] = (float)(cd.crop[2] - cd.crop[0]); m.crop_box_xywh[3] = (float)(cd.crop[3] - cd.crop[1]);
+    }
+    ENG_HIP(e, hipStreamSynchronize(s));
+    *out_count = nf;
+    return SABER_OK;
+}

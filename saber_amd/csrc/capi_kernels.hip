@@ -1,0 +1,66 @@
+// Kernel-level C-ABI (include/saber_amd_kernels.h): thin wrappers over the launchers.
+#include <string>
+
+#include "../../include/saber_amd_kernels.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local std::string g_kerr;
+static int kfail(const char* m) { g_kerr = m ? m : "unknown"; return -1; }
+static int kcheck(const char* m) {
+    if (m) return kfail(m);
+    hipError_t st = hipGetLastError();
+    if (st != hipSuccess) return kfail(hipGetErrorString(st));
+    return 0;
+}
+
+extern "C" const char* saber_k_last_error(void) { return g_kerr.c_str(); }
+
+extern "C" int saber_k_init(int device_id) {
+    if (hipSetDevice(device_id) != hipSuccess) return kfail("hipSetDevice failed");
+    gemm_init_device();
+    hiera_attention_init_device();
+    image_ops_init_device();
+    return 0;
+}
+
+extern "C" int saber_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, const float* res, float* out_f32,
+                            uint16_t* out_bf16, int M, int N, int K, int act, int act_last, int pool4, int res_shift, int res_mod,
+                            void* stream) {
+    GemmParams p;
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.act_last = act_last; p.pool4 = pool4; p.res_shift = res_shift; p.res_mod = res_mod;
+    return kcheck(launch_gemm(p, (hipStream_t)stream));
+}
+
+extern "C" int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,
+                                 int rows, int C, int act, void* stream) {
+    LayerNormParams p;
+    p.x = x; p.ldx = C; p.gamma = gamma; p.beta = beta; p.eps = eps; p.out_f = out_f32; p.out_bf = out_bf16; p.ldo = C; p.rows = rows; p.C = C; p.act = act;
+    return kcheck(launch_layernorm(p, (hipStream_t)stream));
+}
+
+extern "C" int saber_k_hiera_attention(const uint16_t* qkv, uint16_t* out, int n_windows, int nk, int heads, int q_pool, void* stream) {
+    return kcheck(launch_hiera_attention(qkv, out, n_windows, nk, heads, q_pool, (hipStream_t)stream));
+}
+
+extern "C" int saber_k_dec_attention(const float* q, const float* k, const float* v, uint16_t* out, int B, int nq, int nk, int heads,
+                                     int hd, int k_shared, void* stream) {
+    const int64_t C = (int64_t)heads * hd;
+    return kcheck(launch_dec_attention(q, k, v, out, B, nq, nk, heads, hd, nq * C, k_shared ? 0 : nk * C, k_shared ? 0 : nk * C, nq * C,
+                                       (hipStream_t)stream));
+}
+
+extern "C" int saber_k_prepare(const void* img, int dtype, int H, int W, float* out, float* ws_dev, uint32_t* minmax_dev, void* stream) {
+    if (dtype == 0) return kcheck(launch_prepare_u16((const uint16_t*)img, H, W, out, ws_dev, minmax_dev, (hipStream_t)stream));
+    if (dtype == 1) return kcheck(launch_prepare_f32((const float*)img, H, W, out, ws_dev, minmax_dev, (hipStream_t)stream));
+    return kfail("prepare: dtype must be 0 (u16) or 1 (f32)");
+}
+
+extern "C" int saber_k_mask_post(const float* lowres, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H, int W, float thr,
+                                 float offset, uint32_t* bits, int32_t* stats, void* stream) {
+    return kcheck(launch_mask_post(lowres, nullptr, n, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits,
+                                   reinterpret_cast<MaskStats*>(stats), (hipStream_t)stream));
+}
+
+extern "C" int saber_k_perm_index(int y, int x, int stage) { return perm_index(y, x, stage); }

@@ -1,0 +1,61 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t bf16_t;  // storage type for bf16 in global memory
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 pair (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    __hip_bfloat162 v = __float22bfloat162_rn(make_float2(lo, hi));
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)(pack_bf16(x, 0.f) & 0xffffu); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Hiera token order used throughout the engine (DESIGN.md "token order"): for the
+// 256x256 stage-0 grid, index bits are [y7 y6 x7 x6][y5 y4 y3 x5 x4 x3][y2 x2][y1 x1][y0 x0].
+// Every attention window of every stage and every 2x2 pooling group is then a contiguous
+// run of rows; stage s uses (idx >> 2s).
+__host__ __device__ __forceinline__ int perm_index256(int y, int x) {
+    return (((y >> 6) * 4 + (x >> 6)) << 12) | ((((y >> 3) & 7) * 8 + ((x >> 3) & 7)) << 6) |
+           ((((y >> 2) & 1) * 2 + ((x >> 2) & 1)) << 4) | ((((y >> 1) & 1) * 2 + ((x >> 1) & 1)) << 2) |
+           ((y & 1) * 2 + (x & 1));
+}
+__host__ __device__ __forceinline__ void perm_coords256(int idx, int* y, int* x) {
+    int top = idx >> 12, mid = (idx >> 6) & 63;
+    int yy = ((top >> 2) << 6) | ((mid >> 3) << 3) | (((idx >> 5) & 1) << 2) | (((idx >> 3) & 1) << 1) | ((idx >> 1) & 1);
+    int xx = ((top & 3) << 6) | ((mid & 7) << 3) | (((idx >> 4) & 1) << 2) | (((idx >> 2) & 1) << 1) | (idx & 1);
+    *y = yy; *x = xx;
+}
+// generic: grid of side g = 256 >> s
+__host__ __device__ __forceinline__ int perm_index(int y, int x, int s) { return perm_index256(y << s, x << s) >> (2 * s); }
+__host__ __device__ __forceinline__ void perm_coords(int idx, int s, int* y, int* x) {
+    int yy, xx; perm_coords256(idx << (2 * s), &yy, &xx); *y = yy >> s; *x = xx >> s;
+}

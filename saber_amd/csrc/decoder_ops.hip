@@ -1,0 +1,506 @@
+// Prompt-encoder / mask-decoder side kernels.
+// These are the HBM / latency-bound pieces around the GEMMs of the two-way transformer:
+// point-prompt tokens, the mask_downscaling dense prompt (m2m pass), the tiny fp32
+// attentions over 8 tokens, the hypernetwork mask product, dynamic multimask selection,
+// and K8: fused bilinear upsample + threshold + stability counts + bbox + bit-packing.
+#include "common.h"
+#include "kernels.h"
+
+#define DEC_C 256
+
+// ------------------------------------------------------------------------------------------------
+// tokens[p] = [obj, iou, mask0..3, point(p), pad]  (8 x 256 fp32)
+__global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restrict__ pts, const int* __restrict__ labels, int P,
+                                                            PromptWeights w, float* __restrict__ tokens) {
+    const int p = blockIdx.x, c = threadIdx.x;
+    float* t = tokens + (int64_t)p * 8 * DEC_C;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k * DEC_C + c] = w.out_tokens[k * DEC_C + c];
+    const int label = labels ? labels[p] : 1;
+    float e = 0.f;
+    if (label >= 0) {
+        const float x = 2.0f * ((pts[2 * p] + 0.5f) / 1024.0f) - 1.0f;
+        const float y = 2.0f * ((pts[2 * p + 1] + 0.5f) / 1024.0f) - 1.0f;
+        const int f = c & 127;
+        const float a = 6.283185307179586f * (x * w.gauss[f] + y * w.gauss[128 + f]);
+        e = (c < 128 ? sinf(a) : cosf(a)) + w.point_embed[(label & 3) * DEC_C + c];
+    } else {
+        e = w.not_a_point[c];
+    }
+    t[6 * DEC_C + c] = e;
+    t[7 * DEC_C + c] = w.not_a_point[c];
+}
+
+const char* launch_prompt_tokens(const float* pts, const int* labels, int P, PromptWeights w, float* tokens, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, s, pts, labels, P, w, tokens);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask_downscaling (conv k2s2 1->4, LN2d, GELU, conv k2s2 4->16, LN2d, GELU, conv 1x1 16->256) fused
+// with "src = image_embed + dense".  One wave per token; lane owns 4 output channels.
+__global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
+                                                             const float* __restrict__ image_embed, const float* __restrict__ pos,
+                                                             MaskEmbedWeights w, float* __restrict__ src_f,
+                                                             bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (int64_t)P * 4096) return;
+    const int p = (int)(gw >> 12), tok = (int)(gw & 4095);
+    int ty, tx;
+    perm_coords(tok, 2, &ty, &tx);
+    const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4) * 256 + tx * 4;
+    float in[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(mp + r * 256);
+        in[r][0] = v.x; in[r][1] = v.y; in[r][2] = v.z; in[r][3] = v.w;
+    }
+    // stage 1: for each of the 2x2 positions, 4 channels
+    float h1[2][2][4];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            float v[4], mu = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = w.b1[c];
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) a += w.w1[c * 4 + ky * 2 + kx] * in[py * 2 + ky][px * 2 + kx];
+                v[c] = a;
+                mu += a;
+            }
+            mu *= 0.25f;
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) var += (v[c] - mu) * (v[c] - mu);
+            const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h1[py][px][c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
+        }
+    // stage 2: 16 channels from (4 ch x 2 x 2)
+    float h2[16], mu = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float a = w.b2[c];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) a += w.w2[((c * 4 + ci) * 2 + ky) * 2 + kx] * h1[ky][kx][ci];
+        h2[c] = a;
+        mu += a;
+    }
+    mu *= (1.0f / 16.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) var += (h2[c] - mu) * (h2[c] - mu);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) h2[c] = gelu_erf((h2[c] - mu) * rstd * w.g2[c] + w.be2[c]);
+    // stage 3: lane's 4 output channels
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j;
+        float a = w.b3[c];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += w.w3[c * 16 + k] * h2[k];
+        o[j] = a;
+    }
+    const float4 ie = *reinterpret_cast<const float4*>(image_embed + (int64_t)tok * DEC_C + lane * 4);
+    const float4 pe = *reinterpret_cast<const float4*>(pos + (int64_t)tok * DEC_C + lane * 4);
+    o[0] += ie.x; o[1] += ie.y; o[2] += ie.z; o[3] += ie.w;
+    const int64_t off = gw * DEC_C + lane * 4;
+    *reinterpret_cast<float4*>(src_f + off) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint2*>(src_bf + off) = make_uint2(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]));
+    *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_bf16(o[0] + pe.x, o[1] + pe.y), pack_bf16(o[2] + pe.z, o[3] + pe.w));
+}
+
+const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, const float* pos, MaskEmbedWeights w,
+                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(P * 1024), dim3(256), 0, s, mask_in, P, image_embed, pos, w, src_f, src_bf, srcpos_bf);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention, few keys (nk <= 8): one thread per (b, q row, head)
+template <int HDIM>
+__global__ __launch_bounds__(256) void dec_attn_fewkeys_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, bf16_t* __restrict__ out, int B, int nq,
+                                                               int nk, int heads, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                                                               int64_t o_bs) {
+    const int C = heads * HDIM;
+    const int64_t total = (int64_t)B * nq * heads;
+    const float scale = rsqrtf((float)HDIM);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int h = (int)(idx % heads);
+        const int64_t r = idx / heads;
+        const int qi = (int)(r % nq);
+        const int b = (int)(r / nq);
+        const float* qp = q + b * q_bs + (int64_t)qi * C + h * HDIM;
+        float qv[HDIM];
+#pragma unroll
+        for (int d = 0; d < HDIM; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + d);
+            qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
+        }
+        float sc[8], mx = -3.0e38f;
+        for (int j = 0; j < nk; ++j) {
+            const float* kp = k + b * k_bs + (int64_t)j * C + h * HDIM;
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDIM; ++d) a += qv[d] * kp[d];
+            sc[j] = a * scale;
+            mx = fmaxf(mx, sc[j]);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < nk; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+        const float inv = 1.0f / sum;
+        float o[HDIM];
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) o[d] = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            const float* vp = v + b * v_bs + (int64_t)j * C + h * HDIM;
+            const float pj = sc[j] * inv;
+#pragma unroll
+            for (int d = 0; d < HDIM; ++d) o[d] += pj * vp[d];
+        }
+        bf16_t* op = out + b * o_bs + (int64_t)qi * C + h * HDIM;
+#pragma unroll
+        for (int d = 0; d < HDIM; d += 4) *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf16(o[d], o[d + 1]), pack_bf16(o[d + 2], o[d + 3]));
+    }
+}
+
+// attention, few queries (nq <= 8) over many keys: one block per (b, head); each thread streams keys
+// with an online softmax for all nq queries, then the 256 partial states are merged through LDS.
+template <int HDIM>
+__global__ __launch_bounds__(256) void dec_attn_fewq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, bf16_t* __restrict__ out, int nq, int nk,
+                                                            int heads, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs) {
+    constexpr int NQ = 8;
+    __shared__ float red[4][NQ][HDIM + 2];
+    __shared__ float qs[NQ][HDIM];
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int C = heads * HDIM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float scale = rsqrtf((float)HDIM);
+    for (int i = tid; i < NQ * HDIM; i += 256) {
+        const int t = i / HDIM, d = i - t * HDIM;
+        qs[t][d] = t < nq ? q[b * q_bs + (int64_t)t * C + h * HDIM + d] * scale : 0.f;
+    }
+    __syncthreads();
+    float m[NQ], l[NQ], acc[NQ][HDIM];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        m[t] = -3.0e38f; l[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) acc[t][d] = 0.f;
+    }
+    for (int j = tid; j < nk; j += 256) {
+        const float* kp = k + b * k_bs + (int64_t)j * C + h * HDIM;
+        const float* vp = v + b * v_bs + (int64_t)j * C + h * HDIM;
+        float kv[HDIM], vv[HDIM];
+#pragma unroll
+        for (int d = 0; d < HDIM; d += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(kp + d);
+            const float4 c4 = *reinterpret_cast<const float4*>(vp + d);
+            kv[d] = a.x; kv[d + 1] = a.y; kv[d + 2] = a.z; kv[d + 3] = a.w;
+            vv[d] = c4.x; vv[d + 1] = c4.y; vv[d + 2] = c4.z; vv[d + 3] = c4.w;
+        }
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDIM; ++d) s += qs[t][d] * kv[d];
+            const float mn = fmaxf(m[t], s);
+            const float alpha = expf(m[t] - mn), e = expf(s - mn);
+            m[t] = mn;
+            l[t] = l[t] * alpha + e;
+#pragma unroll
+            for (int d = 0; d < HDIM; ++d) acc[t][d] = acc[t][d] * alpha + e * vv[d];
+        }
+    }
+    // merge across the wave, then across the 4 waves
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const float mw = wave_max(m[t]);
+        const float f = expf(m[t] - mw);
+        l[t] = wave_sum(l[t] * f);
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) acc[t][d] = wave_sum(acc[t][d] * f);
+        if (lane == 0) {
+            red[wave][t][HDIM] = mw;
+            red[wave][t][HDIM + 1] = l[t];
+#pragma unroll
+            for (int d = 0; d < HDIM; ++d) red[wave][t][d] = acc[t][d];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nq * HDIM; i += 256) {
+        const int t = i / HDIM, d = i - t * HDIM;
+        float mm = -3.0e38f;
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][t][HDIM]);
+        float L = 0.f, A = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            const float f = expf(red[w][t][HDIM] - mm);
+            L += red[w][t][HDIM + 1] * f;
+            A += red[w][t][d] * f;
+        }
+        out[b * o_bs + (int64_t)t * C + h * HDIM + d] = f2bf(A / L);
+    }
+}
+
+const char* launch_dec_attention(const float* q, const float* k, const float* v, bf16_t* out, int B, int nq, int nk, int heads,
+                                 int hd, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs, hipStream_t s) {
+    if (B <= 0) return nullptr;
+    if (hd != 16 && hd != 32) return "dec_attention: head_dim must be 16 or 32";
+    if (nk <= 8) {
+        const int64_t total = (int64_t)B * nq * heads;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 16384) blocks = 16384;
+        if (hd == 16) hipLaunchKernelGGL(dec_attn_fewkeys_kernel<16>, dim3(blocks), dim3(256), 0, s, q, k, v, out, B, nq, nk, heads, q_bs, k_bs, v_bs, o_bs);
+        else hipLaunchKernelGGL(dec_attn_fewkeys_kernel<32>, dim3(blocks), dim3(256), 0, s, q, k, v, out, B, nq, nk, heads, q_bs, k_bs, v_bs, o_bs);
+        return nullptr;
+    }
+    if (nq > 8) return "dec_attention: need nq <= 8 or nk <= 8";
+    if (hd != 16) return "dec_attention: few-query path is instantiated for head_dim 16";
+    hipLaunchKernelGGL(dec_attn_fewq_kernel<16>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, nq, nk, heads, q_bs, k_bs, v_bs, o_bs);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hypernetwork product: masks[p][k][y][x] = sum_c hyper[p][k][c] * up[p][perm(y,x)][c]
+__global__ __launch_bounds__(256) void mask_dot_kernel(const bf16_t* __restrict__ up, const float* __restrict__ hyper, int P,
+                                                       float* __restrict__ masks4) {
+    __shared__ float hs[4][32];
+    const int p = blockIdx.y;
+    if (threadIdx.x < 128) hs[threadIdx.x >> 5][threadIdx.x & 31] = hyper[(int64_t)p * 128 + threadIdx.x];
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;  // row-major output pixel
+    const int y = pix >> 8, x = pix & 255;
+    const int tok = perm_index256(y, x);
+    const uint4* src = reinterpret_cast<const uint4*>(up + ((int64_t)p * 65536 + tok) * 32);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 u = src[q];
+        const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(wds[j] << 16), hi = __uint_as_float(wds[j] & 0xffff0000u);
+            const int c = q * 8 + j * 2;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[kk] += hs[kk][c] * lo + hs[kk][c + 1] * hi;
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) masks4[((int64_t)p * 4 + kk) * 65536 + pix] = acc[kk];
+}
+
+const char* launch_mask_dot(const bf16_t* up, const float* hyper, int P, float* masks4, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(mask_dot_kernel, dim3(256, P), dim3(256), 0, s, up, hyper, P, masks4);
+    return nullptr;
+}
+
+// dynamic multimask: counts of mask0 > +delta, > -delta
+__global__ __launch_bounds__(256) void stab_count_kernel(const float* __restrict__ masks4, int* __restrict__ counts, float delta) {
+    const int p = blockIdx.y;
+    const float* m0 = masks4 + (int64_t)p * 4 * 65536;
+    int a = 0, u = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 65536; i += gridDim.x * 256) {
+        const float v = m0[i];
+        a += v > delta;
+        u += v > -delta;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); u += __shfl_xor(u, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[2 * p], a); atomicAdd(&counts[2 * p + 1], u); }
+}
+
+__global__ __launch_bounds__(256) void mask_select_kernel(const float* __restrict__ masks4, const float* __restrict__ iou4, int multimask,
+                                                          float* __restrict__ out_masks, float* __restrict__ out_iou,
+                                                          const int* __restrict__ counts, float thresh) {
+    const int p = blockIdx.y;
+    if (multimask) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * 65536 / 4; i += gridDim.x * 256)
+            reinterpret_cast<float4*>(out_masks + (int64_t)p * 3 * 65536)[i] =
+                reinterpret_cast<const float4*>(masks4 + ((int64_t)p * 4 + 1) * 65536)[i];
+        if (blockIdx.x == 0 && threadIdx.x < 3) out_iou[p * 3 + threadIdx.x] = iou4[p * 4 + 1 + threadIdx.x];
+        return;
+    }
+    const float ai = (float)counts[2 * p], au = (float)counts[2 * p + 1];
+    const float stab = au > 0.f ? ai / au : 1.0f;
+    int sel = 0;
+    if (!(stab >= thresh)) {
+        sel = 1;
+        float best = iou4[p * 4 + 1];
+        if (iou4[p * 4 + 2] > best) { best = iou4[p * 4 + 2]; sel = 2; }
+        if (iou4[p * 4 + 3] > best) { best = iou4[p * 4 + 3]; sel = 3; }
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 65536 / 4; i += gridDim.x * 256)
+        reinterpret_cast<float4*>(out_masks + (int64_t)p * 65536)[i] =
+            reinterpret_cast<const float4*>(masks4 + ((int64_t)p * 4 + sel) * 65536)[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_iou[p] = iou4[p * 4 + sel];
+}
+
+const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,
+                               int* counts_ws, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    if (!multimask) {
+        hipMemsetAsync(counts_ws, 0, sizeof(int) * 2 * P, s);
+        hipLaunchKernelGGL(stab_count_kernel, dim3(16, P), dim3(256), 0, s, masks4, counts_ws, 0.05f);
+    }
+    hipLaunchKernelGGL(mask_select_kernel, dim3(16, P), dim3(256), 0, s, masks4, iou4, multimask, out_masks, out_iou, counts_ws, 0.98f);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ K8
+// For each selected low-res mask: bilinear-upsample (align_corners=False) to the crop size, compare with
+// thr / thr+-offset, count, track the bounding box, and bit-pack the >thr mask into full-image rows.
+// One block per (mask, band of 4 full-image rows); a wave covers 64 consecutive x of one row, so
+// __ballot gives two packed 32-bit words directly.  fp32 full-res logits never touch HBM.
+__global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ lowres, const int* __restrict__ idx, int crop_x0,
+                                                        int crop_y0, int crop_w, int crop_h, int H, int W, float thr, float offset,
+                                                        uint32_t* __restrict__ bits, MaskStats* __restrict__ stats) {
+    const int mi = blockIdx.y;
+    const float* src = lowres + (int64_t)(idx ? idx[mi] : mi) * 65536;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = blockIdx.x * 4 + wave;
+    if (y >= H) return;
+    const int W32 = (W + 31) >> 5;
+    uint32_t* brow = bits + ((int64_t)mi * H + y) * W32;
+    const int cy = y - crop_y0;
+    const bool row_in = cy >= 0 && cy < crop_h;
+    const float sy_scale = 256.0f / (float)crop_h, sx_scale = 256.0f / (float)crop_w;
+    int y0i = 0, y1i = 0;
+    float ly = 0.f;
+    if (row_in) {
+        float sy = ((float)cy + 0.5f) * sy_scale - 0.5f;
+        sy = fmaxf(sy, 0.f);
+        y0i = min((int)sy, 255);
+        y1i = min(y0i + 1, 255);
+        ly = sy - (float)y0i;
+    }
+    int area = 0, inter = 0, uni = 0, xmin = 1 << 30, xmax = -1;
+    for (int xb = 0; xb < W; xb += 64) {
+        const int x = xb + lane;
+        const int cx = x - crop_x0;
+        bool on = false, hi = false, lo = false;
+        if (row_in && x < W && cx >= 0 && cx < crop_w) {
+            float sx = ((float)cx + 0.5f) * sx_scale - 0.5f;
+            sx = fmaxf(sx, 0.f);
+            const int x0i = min((int)sx, 255);
+            const int x1i = min(x0i + 1, 255);
+            const float lx = sx - (float)x0i;
+            const float v00 = src[y0i * 256 + x0i], v01 = src[y0i * 256 + x1i];
+            const float v10 = src[y1i * 256 + x0i], v11 = src[y1i * 256 + x1i];
+            const float v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+            on = v > thr;
+            hi = v > thr + offset;
+            lo = v > thr - offset;
+        }
+        const unsigned long long bm = __ballot(on);
+        area += __popcll(bm);
+        inter += __popcll(__ballot(hi));
+        uni += __popcll(__ballot(lo));
+        if (bm) {
+            xmin = min(xmin, xb + (int)__ffsll((long long)bm) - 1);
+            xmax = max(xmax, xb + 63 - (int)__clzll((long long)bm));
+        }
+        if (lane == 0) {
+            const int wd = xb >> 5;
+            brow[wd] = (uint32_t)(bm & 0xffffffffull);
+            if (wd + 1 < W32) brow[wd + 1] = (uint32_t)(bm >> 32);
+        }
+    }
+    if (lane == 0 && (uni | area | inter)) {
+        MaskStats* st = stats + mi;
+        if (area) {
+            atomicAdd(&st->area, area);
+            atomicMin(&st->x0, xmin);
+            atomicMax(&st->x1, xmax);
+            atomicMin(&st->y0, y);
+            atomicMax(&st->y1, y);
+        }
+        if (inter) atomicAdd(&st->inter, inter);
+        if (uni) atomicAdd(&st->uni, uni);
+    }
+}
+
+__global__ void mask_stats_init_kernel(MaskStats* stats, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { MaskStats s; s.area = 0; s.inter = 0; s.uni = 0; s.x0 = 1 << 30; s.y0 = 1 << 30; s.x1 = -1; s.y1 = -1; s.pad = 0; stats[i] = s; }
+}
+
+const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
+                             int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s) {
+    if (n <= 0) return nullptr;
+    if (crop_w <= 0 || crop_h <= 0) return "mask_post: empty crop";
+    hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, n);
+    hipLaunchKernelGGL(mask_post_kernel, dim3((H + 3) / 4, n), dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr,
+                       offset, bits, stats);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// label plane of reference slice_by_slice (saber/segmenters/propagation.py:185-186): masks are painted
+// in list order with value (position+1); a later mask overwrites an earlier one.
+__global__ __launch_bounds__(256) void label_plane_kernel(const uint32_t* __restrict__ bits, const int* __restrict__ order, int n, int H,
+                                                          int W, uint16_t* __restrict__ plane) {
+    const int W32 = (W + 31) >> 5;
+    const int64_t words = (int64_t)H * W32;
+    for (int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x; wi < words; wi += (int64_t)gridDim.x * 256) {
+        const int y = (int)(wi / W32), xw = (int)(wi - (int64_t)y * W32);
+        uint16_t lab[32];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) lab[b] = 0;
+        for (int i = 0; i < n; ++i) {
+            const int mi = order ? order[i] : i;
+            const uint32_t wd = bits[(int64_t)mi * words + wi];
+            if (wd) {
+#pragma unroll
+                for (int b = 0; b < 32; ++b) if ((wd >> b) & 1u) lab[b] = (uint16_t)(i + 1);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            const int x = xw * 32 + b;
+            if (x < W) plane[(int64_t)y * W + x] = lab[b];
+        }
+    }
+}
+
+const char* launch_label_plane(const uint32_t* bits, const int* order, int n, int H, int W, uint16_t* plane, hipStream_t s) {
+    const int64_t words = (int64_t)H * ((W + 31) >> 5);
+    int blocks = (int)((words + 255) / 256);
+    hipLaunchKernelGGL(label_plane_kernel, dim3(blocks), dim3(256), 0, s, bits, order, n, H, W, plane);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpermute_nchw_kernel(const float* __restrict__ tok, int C, int stage, float* __restrict__ out) {
+    const int g = 256 >> stage;
+    const int64_t total = (int64_t)g * g * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i / ((int64_t)g * g));
+        const int r = (int)(i - (int64_t)c * g * g);
+        const int y = r / g, x = r - y * g;
+        out[i] = tok[(int64_t)perm_index(y, x, stage) * C + c];
+    }
+}
+const char* launch_unpermute_nchw(const float* tok, int C, int stage, float* out, hipStream_t s) {
+    const int g = 256 >> stage;
+    const int64_t total = (int64_t)g * g * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(unpermute_nchw_kernel, dim3(blocks), dim3(256), 0, s, tok, C, stage, out);
+    return nullptr;
+}

@@ -1,0 +1,110 @@
+// Engine state shared by engine.hip (encode / decode) and amg.hip (automatic mask generation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/saber_amd.h"
+#include "kernels.h"
+
+struct BlockSpec { int din, dout, heads, window, q_stride; };
+
+struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
+
+struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0; };
+struct LnW { const float* g = nullptr; const float* b = nullptr; };
+
+struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
+
+struct AttnW { LinW q, k, v, o; };
+struct DecLayerW { AttnW self_attn, t2i, i2t; LnW n1, n2, n3, n4; LinW mlp1, mlp2; };
+
+struct saber_engine {
+    int device = 0;
+    std::string trunk;
+    int max_images = 1, max_prompts = 64;
+    std::string err;
+    bool finalized = false;
+
+    // model description (Hiera-L only in this build)
+    int embed_dim = 0;
+    std::vector<BlockSpec> blocks;
+    std::vector<int> stage_ends;
+    std::vector<int> stage_dims;
+
+    std::map<std::string, HostTensor> host_w;
+    std::vector<void*> allocs;
+
+    // encoder weights
+    const float *pe_wt = nullptr, *pe_bias = nullptr, *pos_table = nullptr;
+    std::vector<BlockW> bw;
+    LinW neck3, neck2, s1, s0;  // lateral 32^2, (64^2 + no_mem), composed conv_s1.neck, composed conv_s0.neck
+
+    // decoder weights
+    PromptWeights pw{};
+    MaskEmbedWeights mw{};
+    const float* no_mask_embed = nullptr;
+    const float* dense_pe = nullptr;  // [4096][256], engine token order
+    DecLayerW dl[2];
+    AttnW final_attn; LnW final_ln;
+    LinW dc1, dc2; LnW up_ln;
+    LinW hyper[3];  // stacked over the 4 mask tokens (batched GEMM)
+    LinW iou_head[3], obj_head[3];
+
+    // encoder workspace
+    float *pix = nullptr, *xa = nullptr, *xb = nullptr, *lat3 = nullptr;
+    bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    bf16_t* sb[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* crops_dev = nullptr;
+    // resident features per slot
+    float *emb = nullptr, *fs1 = nullptr, *fs0 = nullptr;
+    // per-slot first-pass shared tensors (src0 = image_embed + no_mask_embed)
+    float* src0_f = nullptr; bf16_t *src0_bf = nullptr, *src0pos_bf = nullptr;
+    float *k0 = nullptr, *v0 = nullptr, *qi0 = nullptr;
+    std::vector<char> slot_valid, slot_shared_valid;
+
+    // decoder workspace (per chunk of max_prompts prompts)
+    float *tok_pe = nullptr, *queries = nullptr, *tq = nullptr, *tk = nullptr, *tv = nullptr;
+    bf16_t *t_bf0 = nullptr, *t_bf1 = nullptr, *t_att = nullptr, *t_hid = nullptr;
+    float *keys = nullptr, *kp = nullptr, *vp = nullptr, *qp = nullptr;
+    bf16_t *keys_bf = nullptr, *keyspos_bf = nullptr, *iatt_bf = nullptr;
+    float* u1 = nullptr; bf16_t *u1b = nullptr, *up2 = nullptr;
+    float *masks4 = nullptr, *hyper_out = nullptr, *iou4 = nullptr, *head_tmp = nullptr;
+    bf16_t *head_bf0 = nullptr, *head_bf1 = nullptr;
+    int* counts_ws = nullptr;
+    float* dec_out_masks = nullptr;  // [max_prompts][3][65536] staging when caller passes NULL
+    float* dec_out_iou = nullptr;
+
+    // prepare workspace
+    float* prep_ws = nullptr; size_t prep_ws_elems = 0; unsigned int* prep_minmax = nullptr;
+
+    // AMG workspace (grown on demand)
+    float *amg_prep = nullptr; size_t amg_prep_elems = 0;
+    float *amg_pts = nullptr, *amg_low1 = nullptr, *amg_low2 = nullptr, *amg_iou1 = nullptr, *amg_iou2 = nullptr, *amg_pts2 = nullptr;
+    size_t amg_prompts_cap = 0;
+    uint32_t* amg_bits = nullptr; size_t amg_bits_words = 0;        // masks kept across crops (persistent, grown on demand)
+    uint32_t* amg_crop_bits = nullptr; size_t amg_crop_words = 0;   // one crop's pred_iou survivors
+    MaskStats* amg_stats = nullptr; int* amg_idx = nullptr; size_t amg_stats_cap = 0;
+    int* order_dev = nullptr; size_t order_cap = 0;
+};
+
+int eng_fail(saber_engine* e, int code, const std::string& msg);
+#define ENG_HIP(e, call)                                                                              \
+    do {                                                                                              \
+        hipError_t _st = (call);                                                                      \
+        if (_st != hipSuccess) return eng_fail((e), SABER_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st)); \
+    } while (0)
+#define ENG_K(e, call)                                                   \
+    do {                                                                 \
+        const char* _m = (call);                                         \
+        if (_m) return eng_fail((e), SABER_ERR_INVALID, _m);             \
+    } while (0)
+
+// internal entry points used by amg.hip
+int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crops_host, int n, int slot0, hipStream_t s);
+int eng_decode(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask, const float* mask_in_dev,
+               float* out_lowres, float* out_iou, float* out_obj, hipStream_t s);
+template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count);
+int eng_alloc_bytes(saber_engine* e, void** p, size_t bytes);
+void eng_free(saber_engine* e, void* p);

@@ -1,0 +1,808 @@
+// Engine: weights, workspaces, the batched Hiera-L encoder pass and the batched prompt decoder.
+// C-ABI entry points are declared in include/saber_amd.h (each cites the reference interface it replaces).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <utility>
+
+#include "common.h"
+
+static thread_local std::string g_create_err;
+
+int eng_fail(saber_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg; else g_create_err = msg;
+    return code;
+}
+
+int eng_alloc_bytes(saber_engine* e, void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t st = hipMalloc(p, bytes);
+    if (st != hipSuccess) return eng_fail(e, SABER_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(st));
+    e->allocs.push_back(*p);
+    return SABER_OK;
+}
+void eng_free(saber_engine* e, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < e->allocs.size(); ++i)
+        if (e->allocs[i] == p) { e->allocs.erase(e->allocs.begin() + i); break; }
+    (void)hipFree(p);
+}
+template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count) { return eng_alloc_bytes(e, reinterpret_cast<void**>(p), count * sizeof(T)); }
+template int eng_alloc<float>(saber_engine*, float**, size_t);
+template int eng_alloc<bf16_t>(saber_engine*, bf16_t**, size_t);
+template int eng_alloc<int>(saber_engine*, int**, size_t);
+template int eng_alloc<uint32_t>(saber_engine*, uint32_t**, size_t);
+template int eng_alloc<MaskStats>(saber_engine*, MaskStats**, size_t);
+
+#define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
+
+// ------------------------------------------------------------------------------------------------ model description
+static void hiera_large_spec(saber_engine* e) {
+    const int stages[4] = {2, 6, 36, 4};
+    const int window_spec[4] = {8, 4, 16, 8};
+    const int global_blocks[3] = {23, 33, 43};
+    e->embed_dim = 144;
+    e->blocks.clear(); e->stage_ends.clear(); e->stage_dims.clear();
+    int idx = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int dim = 144 << s, heads = 2 << s;
+        e->stage_dims.push_back(dim);
+        for (int b = 0; b < stages[s]; ++b, ++idx) {
+            BlockSpec bs;
+            const bool first = s > 0 && b == 0;
+            bs.dout = dim;
+            bs.din = first ? dim / 2 : dim;
+            bs.heads = heads;
+            bs.window = first ? window_spec[s - 1] : window_spec[s];
+            for (int g : global_blocks) if (g == idx) bs.window = 0;
+            bs.q_stride = first ? 2 : 1;
+            e->blocks.push_back(bs);
+        }
+        e->stage_ends.push_back(idx - 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI: lifecycle
+extern "C" int saber_engine_create(int device_id, const char* trunk, int max_images, int max_prompts, saber_engine** out) {
+    if (!out) return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: out is NULL");
+    *out = nullptr;
+    if (!trunk) return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: trunk is NULL");
+    const std::string t(trunk);
+    if (t != "tiny" && t != "small" && t != "base" && t != "large")
+        return eng_fail(nullptr, SABER_ERR_INVALID, "cfg must be one of tiny/small/base/large, got '" + t + "'");
+    if (t != "large")
+        return eng_fail(nullptr, SABER_ERR_INVALID,
+                        "HIP engine: trunk '" + t + "' is not built yet (its 14x14 / 7x7 windows do not tile the engine's token order); use 'large'");
+    if (max_images < 1 || max_images > 64 || max_prompts < 1 || max_prompts > 1024)
+        return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: max_images must be 1..64 and max_prompts 1..1024");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return eng_fail(nullptr, SABER_ERR_HIP, "no HIP device visible: the MI355X engine cannot run");
+    if (device_id < 0 || device_id >= ndev) return eng_fail(nullptr, SABER_ERR_INVALID, "device_id out of range");
+    if (hipSetDevice(device_id) != hipSuccess) return eng_fail(nullptr, SABER_ERR_HIP, "hipSetDevice failed");
+    saber_engine* e = new saber_engine();
+    e->device = device_id;
+    e->trunk = t;
+    e->max_images = max_images;
+    e->max_prompts = max_prompts;
+    hiera_large_spec(e);
+    gemm_init_device();
+    hiera_attention_init_device();
+    image_ops_init_device();
+    *out = e;
+    return SABER_OK;
+}
+
+extern "C" void saber_engine_destroy(saber_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" const char* saber_last_error(const saber_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int saber_engine_set_weight(saber_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!name || !host || !shape || ndim < 1 || ndim > 4) return eng_fail(e, SABER_ERR_INVALID, "set_weight: bad argument");
+    if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "set_weight after finalize");
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return eng_fail(e, SABER_ERR_INVALID, "set_weight: non-positive dim"); t.shape.push_back(shape[i]); n *= shape[i]; }
+    t.data.assign(host, host + n);
+    e->host_w[name] = std::move(t);
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ finalize helpers
+static inline bf16_t host_f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+struct Finalizer {
+    saber_engine* e;
+    int status = SABER_OK;
+    const HostTensor* get(const std::string& name, std::vector<int64_t> shape) {
+        if (status != SABER_OK) return nullptr;
+        auto it = e->host_w.find(name);
+        if (it == e->host_w.end()) { status = eng_fail(e, SABER_ERR_INVALID, "missing weight tensor '" + name + "'"); return nullptr; }
+        if (it->second.shape != shape) {
+            std::string got = "(", want = "(";
+            for (auto d : it->second.shape) got += std::to_string(d) + ",";
+            for (auto d : shape) want += std::to_string(d) + ",";
+            status = eng_fail(e, SABER_ERR_INVALID, "weight '" + name + "' has shape " + got + ") expected " + want + ")");
+            return nullptr;
+        }
+        return &it->second;
+    }
+    const float* up_f32(const std::vector<float>& v) {
+        if (status != SABER_OK) return nullptr;
+        float* d = nullptr;
+        status = eng_alloc(e, &d, v.size());
+        if (status != SABER_OK) return nullptr;
+        if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { status = eng_fail(e, SABER_ERR_HIP, "weight upload failed"); return nullptr; }
+        return d;
+    }
+    const bf16_t* up_bf16(const std::vector<float>& v) {
+        if (status != SABER_OK) return nullptr;
+        std::vector<bf16_t> h(v.size());
+        for (size_t i = 0; i < v.size(); ++i) h[i] = host_f2bf(v[i]);
+        bf16_t* d = nullptr;
+        status = eng_alloc(e, &d, h.size());
+        if (status != SABER_OK) return nullptr;
+        if (hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { status = eng_fail(e, SABER_ERR_HIP, "weight upload failed"); return nullptr; }
+        return d;
+    }
+    LinW lin(const std::string& prefix, int out, int in) {
+        LinW l; l.out = out; l.in = in;
+        const HostTensor* w = get(prefix + ".weight", {out, in});
+        const HostTensor* b = get(prefix + ".bias", {out});
+        if (!w || !b) return l;
+        l.w = up_bf16(w->data); l.b = up_f32(b->data);
+        return l;
+    }
+    LinW lin_conv1x1(const std::string& prefix, int out, int in) {
+        LinW l; l.out = out; l.in = in;
+        const HostTensor* w = get(prefix + ".weight", {out, in, 1, 1});
+        const HostTensor* b = get(prefix + ".bias", {out});
+        if (!w || !b) return l;
+        l.w = up_bf16(w->data); l.b = up_f32(b->data);
+        return l;
+    }
+    LnW ln(const std::string& prefix, int c) {
+        LnW l;
+        const HostTensor* g = get(prefix + ".weight", {c});
+        const HostTensor* b = get(prefix + ".bias", {c});
+        if (!g || !b) return l;
+        l.g = up_f32(g->data); l.b = up_f32(b->data);
+        return l;
+    }
+    AttnW attn(const std::string& prefix, int internal) {
+        AttnW a;
+        a.q = lin(prefix + ".q_proj", internal, 256);
+        a.k = lin(prefix + ".k_proj", internal, 256);
+        a.v = lin(prefix + ".v_proj", internal, 256);
+        a.o = lin(prefix + ".out_proj", 256, internal);
+        return a;
+    }
+};
+
+// bicubic (A = -0.75, align_corners=False) sample of a (h,w) plane at output (oy, ox) of an (H,W) grid
+static double cubic_w(double t, int k) {
+    const double A = -0.75;
+    switch (k) {
+        case 0: { const double x = t + 1.0; return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A; }
+        case 1: return ((A + 2.0) * t - (A + 3.0)) * t * t + 1.0;
+        case 2: { const double x = 1.0 - t; return ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0; }
+        default: { const double x = 2.0 - t; return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A; }
+    }
+}
+static double bicubic_sample(const float* plane, int h, int w, int oy, int ox, int H, int W) {
+    const double sy = (double)h / H * (oy + 0.5) - 0.5, sx = (double)w / W * (ox + 0.5) - 0.5;
+    const int iy = (int)std::floor(sy), ix = (int)std::floor(sx);
+    const double ty = sy - iy, tx = sx - ix;
+    double acc = 0.0;
+    for (int j = 0; j < 4; ++j) {
+        const int yy = std::min(std::max(iy - 1 + j, 0), h - 1);
+        double row = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            const int xx = std::min(std::max(ix - 1 + i, 0), w - 1);
+            row += cubic_w(tx, i) * plane[yy * w + xx];
+        }
+        acc += cubic_w(ty, j) * row;
+    }
+    return acc;
+}
+
+extern "C" int saber_engine_finalize(saber_engine* e) {
+    if (!e) return SABER_ERR_INVALID;
+    if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "finalize called twice");
+    ENG_HIP(e, hipSetDevice(e->device));
+    Finalizer F{e};
+    const int C0 = e->embed_dim;
+    const std::string t = "image_encoder.trunk.";
+    // ---- patch embed: wt[tap][c]
+    {
+        const HostTensor* w = F.get(t + "patch_embed.proj.weight", {C0, 3, 7, 7});
+        const HostTensor* b = F.get(t + "patch_embed.proj.bias", {C0});
+        const HostTensor* pe = F.get(t + "pos_embed", {1, C0, 7, 7});
+        const HostTensor* pw = F.get(t + "pos_embed_window", {1, C0, 8, 8});
+        if (F.status != SABER_OK) return F.status;
+        std::vector<float> wt((size_t)147 * C0);
+        for (int c = 0; c < C0; ++c)
+            for (int tap = 0; tap < 147; ++tap) wt[(size_t)tap * C0 + c] = w->data[(size_t)c * 147 + tap];
+        e->pe_wt = F.up_f32(wt);
+        e->pe_bias = F.up_f32(b->data);
+        std::vector<float> pos((size_t)65536 * C0);
+        for (int y = 0; y < 256; ++y)
+            for (int x = 0; x < 256; ++x) {
+                const size_t row = (size_t)perm_index256(y, x);
+                for (int c = 0; c < C0; ++c)
+                    pos[row * C0 + c] = (float)bicubic_sample(pe->data.data() + (size_t)c * 49, 7, 7, y, x, 256, 256) +
+                                        pw->data[(size_t)c * 64 + (y & 7) * 8 + (x & 7)];
+            }
+        e->pos_table = F.up_f32(pos);
+    }
+    // ---- blocks
+    e->bw.resize(e->blocks.size());
+    for (size_t i = 0; i < e->blocks.size(); ++i) {
+        const BlockSpec& bs = e->blocks[i];
+        const std::string b = t + "blocks." + std::to_string(i) + ".";
+        BlockW& w = e->bw[i];
+        w.n1 = F.ln(b + "norm1", bs.din);
+        w.qkv = F.lin(b + "attn.qkv", 3 * bs.dout, bs.din);
+        w.proj = F.lin(b + "attn.proj", bs.dout, bs.dout);
+        w.n2 = F.ln(b + "norm2", bs.dout);
+        w.fc1 = F.lin(b + "mlp.layers.0", 4 * bs.dout, bs.dout);
+        w.fc2 = F.lin(b + "mlp.layers.1", bs.dout, 4 * bs.dout);
+        if (bs.din != bs.dout) w.sc = F.lin(b + "proj", bs.dout, bs.din);
+        if (F.status != SABER_OK) return F.status;
+    }
+    // ---- neck (+ conv_s0 / conv_s1 composed with their lateral convs; no_mem_embed folded into the 64^2 bias)
+    {
+        const std::string nk = "image_encoder.neck.convs.";
+        const int dims[4] = {C0 * 8, C0 * 4, C0 * 2, C0};
+        const HostTensor *nw[4], *nb[4];
+        for (int i = 0; i < 4; ++i) {
+            nw[i] = F.get(nk + std::to_string(i) + ".conv.weight", {256, dims[i], 1, 1});
+            nb[i] = F.get(nk + std::to_string(i) + ".conv.bias", {256});
+        }
+        const HostTensor* nm = F.get("no_mem_embed", {1, 1, 256});
+        const HostTensor* s0w = F.get("sam_mask_decoder.conv_s0.weight", {32, 256, 1, 1});
+        const HostTensor* s0b = F.get("sam_mask_decoder.conv_s0.bias", {32});
+        const HostTensor* s1w = F.get("sam_mask_decoder.conv_s1.weight", {64, 256, 1, 1});
+        const HostTensor* s1b = F.get("sam_mask_decoder.conv_s1.bias", {64});
+        if (F.status != SABER_OK) return F.status;
+        e->neck3.out = 256; e->neck3.in = dims[0]; e->neck3.w = F.up_bf16(nw[0]->data); e->neck3.b = F.up_f32(nb[0]->data);
+        std::vector<float> b2(nb[1]->data);
+        for (int c = 0; c < 256; ++c) b2[c] += nm->data[c];
+        e->neck2.out = 256; e->neck2.in = dims[1]; e->neck2.w = F.up_bf16(nw[1]->data); e->neck2.b = F.up_f32(b2);
+        auto compose = [&](const HostTensor* sw, const HostTensor* sbias, int so, const HostTensor* lw, const HostTensor* lb, int li, LinW* out) {
+            std::vector<float> w((size_t)so * li), b(so);
+            for (int o = 0; o < so; ++o) {
+                double bb = sbias->data[o];
+                for (int m = 0; m < 256; ++m) bb += (double)sw->data[(size_t)o * 256 + m] * lb->data[m];
+                b[o] = (float)bb;
+                for (int k = 0; k < li; ++k) {
+                    double a = 0.0;
+                    for (int m = 0; m < 256; ++m) a += (double)sw->data[(size_t)o * 256 + m] * lw->data[(size_t)m * li + k];
+                    w[(size_t)o * li + k] = (float)a;
+                }
+            }
+            out->out = so; out->in = li; out->w = F.up_bf16(w); out->b = F.up_f32(b);
+        };
+        compose(s1w, s1b, 64, nw[2], nb[2], dims[2], &e->s1);
+        compose(s0w, s0b, 32, nw[3], nb[3], dims[3], &e->s0);
+    }
+    // ---- prompt encoder
+    {
+        const std::string p = "sam_prompt_encoder.";
+        const HostTensor* g = F.get(p + "pe_layer.positional_encoding_gaussian_matrix", {2, 128});
+        const HostTensor* nap = F.get(p + "not_a_point_embed.weight", {1, 256});
+        const HostTensor* nme = F.get(p + "no_mask_embed.weight", {1, 256});
+        std::vector<float> pemb;
+        for (int k = 0; k < 4; ++k) {
+            const HostTensor* pk = F.get(p + "point_embeddings." + std::to_string(k) + ".weight", {1, 256});
+            if (pk) pemb.insert(pemb.end(), pk->data.begin(), pk->data.end());
+        }
+        const std::string d = "sam_mask_decoder.";
+        const HostTensor* obj = F.get(d + "obj_score_token.weight", {1, 256});
+        const HostTensor* iou = F.get(d + "iou_token.weight", {1, 256});
+        const HostTensor* mt = F.get(d + "mask_tokens.weight", {4, 256});
+        if (F.status != SABER_OK) return F.status;
+        std::vector<float> ot;
+        ot.insert(ot.end(), obj->data.begin(), obj->data.end());
+        ot.insert(ot.end(), iou->data.begin(), iou->data.end());
+        ot.insert(ot.end(), mt->data.begin(), mt->data.end());
+        e->pw.gauss = F.up_f32(g->data);
+        e->pw.point_embed = F.up_f32(pemb);
+        e->pw.not_a_point = F.up_f32(nap->data);
+        e->pw.out_tokens = F.up_f32(ot);
+        e->no_mask_embed = F.up_f32(nme->data);
+        // dense PE on the 64x64 grid in engine order
+        std::vector<float> dpe((size_t)4096 * 256);
+        for (int ty = 0; ty < 64; ++ty)
+            for (int tx = 0; tx < 64; ++tx) {
+                const size_t row = (size_t)perm_index(ty, tx, 2);
+                const float x = 2.0f * ((tx + 0.5f) / 64.0f) - 1.0f, y = 2.0f * ((ty + 0.5f) / 64.0f) - 1.0f;
+                for (int f = 0; f < 128; ++f) {
+                    const float a = 6.283185307179586f * (x * g->data[f] + y * g->data[128 + f]);
+                    dpe[row * 256 + f] = sinf(a);
+                    dpe[row * 256 + 128 + f] = cosf(a);
+                }
+            }
+        e->dense_pe = F.up_f32(dpe);
+        const std::string m = p + "mask_downscaling.";
+        const HostTensor *w1 = F.get(m + "0.weight", {4, 1, 2, 2}), *b1 = F.get(m + "0.bias", {4});
+        const HostTensor *g1 = F.get(m + "1.weight", {4}), *be1 = F.get(m + "1.bias", {4});
+        const HostTensor *w2 = F.get(m + "3.weight", {16, 4, 2, 2}), *b2 = F.get(m + "3.bias", {16});
+        const HostTensor *g2 = F.get(m + "4.weight", {16}), *be2 = F.get(m + "4.bias", {16});
+        const HostTensor *w3 = F.get(m + "6.weight", {256, 16, 1, 1}), *b3 = F.get(m + "6.bias", {256});
+        if (F.status != SABER_OK) return F.status;
+        e->mw.w1 = F.up_f32(w1->data); e->mw.b1 = F.up_f32(b1->data); e->mw.g1 = F.up_f32(g1->data); e->mw.be1 = F.up_f32(be1->data);
+        e->mw.w2 = F.up_f32(w2->data); e->mw.b2 = F.up_f32(b2->data); e->mw.g2 = F.up_f32(g2->data); e->mw.be2 = F.up_f32(be2->data);
+        e->mw.w3 = F.up_f32(w3->data); e->mw.b3 = F.up_f32(b3->data);
+    }
+    // ---- mask decoder
+    {
+        const std::string d = "sam_mask_decoder.";
+        for (int l = 0; l < 2; ++l) {
+            const std::string L = d + "transformer.layers." + std::to_string(l) + ".";
+            DecLayerW& w = e->dl[l];
+            w.self_attn = F.attn(L + "self_attn", 256);
+            w.n1 = F.ln(L + "norm1", 256);
+            w.t2i = F.attn(L + "cross_attn_token_to_image", 128);
+            w.n2 = F.ln(L + "norm2", 256);
+            w.mlp1 = F.lin(L + "mlp.layers.0", 2048, 256);
+            w.mlp2 = F.lin(L + "mlp.layers.1", 256, 2048);
+            w.n3 = F.ln(L + "norm3", 256);
+            w.n4 = F.ln(L + "norm4", 256);
+            w.i2t = F.attn(L + "cross_attn_image_to_token", 128);
+        }
+        e->final_attn = F.attn(d + "transformer.final_attn_token_to_image", 128);
+        e->final_ln = F.ln(d + "transformer.norm_final_attn", 256);
+        // ConvTranspose2d(k2,s2) as a GEMM: N index = (ky*2+kx)*Cout + co
+        auto convT = [&](const std::string& prefix, int cin, int cout, LinW* out) {
+            const HostTensor* w = F.get(prefix + ".weight", {cin, cout, 2, 2});
+            const HostTensor* b = F.get(prefix + ".bias", {cout});
+            if (!w || !b) return;
+            std::vector<float> wt((size_t)4 * cout * cin), bt((size_t)4 * cout);
+            for (int pos = 0; pos < 4; ++pos)
+                for (int co = 0; co < cout; ++co) {
+                    bt[(size_t)pos * cout + co] = b->data[co];
+                    for (int ci = 0; ci < cin; ++ci)
+                        wt[((size_t)pos * cout + co) * cin + ci] = w->data[(((size_t)ci * cout + co) * 2 + (pos >> 1)) * 2 + (pos & 1)];
+                }
+            out->out = 4 * cout; out->in = cin; out->w = F.up_bf16(wt); out->b = F.up_f32(bt);
+        };
+        convT(d + "output_upscaling.0", 256, 64, &e->dc1);
+        e->up_ln = F.ln(d + "output_upscaling.1", 64);
+        convT(d + "output_upscaling.3", 64, 32, &e->dc2);
+        const int hdims[3][2] = {{256, 256}, {256, 256}, {32, 256}};
+        for (int l = 0; l < 3; ++l) {
+            std::vector<float> w, b;
+            for (int k = 0; k < 4; ++k) {
+                const std::string pfx = d + "output_hypernetworks_mlps." + std::to_string(k) + ".layers." + std::to_string(l);
+                const HostTensor* wk = F.get(pfx + ".weight", {hdims[l][0], hdims[l][1]});
+                const HostTensor* bk = F.get(pfx + ".bias", {hdims[l][0]});
+                if (!wk || !bk) return F.status;
+                w.insert(w.end(), wk->data.begin(), wk->data.end());
+                b.insert(b.end(), bk->data.begin(), bk->data.end());
+            }
+            e->hyper[l].out = hdims[l][0]; e->hyper[l].in = hdims[l][1];
+            e->hyper[l].w = F.up_bf16(w); e->hyper[l].b = F.up_f32(b);
+        }
+        const int iou_out[3] = {256, 256, 4}, obj_out[3] = {256, 256, 1};
+        for (int l = 0; l < 3; ++l) {
+            e->iou_head[l] = F.lin(d + "iou_prediction_head.layers." + std::to_string(l), iou_out[l], 256);
+            e->obj_head[l] = F.lin(d + "pred_obj_score_head.layers." + std::to_string(l), obj_out[l], 256);
+        }
+    }
+    if (F.status != SABER_OK) return F.status;
+
+    // ---- workspaces
+    const size_t B = e->max_images, P = e->max_prompts;
+    TRY(eng_alloc(e, &e->pix, B * 3 * 1024 * 1024));
+    TRY(eng_alloc(e, &e->xa, B * 65536 * 144));
+    TRY(eng_alloc(e, &e->xb, B * 65536 * 144));
+    TRY(eng_alloc(e, &e->xn, B * 65536 * 144));
+    TRY(eng_alloc(e, &e->qkv, B * 65536 * 864));
+    TRY(eng_alloc(e, &e->att, B * 65536 * 144));
+    TRY(eng_alloc(e, &e->hid, B * 65536 * 576));
+    for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &e->sb[s], B * (65536 >> (2 * s)) * (size_t)(144 << s)));
+    TRY(eng_alloc(e, &e->lat3, B * 1024 * 256));
+    TRY(eng_alloc(e, &e->crops_dev, B * 4));
+    TRY(eng_alloc(e, &e->emb, B * 4096 * 256));
+    TRY(eng_alloc(e, &e->fs1, B * 16384 * 64));
+    TRY(eng_alloc(e, &e->fs0, B * 65536 * 32));
+    TRY(eng_alloc(e, &e->src0_f, B * 4096 * 256));
+    TRY(eng_alloc(e, &e->src0_bf, B * 4096 * 256));
+    TRY(eng_alloc(e, &e->src0pos_bf, B * 4096 * 256));
+    TRY(eng_alloc(e, &e->k0, B * 4096 * 128));
+    TRY(eng_alloc(e, &e->v0, B * 4096 * 128));
+    TRY(eng_alloc(e, &e->qi0, B * 4096 * 128));
+    e->slot_valid.assign(B, 0);
+    e->slot_shared_valid.assign(B, 0);
+
+    TRY(eng_alloc(e, &e->tok_pe, P * 8 * 256));
+    TRY(eng_alloc(e, &e->queries, P * 8 * 256));
+    TRY(eng_alloc(e, &e->tq, P * 8 * 256));
+    TRY(eng_alloc(e, &e->tk, P * 8 * 256));
+    TRY(eng_alloc(e, &e->tv, P * 8 * 256));
+    TRY(eng_alloc(e, &e->t_bf0, P * 8 * 256));
+    TRY(eng_alloc(e, &e->t_bf1, P * 8 * 256));
+    TRY(eng_alloc(e, &e->t_att, P * 8 * 256));
+    TRY(eng_alloc(e, &e->t_hid, P * 8 * 2048));
+    TRY(eng_alloc(e, &e->keys, P * 4096 * 256));
+    TRY(eng_alloc(e, &e->keys_bf, P * 4096 * 256));
+    TRY(eng_alloc(e, &e->keyspos_bf, P * 4096 * 256));
+    TRY(eng_alloc(e, &e->kp, P * 4096 * 128));
+    TRY(eng_alloc(e, &e->vp, P * 4096 * 128));
+    TRY(eng_alloc(e, &e->qp, P * 4096 * 128));
+    TRY(eng_alloc(e, &e->iatt_bf, P * 4096 * 128));
+    TRY(eng_alloc(e, &e->u1, P * 4096 * 256));
+    TRY(eng_alloc(e, &e->u1b, P * 4096 * 256));
+    TRY(eng_alloc(e, &e->up2, P * 16384 * 128));
+    TRY(eng_alloc(e, &e->masks4, P * 4 * 65536));
+    TRY(eng_alloc(e, &e->hyper_out, P * 128));
+    TRY(eng_alloc(e, &e->iou4, P * 4));
+    TRY(eng_alloc(e, &e->head_tmp, P * 4));
+    TRY(eng_alloc(e, &e->head_bf0, 4 * P * 256));
+    TRY(eng_alloc(e, &e->head_bf1, 4 * P * 256));
+    TRY(eng_alloc(e, &e->counts_ws, 2 * P));
+    TRY(eng_alloc(e, &e->dec_out_masks, P * 3 * 65536));
+    TRY(eng_alloc(e, &e->dec_out_iou, P * 3));
+    TRY(eng_alloc(e, &e->prep_minmax, 4));
+    ENG_HIP(e, hipDeviceSynchronize());
+    e->host_w.clear();
+    e->finalized = true;
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+static GemmParams mk_gemm(const bf16_t* A, int64_t lda, int M, const LinW& w) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = w.w; p.ldw = w.in; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in;
+    return p;
+}
+static const char* ln_run(const float* x, const LnW& w, float eps, int rows, int C, float* out_f, bf16_t* out_bf, int act, hipStream_t s,
+                          bf16_t* out_bf_add = nullptr, const float* addvec = nullptr, int add_mod = 0) {
+    LayerNormParams p;
+    p.x = x; p.ldx = C; p.gamma = w.g; p.beta = w.b; p.eps = eps; p.out_f = out_f; p.out_bf = out_bf; p.out_bf_add = out_bf_add;
+    p.ldo = C; p.addvec = addvec; p.add_mod = add_mod; p.rows = rows; p.C = C; p.act = act;
+    return launch_layernorm(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------ K0
+extern "C" int saber_prepare(saber_engine* e, const void* img_dev, int dtype, int H, int W, float* out_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (!img_dev || !out_dev || H <= 0 || W <= 0) return eng_fail(e, SABER_ERR_INVALID, "prepare: bad argument");
+    ENG_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)4 * H * W;
+    if (e->prep_ws_elems < need) {
+        TRY(eng_alloc(e, &e->prep_ws, need));
+        e->prep_ws_elems = need;
+    }
+    if (dtype == SABER_U16) ENG_K(e, launch_prepare_u16((const uint16_t*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
+    else if (dtype == SABER_F32) ENG_K(e, launch_prepare_f32((const float*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
+    else return eng_fail(e, SABER_ERR_INVALID, "prepare: dtype must be SABER_U16 or SABER_F32");
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ encoder
+int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crops_host, int n, int slot0, hipStream_t s) {
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (!img_dev || !crops_host || n < 1 || n > e->max_images || slot0 < 0 || slot0 + n > e->max_images)
+        return eng_fail(e, SABER_ERR_INVALID, "encode: bad argument (n / slot range exceeds max_images?)");
+    for (int i = 0; i < n; ++i) {
+        const int* c = crops_host + 4 * i;
+        if (c[0] < 0 || c[1] < 0 || c[2] > W || c[3] > H || c[2] <= c[0] || c[3] <= c[1]) return eng_fail(e, SABER_ERR_INVALID, "encode: crop box outside the image");
+    }
+    ENG_HIP(e, hipMemcpyAsync(e->crops_dev, crops_host, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
+    ENG_K(e, launch_resize_normalize(img_dev, H, W, channels, e->crops_dev, n, e->pix, 1024, s));
+    ENG_K(e, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
+    float* x = e->xa;
+    float* xalt = e->xb;
+    int tokens = 65536;  // per image, current stage
+    int stage = 0;
+    for (size_t i = 0; i < e->blocks.size(); ++i) {
+        const BlockSpec& bs = e->blocks[i];
+        const BlockW& w = e->bw[i];
+        const int N = n * tokens;
+        ENG_K(e, ln_run(x, w.n1, 1e-6f, N, bs.din, nullptr, e->xn, ACT_NONE, s));
+        float* xres = x;
+        int Nq = N;
+        if (bs.din != bs.dout) {
+            GemmParams g = mk_gemm(e->xn, bs.din, N, w.sc);
+            g.Cf = xalt; g.ldcf = bs.dout; g.pool4 = 1;
+            ENG_K(e, launch_gemm(g, s));
+            xres = xalt;
+            Nq = N / 4;
+        }
+        {
+            GemmParams g = mk_gemm(e->xn, bs.din, N, w.qkv);
+            g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
+            ENG_K(e, launch_gemm(g, s));
+        }
+        const int nk = bs.window > 0 ? bs.window * bs.window : tokens;
+        ENG_K(e, launch_hiera_attention(e->qkv, e->att, N / nk, nk, bs.heads, bs.q_stride > 1, s));
+        {
+            GemmParams g = mk_gemm(e->att, bs.dout, Nq, w.proj);
+            g.Cf = xres; g.ldcf = bs.dout; g.res = xres; g.ldres = bs.dout;
+            ENG_K(e, launch_gemm(g, s));
+        }
+        if (bs.din != bs.dout) { std::swap(x, xalt); tokens /= 4; ++stage; }
+        ENG_K(e, ln_run(x, w.n2, 1e-6f, Nq, bs.dout, nullptr, e->xn, ACT_NONE, s));
+        {
+            GemmParams g = mk_gemm(e->xn, bs.dout, Nq, w.fc1);
+            g.Cb = e->hid; g.ldcb = 4 * bs.dout; g.act = ACT_GELU;
+            ENG_K(e, launch_gemm(g, s));
+        }
+        {
+            GemmParams g = mk_gemm(e->hid, 4 * bs.dout, Nq, w.fc2);
+            g.Cf = x; g.ldcf = bs.dout; g.res = x; g.ldres = bs.dout;
+            if ((int)i == e->stage_ends[stage]) { g.Cb = e->sb[stage]; g.ldcb = bs.dout; }
+            ENG_K(e, launch_gemm(g, s));
+        }
+    }
+    // neck
+    {
+        GemmParams g = mk_gemm(e->sb[3], e->stage_dims[3], n * 1024, e->neck3);
+        g.Cf = e->lat3; g.ldcf = 256;
+        ENG_K(e, launch_gemm(g, s));
+    }
+    {
+        GemmParams g = mk_gemm(e->sb[2], e->stage_dims[2], n * 4096, e->neck2);
+        g.Cf = e->emb + (size_t)slot0 * 4096 * 256; g.ldcf = 256; g.res = e->lat3; g.ldres = 256; g.res_shift = 2;
+        ENG_K(e, launch_gemm(g, s));
+    }
+    {
+        GemmParams g = mk_gemm(e->sb[1], e->stage_dims[1], n * 16384, e->s1);
+        g.Cf = e->fs1 + (size_t)slot0 * 16384 * 64; g.ldcf = 64;
+        ENG_K(e, launch_gemm(g, s));
+    }
+    {
+        GemmParams g = mk_gemm(e->sb[0], e->stage_dims[0], n * 65536, e->s0);
+        g.Cf = e->fs0 + (size_t)slot0 * 65536 * 32; g.ldcf = 32;
+        ENG_K(e, launch_gemm(g, s));
+    }
+    for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+extern "C" int saber_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crop_boxes_host, int n,
+                            int slot0, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    ENG_HIP(e, hipSetDevice(e->device));
+    return eng_encode(e, img_dev, H, W, channels, crop_boxes_host, n, slot0, (hipStream_t)stream);
+}
+
+extern "C" int saber_get_features(saber_engine* e, int slot, float* image_embed, float* feat_s0, float* feat_s1, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot]) return eng_fail(e, SABER_ERR_STATE, "get_features: slot holds no encoded image; call saber_encode first");
+    ENG_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (image_embed) ENG_K(e, launch_unpermute_nchw(e->emb + (size_t)slot * 4096 * 256, 256, 2, image_embed, s));
+    if (feat_s1) ENG_K(e, launch_unpermute_nchw(e->fs1 + (size_t)slot * 16384 * 64, 64, 1, feat_s1, s));
+    if (feat_s0) ENG_K(e, launch_unpermute_nchw(e->fs0 + (size_t)slot * 65536 * 32, 32, 0, feat_s0, s));
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
+    if (e->slot_shared_valid[slot]) return SABER_OK;
+    const size_t o256 = (size_t)slot * 4096 * 256, o128 = (size_t)slot * 4096 * 128;
+    ENG_K(e, launch_add_to_bf16(e->emb + o256, e->no_mask_embed, 1, e->src0_bf + o256, e->src0_f + o256, 4096, 256, s));
+    ENG_K(e, launch_add_to_bf16(e->src0_f + o256, e->dense_pe, 4096, e->src0pos_bf + o256, nullptr, 4096, 256, s));
+    GemmParams g = mk_gemm(e->src0pos_bf + o256, 256, 4096, e->dl[0].t2i.k);
+    g.Cf = e->k0 + o128; g.ldcf = 128;
+    ENG_K(e, launch_gemm(g, s));
+    g = mk_gemm(e->src0_bf + o256, 256, 4096, e->dl[0].t2i.v);
+    g.Cf = e->v0 + o128; g.ldcf = 128;
+    ENG_K(e, launch_gemm(g, s));
+    g = mk_gemm(e->src0pos_bf + o256, 256, 4096, e->dl[0].i2t.q);
+    g.Cf = e->qi0 + o128; g.ldcf = 128;
+    ENG_K(e, launch_gemm(g, s));
+    e->slot_shared_valid[slot] = 1;
+    return SABER_OK;
+}
+
+static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* labels, int P, int multimask, const float* mask_in,
+                        float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+    const int T = 8;
+    const int PT = P * T;
+    const size_t o256 = (size_t)slot * 4096 * 256, o128 = (size_t)slot * 4096 * 128;
+    const bool shared = (mask_in == nullptr);
+    ENG_K(e, launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
+    ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
+    if (shared) TRY(ensure_shared(e, slot, s));
+    else ENG_K(e, launch_mask_embed_src(mask_in, P, e->emb + o256, e->dense_pe, e->mw, e->keys, e->keys_bf, e->keyspos_bf, s));
+
+    auto t2i = [&](const AttnW& a, const LnW& ln, bool use_shared) -> int {
+        ENG_K(e, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
+        GemmParams g = mk_gemm(e->t_bf0, 256, PT, a.q);
+        g.Cf = e->tq; g.ldcf = 128;
+        ENG_K(e, launch_gemm(g, s));
+        const float *K, *V;
+        int64_t kbs;
+        if (use_shared) { K = e->k0 + o128; V = e->v0 + o128; kbs = 0; }
+        else {
+            g = mk_gemm(e->keyspos_bf, 256, P * 4096, a.k);
+            g.Cf = e->kp; g.ldcf = 128;
+            ENG_K(e, launch_gemm(g, s));
+            g = mk_gemm(e->keys_bf, 256, P * 4096, a.v);
+            g.Cf = e->vp; g.ldcf = 128;
+            ENG_K(e, launch_gemm(g, s));
+            K = e->kp; V = e->vp; kbs = (int64_t)4096 * 128;
+        }
+        ENG_K(e, launch_dec_attention(e->tq, K, V, e->t_att, P, T, 4096, 8, 16, T * 128, kbs, kbs, T * 128, s));
+        g = mk_gemm(e->t_att, 128, PT, a.o);
+        g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
+        ENG_K(e, launch_gemm(g, s));
+        ENG_K(e, ln_run(e->queries, ln, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
+        return SABER_OK;
+    };
+
+    for (int l = 0; l < 2; ++l) {
+        const DecLayerW& w = e->dl[l];
+        // (1) self attention of the tokens
+        ENG_K(e, launch_add_to_bf16(e->queries, l == 0 ? nullptr : e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
+        const bf16_t* vin = e->t_bf0;
+        if (l > 0) { ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s)); vin = e->t_bf1; }
+        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_K(e, launch_gemm(g, s));
+        ENG_K(e, launch_dec_attention(e->tq, e->tk, e->tv, e->t_att, P, T, T, 8, 32, T * 256, T * 256, T * 256, T * 256, s));
+        g = mk_gemm(e->t_att, 256, PT, w.self_attn.o);
+        g.Cf = e->queries; g.ldcf = 256;
+        if (l > 0) { g.res = e->queries; g.ldres = 256; }
+        ENG_K(e, launch_gemm(g, s));
+        ENG_K(e, ln_run(e->queries, w.n1, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
+        // (2) tokens -> image
+        TRY(t2i(w.t2i, w.n2, shared && l == 0));
+        // (3) MLP
+        ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_K(e, launch_gemm(g, s));
+        ENG_K(e, ln_run(e->queries, w.n3, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
+        // (4) image -> tokens
+        ENG_K(e, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
+        ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_K(e, launch_gemm(g, s));
+        const float* Q;
+        int64_t qbs;
+        if (shared && l == 0) { Q = e->qi0 + o128; qbs = 0; }
+        else {
+            g = mk_gemm(e->keyspos_bf, 256, P * 4096, w.i2t.q); g.Cf = e->qp; g.ldcf = 128; ENG_K(e, launch_gemm(g, s));
+            Q = e->qp; qbs = (int64_t)4096 * 128;
+        }
+        ENG_K(e, launch_dec_attention(Q, e->tk, e->tv, e->iatt_bf, P, 4096, T, 8, 16, qbs, T * 128, T * 128, (int64_t)4096 * 128, s));
+        g = mk_gemm(e->iatt_bf, 128, P * 4096, w.i2t.o);
+        g.Cf = e->keys; g.ldcf = 256; g.ldres = 256;
+        if (shared && l == 0) { g.res = e->src0_f + o256; g.res_mod = 4096; }
+        else g.res = e->keys;
+        ENG_K(e, launch_gemm(g, s));
+        ENG_K(e, ln_run(e->keys, w.n4, 1e-5f, P * 4096, 256, e->keys, e->keys_bf, ACT_NONE, s, e->keyspos_bf, e->dense_pe, 4096));
+    }
+    TRY(t2i(e->final_attn, e->final_ln, false));
+
+    // heads
+    ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
+    auto mlp3 = [&](const LinW* L, const bf16_t* A, int last_act, float* outf, int ldo) -> int {
+        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_K(e, launch_gemm(g, s));
+        return SABER_OK;
+    };
+    TRY(mlp3(e->iou_head, e->t_bf0 + 1 * 256, ACT_SIGMOID, e->iou4, 4));
+    if (out_obj) TRY(mlp3(e->obj_head, e->t_bf0, ACT_NONE, out_obj, 1));
+    {   // 4 hypernetwork MLPs as batched GEMMs (batch = mask token)
+        GemmParams g = mk_gemm(e->t_bf0 + 2 * 256, T * 256, P, e->hyper[0]);
+        g.batch = 4; g.strideA = 256; g.strideW = 256 * 256; g.strideBias = 256;
+        g.Cb = e->head_bf0; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
+        ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf0, 256, P, e->hyper[1]);
+        g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 256 * 256; g.strideBias = 256;
+        g.Cb = e->head_bf1; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
+        ENG_K(e, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf1, 256, P, e->hyper[2]);
+        g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 32 * 256; g.strideBias = 32;
+        g.Cf = e->hyper_out; g.ldcf = 128; g.strideCf = 32;
+        ENG_K(e, launch_gemm(g, s));
+    }
+    // upscaling: dc1 + feat_s1 -> LN2d -> GELU -> dc2 + feat_s0 -> GELU
+    {
+        GemmParams g = mk_gemm(e->keys_bf, 256, P * 4096, e->dc1);
+        g.Cf = e->u1; g.ldcf = 256; g.res = e->fs1 + (size_t)slot * 16384 * 64; g.ldres = 256; g.res_mod = 4096;
+        ENG_K(e, launch_gemm(g, s));
+        ENG_K(e, ln_run(e->u1, e->up_ln, 1e-6f, P * 16384, 64, nullptr, e->u1b, ACT_GELU, s));
+        g = mk_gemm(e->u1b, 64, P * 16384, e->dc2);
+        g.Cb = e->up2; g.ldcb = 128; g.res = e->fs0 + (size_t)slot * 65536 * 32; g.ldres = 128; g.res_mod = 16384;
+        g.act = ACT_GELU; g.act_last = 1;
+        ENG_K(e, launch_gemm(g, s));
+    }
+    ENG_K(e, launch_mask_dot(e->up2, e->hyper_out, P, e->masks4, s));
+    float* om = out_lowres ? out_lowres : e->dec_out_masks;
+    float* oi = out_iou ? out_iou : e->dec_out_iou;
+    ENG_K(e, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
+    return SABER_OK;
+}
+
+int eng_decode(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask, const float* mask_in_dev,
+               float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot]) return eng_fail(e, SABER_ERR_STATE, "decode: slot holds no encoded image; call saber_encode first");
+    if (!pts_dev || n < 0) return eng_fail(e, SABER_ERR_INVALID, "decode: bad argument");
+    const int M = multimask ? 3 : 1;
+    for (int p0 = 0; p0 < n; p0 += e->max_prompts) {
+        const int P = std::min(e->max_prompts, n - p0);
+        TRY(decode_chunk(e, slot, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
+                         mask_in_dev ? mask_in_dev + (size_t)p0 * 65536 : nullptr,
+                         out_lowres ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
+                         out_obj ? out_obj + p0 : nullptr, s));
+    }
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+extern "C" int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
+                                   const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    ENG_HIP(e, hipSetDevice(e->device));
+    return eng_decode(e, slot, pts_dev, labels_dev, n, multimask, mask_in_dev, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ label plane
+extern "C" int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, const int* order_host, int n, int H, int W, uint16_t* plane_dev,
+                                 void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!plane_dev || H <= 0 || W <= 0 || n < 0 || (n > 0 && !bits_dev)) return eng_fail(e, SABER_ERR_INVALID, "label_plane: bad argument");
+    if (n > 65535) return eng_fail(e, SABER_ERR_INVALID, "label_plane: more than 65535 masks do not fit a uint16 plane");
+    ENG_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    int* od = nullptr;
+    if (order_host && n > 0) {
+        if (e->order_cap < (size_t)n) { TRY(eng_alloc(e, &e->order_dev, (size_t)n)); e->order_cap = n; }
+        ENG_HIP(e, hipMemcpyAsync(e->order_dev, order_host, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        od = e->order_dev;
+    }
+    ENG_K(e, launch_label_plane(bits_dev, od, n, H, W, plane_dev, s));
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ work counters
+extern "C" double saber_encoder_flops(const saber_engine* e) {
+    if (!e) return 0.0;
+    // SURVEY.md 8d formula (algorithmic, 2*MAC): per block qkv + shortcut + proj + attention + MLP, plus patch embed, neck, conv_s0/s1
+    double fl = 65536.0 * 147 * e->embed_dim * 2;
+    int tokens = 65536;
+    for (const BlockSpec& b : e->blocks) {
+        const double nin = tokens, nq = b.q_stride > 1 ? tokens / 4 : tokens;
+        const double nk = b.window > 0 ? (double)b.window * b.window : (double)tokens;
+        const double qpw = b.q_stride > 1 ? nk / 4 : nk;
+        const double nwin = nin / nk;
+        double mac = nin * b.din * 3.0 * b.dout + nq * (double)b.dout * b.dout + nwin * qpw * nk * b.dout * 2.0 + nq * 8.0 * b.dout * b.dout;
+        if (b.din != b.dout) mac += nin * b.din * b.dout;
+        fl += 2.0 * mac;
+        if (b.q_stride > 1) tokens /= 4;
+    }
+    const double toks[4] = {65536, 16384, 4096, 1024};
+    for (int s = 0; s < 4; ++s) fl += 2.0 * toks[s] * e->stage_dims[s] * 256.0;
+    fl += 2.0 * (65536.0 * 256 * 32 + 16384.0 * 256 * 64);
+    return fl;
+}
+extern "C" double saber_decoder_flops_per_prompt(void) { return 3.639e9; }

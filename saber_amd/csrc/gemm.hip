@@ -1,0 +1,194 @@
+// bf16 MFMA GEMM with fused epilogues:  C[M,N] = epi( A[M,K] . W[N,K]^T + bias )
+//
+// Replaces the torch ops nn.Linear / 1x1 Conv2d / ConvTranspose2d(k2s2) executed by the
+// third-party sam2 package under the reference call site saber/adapters/sam2/predictor.py:70
+// (SURVEY.md 8a rows b4-b7, b9, b10).  gfx950 only: v_mfma_f32_16x16x32_bf16, wave64.
+//
+// Tile 128x128x64, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.  Both operands are
+// K-contiguous, staged global->registers->LDS (double-buffered, XOR-swizzled 16-B chunks so
+// ds_read_b128 fragment reads are bank-conflict-free).  The MFMA is issued "swapped"
+// (A-operand = W fragment, B-operand = A fragment) so each lane ends up owning 4 consecutive
+// output columns of one row: epilogue loads/stores are 16-B (fp32) / 8-B (bf16) vectors.
+#include "common.h"
+#include "kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand per buffer
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int64_t z = blockIdx.z;
+    const bf16_t* __restrict__ A = p.A + z * p.strideA;
+    const bf16_t* __restrict__ W = p.W + z * p.strideW;
+
+    const int c = tid & 7, r0 = tid >> 3;
+    uint4 ra[4], rw[4];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto gload = [&](int kt) {
+        const int k = kt * BK + c * 8;
+        const bool kok = k < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + r0 + 32 * i;
+            ra[i] = (kok && row < p.M) ? *reinterpret_cast<const uint4*>(A + (int64_t)row * p.lda + k) : zero4;
+            const int n = n0 + r0 + 32 * i;
+            rw[i] = (kok && n < p.N) ? *reinterpret_cast<const uint4*>(W + (int64_t)n * p.ldw + k) : zero4;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 32 * i;
+            const int off = swz(row, c);
+            *reinterpret_cast<uint4*>(sa + off) = ra[i];
+            *reinterpret_cast<uint4*>(sw + off) = rw[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fi = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: lane owns C[m][n..n+3]
+    const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+    const float* res = p.res ? p.res + z * p.strideRes : nullptr;
+    float* Cf = p.Cf ? p.Cf + z * p.strideCf : nullptr;
+    bf16_t* Cb = p.Cb ? p.Cb + z * p.strideCb : nullptr;
+    const bool vec_ok = (p.N & 3) == 0;
+    auto apply_act = [&](float (&v)[4]) {
+        if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const bool nvec = vec_ok && (n + 3 < p.N);
+            if (bias) {
+                if (nvec) {
+                    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bias[n + r];
+                }
+            }
+            if (!p.act_last) apply_act(v);
+            int mo = m;
+            bool writer = m < p.M;
+            if (p.pool4) {  // max over 4 consecutive rows (lanes 4q..4q+3 of the 16-lane group)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = (m < p.M) ? v[r] : -3.0e38f;
+                    x = fmaxf(x, __shfl_xor(x, 1, 64));
+                    x = fmaxf(x, __shfl_xor(x, 2, 64));
+                    v[r] = x;
+                }
+                writer = writer && ((fi & 3) == 0);
+                mo = m >> 2;
+            }
+            if (!writer) continue;
+            if (res) {
+                int rr = mo >> p.res_shift;
+                if (p.res_mod > 0) rr %= p.res_mod;
+                const float* rp = res + (int64_t)rr * p.ldres + n;
+                if (nvec) {
+                    const float4 b = *reinterpret_cast<const float4*>(rp);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
+                }
+            }
+            if (p.act_last) apply_act(v);
+            if (Cf) {
+                float* cp = Cf + (int64_t)mo * p.ldcf + n;
+                if (nvec) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = v[r];
+                }
+            }
+            if (Cb) {
+                bf16_t* cp = Cb + (int64_t)mo * p.ldcb + n;
+                if (nvec) *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
+void gemm_init_device() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+}
+
+const char* launch_gemm(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
+    if ((p.K & 7) || (p.lda & 7) || (p.ldw & 7)) return "gemm: K, lda, ldw must be multiples of 8";
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return "gemm: A/W must be 16-byte aligned";
+    if ((p.strideA & 7) || (p.strideW & 7)) return "gemm: batch strides must be multiples of 8";
+    if ((p.N & 3) == 0) {
+        if ((p.Cf && ((p.ldcf & 3) || ((uintptr_t)p.Cf & 15))) || (p.Cb && ((p.ldcb & 3) || ((uintptr_t)p.Cb & 7))) ||
+            (p.res && ((p.ldres & 3) || ((uintptr_t)p.res & 15))) || (p.bias && ((uintptr_t)p.bias & 15)))
+            return "gemm: output/residual/bias alignment";
+    }
+    if (p.pool4 && (p.M & 3)) return "gemm: pool4 needs M % 4 == 0";
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
+    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+    return nullptr;
+}

@@ -1,0 +1,93 @@
+// Internal launcher interface between the engine (engine.hip) and the gfx950 kernels.
+// Every launcher returns nullptr on success or a static error string (no exceptions,
+// no abort): errors surface through the C-ABI status + saber_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+// ------------------------------------------------------------------ gemm.hip
+struct GemmParams {
+    const bf16_t* A = nullptr; int64_t lda = 0; int64_t strideA = 0;
+    const bf16_t* W = nullptr; int64_t ldw = 0; int64_t strideW = 0;  // [N][K] row-major
+    const float* bias = nullptr; int64_t strideBias = 0;
+    const float* res = nullptr; int64_t ldres = 0; int64_t strideRes = 0;  // fp32 residual
+    float* Cf = nullptr; int64_t ldcf = 0; int64_t strideCf = 0;
+    bf16_t* Cb = nullptr; int64_t ldcb = 0; int64_t strideCb = 0;
+    int M = 0, N = 0, K = 0;
+    int act = ACT_NONE;
+    int act_last = 0;    // apply the activation after the residual add (act(dc2(x) + feat_s0))
+    int res_shift = 0;   // residual row = (row >> res_shift) ...
+    int res_mod = 0;     // ... then % res_mod when res_mod > 0 (broadcast over prompts)
+    int pool4 = 0;       // rows 4q..4q+3 max-pooled into output row q (Hiera q-pool shortcut)
+    int batch = 1;
+};
+const char* launch_gemm(const GemmParams& p, hipStream_t stream);
+void gemm_init_device();
+
+// ------------------------------------------------------------------ layernorm.hip
+struct LayerNormParams {
+    const float* x = nullptr; int64_t ldx = 0;
+    const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-6f;
+    float* out_f = nullptr; bf16_t* out_bf = nullptr; bf16_t* out_bf_add = nullptr; int64_t ldo = 0;
+    const float* addvec = nullptr; int add_mod = 0;  // out_bf_add = bf16(y + addvec[row % add_mod])
+    int rows = 0, C = 0, act = ACT_NONE;
+};
+const char* launch_layernorm(const LayerNormParams& p, hipStream_t s);
+const char* launch_add_to_bf16(const float* x, const float* y, int ymod, bf16_t* out_bf, float* out_f, int64_t rows, int C,
+                               hipStream_t s);
+
+// ------------------------------------------------------------------ attention_hiera.hip
+// qkv: bf16 [tokens][3*heads*72]; out: bf16 [tokens_q][heads*72]; windows are contiguous runs of nk rows.
+const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int q_pool, hipStream_t s);
+void hiera_attention_init_device();
+
+// ------------------------------------------------------------------ image_ops.hip
+const char* launch_prepare_u16(const uint16_t* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s);
+const char* launch_prepare_f32(const float* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s);
+const char* launch_resize_normalize(const float* img, int H, int W, int channels, const int* crops_dev, int n, float* out, int res,
+                                    hipStream_t s);
+const char* launch_patch_embed(const float* pix, const float* wt, const float* bias, const float* pos, float* out, int n_images,
+                               int C, int res, hipStream_t s);
+void image_ops_init_device();
+
+// ------------------------------------------------------------------ decoder_ops.hip
+struct PromptWeights {
+    const float* gauss;         // [2][128]
+    const float* point_embed;   // [4][256]
+    const float* not_a_point;   // [256]
+    const float* out_tokens;    // [6][256]: obj, iou, mask0..3
+};
+const char* launch_prompt_tokens(const float* pts, const int* labels, int P, PromptWeights w, float* tokens, hipStream_t s);
+
+struct MaskEmbedWeights {
+    const float *w1, *b1, *g1, *be1;   // conv 1->4 k2s2 [4][4], LN2d(4)
+    const float *w2, *b2, *g2, *be2;   // conv 4->16 k2s2 [16][16], LN2d(16)
+    const float *w3, *b3;              // conv 16->256 1x1 [256][16]
+};
+// src[p][tok] = image_embed[tok] + mask_downscaling(mask_in[p]) (token order = engine order on the 64x64 grid)
+const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, const float* pos, MaskEmbedWeights w,
+                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s);
+
+// fp32 multi-head attention for the two-way transformer.  q [B][nq][heads*hd], k/v [B or 1][nk][heads*hd].
+// Output is bf16 (it always feeds the out_proj GEMM).
+const char* launch_dec_attention(const float* q, const float* k, const float* v, bf16_t* out, int B, int nq, int nk, int heads,
+                                 int hd, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs, hipStream_t s);
+
+// masks[p][k][y][x] = sum_c hyper[p][k][c] * up[p][perm(y,x)][c]  (up: bf16 [P][65536][32], engine token order)
+const char* launch_mask_dot(const bf16_t* up, const float* hyper, int P, float* masks4, hipStream_t s);
+// multimask: out[p][0..2] = masks4[p][1..3], iou_out = iou4[:,1:]; else dynamic single-mask selection (delta 0.05 / thr 0.98)
+const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,
+                               int* counts_ws, hipStream_t s);
+
+// K8: bilinear upsample of 256x256 logits to the crop, threshold / stability counts / bbox / bit-packing.
+struct MaskStats { int area; int inter; int uni; int x0; int y0; int x1; int y1; int pad; };
+const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
+                             int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s);
+// paint label planes: plane[y][x] = max over i (in order) ... later masks overwrite earlier ones (propagation.py:185-186)
+const char* launch_label_plane(const uint32_t* bits, const int* order, int n, int H, int W, uint16_t* plane, hipStream_t s);
+// gather token-major [tokens][C] (engine order, stage s grid) -> NCHW fp32 for inspection / parity tests
+const char* launch_unpermute_nchw(const float* tok, int C, int stage, float* out, hipStream_t s);

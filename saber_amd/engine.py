@@ -1,0 +1,163 @@
+"""Python host wrapper of the C-ABI engine: PyTorch-ROCm tensors in, masks out.
+
+PyTorch is used only for device memory, streams and (elsewhere) torch.distributed; every
+arithmetic step of the hot path runs in the HIP library.  Errors from the C-ABI surface as
+Python exceptions (ValueError for bad configuration, RuntimeError for state / HIP errors) so
+that the reference's per-task accounting (saber/utils/parallelization.py:129-135) keeps working.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model_config import get_config
+from .weights import seeded_weights, load_checkpoint
+
+SABER_U16, SABER_F32 = 0, 1
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One engine handle bound to one device (reference threading contract: one caller per device)."""
+
+    def __init__(self, trunk: str = "large", device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
+                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64):
+        self.lib = _lib.load()
+        self.cfg = get_config(trunk)  # ValueError for unknown names, like the reference
+        if not torch.cuda.is_available():
+            raise RuntimeError("saber_amd.Engine needs a ROCm device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(f"cuda:{device}")
+        self.device_index = device
+        h = C.c_void_p()
+        st = self.lib.saber_engine_create(device, trunk.encode(), max_images, max_prompts, C.byref(h))
+        if st != 0:
+            msg = self.lib.saber_last_error(None).decode()
+            raise (ValueError if st == -1 else RuntimeError)(msg)
+        self.h = h
+        self.max_images, self.max_prompts = max_images, max_prompts
+        if weights is None:
+            weights = load_checkpoint(checkpoint, self.cfg) if checkpoint else seeded_weights(self.cfg, seed)
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.saber_engine_set_weight(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        self._check(self.lib.saber_engine_finalize(self.h))
+
+    def _check(self, st: int):
+        if st != 0:
+            msg = self.lib.saber_last_error(self.h).decode()
+            raise (ValueError if st == -1 else RuntimeError)(f"saber_amd: {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.saber_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ K0
+    def prepare(self, img: torch.Tensor) -> torch.Tensor:
+        """prep.prepare on device.  img: (H,W) uint16 or float32 device tensor -> (H,W) float32 in [0,1]."""
+        assert img.is_cuda and img.dim() == 2 and img.is_contiguous()
+        if img.dtype == torch.uint16:
+            dt = SABER_U16
+        elif img.dtype == torch.float32:
+            dt = SABER_F32
+        else:
+            raise ValueError(f"prepare: unsupported dtype {img.dtype}")
+        out = torch.empty(img.shape, dtype=torch.float32, device=img.device)
+        self._check(self.lib.saber_prepare(self.h, _ptr(img), dt, img.shape[0], img.shape[1], _ptr(out), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ encoder
+    def encode(self, img: torch.Tensor, crop_boxes: Optional[Sequence[Sequence[int]]] = None, slot0: int = 0):
+        """img: (H,W) or (H,W,3) float32 in [0,1] on the device; crop_boxes: list of [x0,y0,x1,y1]."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        H, W = img.shape[:2]
+        ch = 1 if img.dim() == 2 else img.shape[2]
+        if crop_boxes is None:
+            crop_boxes = [[0, 0, W, H]]
+        cb = np.ascontiguousarray(np.asarray(crop_boxes, dtype=np.int32).reshape(-1, 4))
+        self._check(self.lib.saber_encode(self.h, _ptr(img), H, W, ch, cb.ctypes.data_as(C.POINTER(C.c_int)), len(cb), slot0, _stream()))
+
+    def get_features(self, slot: int = 0):
+        emb = torch.empty((256, 64, 64), dtype=torch.float32, device=self.device)
+        s0 = torch.empty((32, 256, 256), dtype=torch.float32, device=self.device)
+        s1 = torch.empty((64, 128, 128), dtype=torch.float32, device=self.device)
+        self._check(self.lib.saber_get_features(self.h, slot, _ptr(emb), _ptr(s0), _ptr(s1), _stream()))
+        return {"image_embed": emb, "feat_s0": s0, "feat_s1": s1}
+
+    # ------------------------------------------------------------------ decoder
+    def decode_points(self, pts: torch.Tensor, slot: int = 0, multimask: bool = True, mask_input: Optional[torch.Tensor] = None,
+                      labels: Optional[torch.Tensor] = None):
+        """pts: (n,2) float32 model-pixel coords on device. Returns (lowres (n,M,256,256), iou (n,M), obj (n,))."""
+        assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
+        n = pts.shape[0]
+        M = 3 if multimask else 1
+        low = torch.empty((n, M, 256, 256), dtype=torch.float32, device=self.device)
+        iou = torch.empty((n, M), dtype=torch.float32, device=self.device)
+        obj = torch.empty((n,), dtype=torch.float32, device=self.device)
+        if mask_input is not None:
+            assert mask_input.is_cuda and mask_input.dtype == torch.float32 and mask_input.is_contiguous() and mask_input.numel() == n * 65536
+        if labels is not None:
+            assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == n
+        self._check(self.lib.saber_decode_points(self.h, slot, _ptr(pts), _ptr(labels), n, int(multimask), _ptr(mask_input),
+                                                 _ptr(low), _ptr(iou), _ptr(obj), _stream()))
+        return low, iou, obj
+
+    # ------------------------------------------------------------------ AMG
+    def amg_generate(self, img: torch.Tensor, params: "_lib.AmgParams", max_masks: int = 1024):
+        """img: (H,W) or (H,W,3) float32 in [0,1].  Returns (bits uint32 (n,H,W32) device tensor, list of MaskMeta)."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        H, W = img.shape[:2]
+        ch = 1 if img.dim() == 2 else img.shape[2]
+        W32 = (W + 31) // 32
+        bits = torch.empty((max_masks, H, W32), dtype=torch.int32, device=self.device)
+        meta = (_lib.MaskMeta * max_masks)()
+        cnt = C.c_int(0)
+        self._check(self.lib.saber_amg_generate(self.h, _ptr(img), H, W, ch, C.byref(params), _ptr(bits), max_masks, meta, C.byref(cnt), _stream()))
+        n = cnt.value
+        return bits[:n], [meta[i] for i in range(n)]
+
+    def label_plane(self, bits: torch.Tensor, order: Sequence[int], H: int, W: int) -> torch.Tensor:
+        plane = torch.empty((H, W), dtype=torch.uint16, device=self.device)
+        n = len(order)
+        arr = (C.c_int * max(n, 1))(*order)
+        self._check(self.lib.saber_label_plane(self.h, _ptr(bits) if n else None, arr, n, H, W, _ptr(plane), _stream()))
+        return plane
+
+    def encoder_flops(self) -> float:
+        return float(self.lib.saber_encoder_flops(self.h))
+
+
+def unpack_bits(bits: torch.Tensor, W: int) -> np.ndarray:
+    """(n,H,W32) int32 device tensor -> (n,H,W) bool numpy (bit b of word w = pixel 32w+b)."""
+    b = bits.cpu().numpy().view(np.uint32)
+    u8 = b.view(np.uint8).reshape(b.shape[0], b.shape[1], -1)  # little-endian bytes
+    out = np.unpackbits(u8, axis=-1, bitorder="little")
+    return out[..., :W].astype(bool)
+
+
+def make_amg_params(amg: Optional[dict] = None) -> "_lib.AmgParams":
+    """cfgAMG dict (saber/adapters/sam2/amg.py:7-17) -> C struct, with the upstream defaults SABER does not pass."""
+    a = dict(npoints=32, points_per_batch=64, pred_iou_thresh=0.7, stability_score_thresh=0.92, stability_score_offset=0.7,
+             crop_n_layers=2, box_nms_thresh=0.7, crop_n_points_downscale_factor=2, use_m2m=True, multimask_output=True)
+    a.update({k: v for k, v in (amg or {}).items() if k in a})
+    return _lib.AmgParams(points_per_side=a["npoints"], points_per_batch=a["points_per_batch"], pred_iou_thresh=a["pred_iou_thresh"],
+                          stability_score_thresh=a["stability_score_thresh"], stability_score_offset=a["stability_score_offset"],
+                          mask_threshold=0.0, box_nms_thresh=a["box_nms_thresh"], crop_n_layers=a["crop_n_layers"], crop_nms_thresh=0.7,
+                          crop_overlap_ratio=512 / 1500, crop_n_points_downscale_factor=a["crop_n_points_downscale_factor"],
+                          use_m2m=int(a["use_m2m"]), multimask_output=int(a["multimask_output"]))

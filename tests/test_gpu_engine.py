@@ -1,0 +1,167 @@
+"""GPU parity of the engine (C-ABI in include/saber_amd.h) against the CPU oracle on the same seeded
+weights and inputs.
+
+Tolerances.  The engine runs GEMM operands in bf16 with fp32 accumulation, fp32 residual stream,
+fp32 LayerNorm/softmax statistics.  Against the fp32 oracle this gives a relative RMS error of a few 1e-3
+per block output that accumulates over 48 blocks; the bounds below are stated per tensor as relative RMS
+(||a-b|| / ||b||) and are ~3x the measured values recorded in DESIGN.md.  Mask-level parity is stated
+as IoU of thresholded masks.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_rms(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
+
+
+@pytest.fixture(scope="module")
+def image():
+    rng = np.random.default_rng(7)
+    img = rng.uniform(0, 1, (1024, 1024)).astype(np.float32)
+    yy, xx = np.mgrid[:1024, :1024]
+    for _ in range(10):
+        cy, cx = rng.integers(100, 924, 2)
+        r = rng.integers(30, 120)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
+    return img
+
+
+@pytest.fixture(scope="module")
+def oracle_feats(image, oracle_large):
+    from oracle import sam2_ref
+    cfg, W = oracle_large
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    taps = {"blocks": []}
+    with torch.no_grad():
+        pix = sam2_ref.sam2_transforms(np.repeat(image[..., None], 3, 2))
+        feats = sam2_ref.encode_image(W, cfg, pix, taps)
+    return feats, taps
+
+
+def test_encode_parity(engine, image, oracle_feats):
+    feats, _ = oracle_feats
+    engine.encode(torch.from_numpy(image).cuda())
+    got = engine.get_features(0)
+    torch.cuda.synchronize()
+    errs = {k: rel_rms(got[k].cpu(), feats[k][0]) for k in ("image_embed", "feat_s0", "feat_s1")}
+    print("encoder rel-rms:", errs)
+    assert errs["feat_s0"] < 0.02 and errs["feat_s1"] < 0.03 and errs["image_embed"] < 0.05, errs
+
+
+def test_encode_crops_and_rgb(engine, image, oracle_large):
+    """A crop is resized to 1024^2 exactly as SAM2Transforms does; RGB input takes the 3-channel path."""
+    from oracle import sam2_ref
+    cfg, W = oracle_large
+    rgb = np.stack([image, image[::-1].copy(), image[:, ::-1].copy()], axis=-1).copy()
+    crop = [100, 200, 697, 797]
+    with torch.no_grad():
+        pix = sam2_ref.sam2_transforms(rgb[crop[1]:crop[3], crop[0]:crop[2]])
+        feats = sam2_ref.encode_image(W, cfg, pix)
+    engine.encode(torch.from_numpy(rgb).cuda(), [crop], slot0=1)
+    got = engine.get_features(1)
+    err = rel_rms(got["image_embed"].cpu(), feats["image_embed"][0])
+    print("crop/rgb image_embed rel-rms:", err)
+    assert err < 0.05
+
+
+def test_decode_parity(engine, image, oracle_large, oracle_feats):
+    from oracle import sam2_ref
+    cfg, W = oracle_large
+    feats, _ = oracle_feats
+    engine.encode(torch.from_numpy(image).cuda())
+    rng = np.random.default_rng(3)
+    pts = torch.tensor(rng.uniform(0, 1024, (8, 2)).astype(np.float32))
+    lab = torch.ones(8, 1, dtype=torch.int64)
+    low, iou, obj = engine.decode_points(pts.cuda(), slot=0, multimask=True)
+    torch.cuda.synchronize()
+    # (a) decoder in isolation: oracle decoder fed with the ENGINE's features
+    gf = {k: v.cpu()[None] for k, v in engine.get_features(0).items()}
+    with torch.no_grad():
+        sp, de = sam2_ref.prompt_encoder(W, pts[:, None], lab, None)
+        r_low, r_iou, r_obj, _, _ = sam2_ref.mask_decoder(W, gf, sp, de, True)
+    e_low, e_iou, e_obj = rel_rms(low.cpu(), r_low), (iou.cpu() - r_iou).abs().max().item(), (obj.cpu() - r_obj[:, 0]).abs().max().item()
+    print("decoder-only: low-res rel-rms", e_low, "iou abs", e_iou, "obj abs", e_obj)
+    assert e_low < 0.03 and e_iou < 0.02 and e_obj < 0.2
+    agree = ((low.cpu() > 0) == (r_low > 0)).float().mean().item()
+    assert agree > 0.995, agree
+    # (b) end to end against the oracle's own features
+    with torch.no_grad():
+        o_low, o_iou, _, _, _ = sam2_ref.mask_decoder(W, feats, sp, de, True)
+    print("end-to-end: low-res rel-rms", rel_rms(low.cpu(), o_low), "iou abs", (iou.cpu() - o_iou).abs().max().item())
+    assert rel_rms(low.cpu(), o_low) < 0.1
+    # (c) m2m pass: mask prompt + dynamic single-mask selection
+    mi = torch.clamp(low[:, 0], -32, 32).contiguous()
+    low2, iou2, _ = engine.decode_points(pts.cuda(), slot=0, multimask=False, mask_input=mi)
+    with torch.no_grad():
+        sp, de = sam2_ref.prompt_encoder(W, pts[:, None], lab, mi.cpu()[:, None])
+        r_low2, r_iou2, _, _, _ = sam2_ref.mask_decoder(W, gf, sp, de, False)
+    e2 = rel_rms(low2.cpu(), r_low2)
+    print("m2m decoder-only: low-res rel-rms", e2, "iou abs", (iou2.cpu() - r_iou2).abs().max().item())
+    assert e2 < 0.03
+
+
+def _match_masks(a, b):
+    """greedy IoU matching of two lists of bool masks -> list of best IoUs for masks of b"""
+    out = []
+    for mb in b:
+        best = 0.0
+        for ma in a:
+            inter = np.logical_and(ma, mb).sum()
+            uni = np.logical_or(ma, mb).sum()
+            best = max(best, inter / uni if uni else 1.0)
+        out.append(best)
+    return out
+
+
+@pytest.mark.parametrize("layers", [0, 1])
+def test_amg_parity(engine, image, oracle_large, large_weights, layers):
+    from oracle.sam2_ref import ImagePredictorRef
+    from oracle.amg_ref import amg_from_saber_cfg
+    from saber_amd.engine import make_amg_params, unpack_bits
+    cfg, Wnp = large_weights
+    amg = dict(npoints=6, crop_n_layers=layers, box_nms_thresh=0.95, pred_iou_thresh=0.5, stability_score_thresh=0.8)
+    ref = amg_from_saber_cfg(ImagePredictorRef(Wnp, cfg), amg).generate(np.repeat(image[..., None], 3, 2))
+    bits, meta = engine.amg_generate(torch.from_numpy(image).cuda(), make_amg_params(amg), max_masks=512)
+    got = unpack_bits(bits, 1024)
+    print(f"AMG layers={layers}: oracle {len(ref)} masks, engine {len(meta)} masks")
+    assert len(ref) > 0
+    # bf16 vs fp32 logits can flip a borderline filter decision; require the sets to agree up to 15 % and matched masks to coincide
+    assert abs(len(ref) - len(meta)) <= max(2, int(0.15 * len(ref)))
+    ious = _match_masks(list(got), [r["segmentation"] for r in ref])
+    good = np.mean(np.array(ious) > 0.97)
+    print("matched IoU: median", float(np.median(ious)), "fraction>0.97", float(good))
+    assert good >= 0.8
+    for m, g in zip(meta, got):
+        assert m.area == int(g.sum())
+        ys, xs = np.where(g)
+        assert [m.bbox_xywh[0], m.bbox_xywh[1], m.bbox_xywh[2], m.bbox_xywh[3]] == [xs.min(), ys.min(), xs.max() - xs.min(), ys.max() - ys.min()]
+
+
+def test_label_plane(engine):
+    rng = np.random.default_rng(0)
+    H, W = 96, 160
+    masks = rng.uniform(size=(5, H, W)) > 0.7
+    packed = np.packbits(masks, axis=-1, bitorder="little").view(np.uint32).astype(np.int32)
+    order = [3, 0, 4, 1, 2]
+    plane = engine.label_plane(torch.from_numpy(packed).cuda(), order, H, W).cpu().numpy()
+    ref = np.zeros((H, W), np.uint16)
+    for i, mi in enumerate(order):  # reference paint loop: saber/segmenters/propagation.py:185-186
+        ref[masks[mi]] = i + 1
+    assert np.array_equal(plane, ref)
+
+
+def test_errors_surface_as_exceptions(engine):
+    with pytest.raises(ValueError):  # crop box outside the image
+        engine.encode(torch.zeros(64, 64).cuda(), [[0, 0, 65, 64]])
+    with pytest.raises(ValueError):  # more crops than resident slots
+        engine.encode(torch.zeros(64, 64).cuda(), [[0, 0, 64, 64]] * (engine.max_images + 1))
+    from saber_amd.engine import Engine
+    with pytest.raises(ValueError):
+        Engine("huge")
+    with pytest.raises(ValueError):
+        Engine("tiny")  # not built for the HIP engine yet: must fail loudly, not fall back

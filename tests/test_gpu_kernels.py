@@ -1,0 +1,206 @@
+"""GPU parity tests of the individual gfx950 kernels, called through the kernel-level C-ABI
+(include/saber_amd_kernels.h).  The reference for each primitive is the plain fp32 formula on the CPU
+(the same formulas oracle/sam2_ref.py is built from), evaluated on the bf16-rounded operands the kernel sees.
+
+Tolerances: bf16 operands with fp32 accumulation reproduce an fp32 evaluation of the SAME rounded operands
+to ~1e-5 relative (summation order only); kernels that round an intermediate to bf16 (attention P, bf16
+outputs) are allowed one bf16 ulp = 2^-8 relative to the row scale.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def bf(x):  # fp32 cpu tensor -> (bf16-rounded fp32 cpu, device uint16 storage)
+    b = x.to(torch.bfloat16)
+    return b.float(), b.view(torch.int16).cuda()
+
+
+def from_bf(t_i16):
+    return t_i16.cpu().view(torch.bfloat16).float()
+
+
+def kcall(lib, st):
+    assert st == 0, lib.saber_k_last_error().decode()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res,pool4", [
+    (300, 432, 144, 0, False, 0), (4096, 576, 2304, 0, True, 0), (1000, 2304, 576, 1, False, 0),
+    (5, 1, 256, 0, False, 0), (64, 4, 256, 3, False, 0), (512, 288, 144, 0, False, 1), (777, 128, 64, 2, True, 0),
+])
+def test_gemm(gpu_lib, M, N, K, act, use_res, pool4):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A, Ad = bf(torch.randn(M, K, generator=g))
+    W, Wd = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    Mo = M // 4 if pool4 else M
+    res = torch.randn(Mo, N, generator=g) if use_res else None
+    ref = (A.double() @ W.double().T + bias.double())
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    elif act == 3:
+        ref = torch.sigmoid(ref)
+    if pool4:
+        ref = ref.view(Mo, 4, N).max(1).values
+    if use_res:
+        ref = ref + res.double()
+    out_f = torch.zeros(Mo, N, dtype=torch.float32, device="cuda")
+    out_b = torch.zeros(Mo, N, dtype=torch.int16, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias.cuda()), ptr(res.cuda()) if use_res else None, ptr(out_f), ptr(out_b),
+                                        M, N, K, act, 0, pool4, 0, 0, None))
+    scale = ref.abs().max().item() + 1e-6
+    err = (out_f.cpu().double() - ref).abs().max().item() / scale
+    assert err < 2e-5, err
+    errb = (from_bf(out_b).double() - ref).abs().max().item() / scale
+    assert errb < 5e-3, errb
+
+
+def test_gemm_act_last_and_res_mod(gpu_lib):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 640, 128, 64
+    A, Ad = bf(torch.randn(M, K, generator=g))
+    W, Wd = bf(torch.randn(N, K, generator=g) / 8)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(160, N, generator=g)
+    ref = F.gelu(A.double() @ W.double().T + bias.double() + res.double().repeat(4, 1))
+    out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias.cuda()), ptr(res.cuda()), ptr(out_f), None, M, N, K, 1, 1, 0, 0, 160, None))
+    assert (out_f.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("rows,C,act", [(1000, 144, 0), (333, 576, 0), (64, 1152, 0), (4096, 64, 1), (17, 256, 0)])
+def test_layernorm(gpu_lib, rows, C, act):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(rows, C, generator=g) * 3 + 1
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-6)
+    if act:
+        ref = F.gelu(ref)
+    of = torch.zeros(rows, C, device="cuda")
+    ob = torch.zeros(rows, C, dtype=torch.int16, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_layernorm(ptr(x.cuda()), ptr(gam.cuda()), ptr(bet.cuda()), 1e-6, ptr(of), ptr(ob), rows, C, act, None))
+    assert (of.cpu().double() - ref).abs().max().item() < 2e-5
+    assert (from_bf(ob).double() - ref).abs().max().item() < 0.03 * ref.abs().max().item()
+
+
+def ref_hiera_attention(qkv, n_windows, nk, heads, q_pool):
+    hd = 72
+    t = qkv.view(n_windows, nk, 3, heads, hd).double()
+    q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+    if q_pool:
+        q = q.view(n_windows, nk // 4, 4, heads, hd).max(2).values
+    q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
+    return a.transpose(1, 2).reshape(-1, heads * hd)
+
+
+@pytest.mark.parametrize("n_windows,nk,heads,q_pool", [
+    (9, 64, 2, 0), (5, 64, 4, 1), (33, 16, 4, 0), (7, 16, 8, 1), (3, 256, 8, 0), (2, 256, 16, 1), (1, 4096, 8, 0), (2, 128, 2, 0),
+])
+def test_hiera_attention(gpu_lib, n_windows, nk, heads, q_pool):
+    g = torch.Generator().manual_seed(nk + heads)
+    qkv, qd = bf(torch.randn(n_windows * nk, 3 * heads * 72, generator=g) * 1.5)
+    ref = ref_hiera_attention(qkv, n_windows, nk, heads, q_pool)
+    out = torch.zeros(ref.shape, dtype=torch.int16, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_hiera_attention(ptr(qd), ptr(out), n_windows, nk, heads, q_pool, None))
+    got = from_bf(out).double()
+    err = (got - ref).abs().max().item()
+    assert err < 0.03, err  # |v| ~ 1.5: bf16 P and bf16 output rounding
+    assert ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 6e-3
+
+
+@pytest.mark.parametrize("B,nq,nk,heads,hd,shared", [(3, 4096, 8, 8, 16, 0), (5, 8, 8, 8, 32, 0), (4, 8, 4096, 8, 16, 0), (4, 8, 4096, 8, 16, 1)])
+def test_dec_attention(gpu_lib, B, nq, nk, heads, hd, shared):
+    g = torch.Generator().manual_seed(nq + nk)
+    C_ = heads * hd
+    q = torch.randn(B, nq, C_, generator=g)
+    k = torch.randn(1 if shared else B, nk, C_, generator=g)
+    v = torch.randn(1 if shared else B, nk, C_, generator=g)
+    qq = q.view(B, nq, heads, hd).transpose(1, 2).double()
+    kk = k.expand(B, -1, -1).reshape(B, nk, heads, hd).transpose(1, 2).double()
+    vv = v.expand(B, -1, -1).reshape(B, nk, heads, hd).transpose(1, 2).double()
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) / hd ** 0.5, -1) @ vv).transpose(1, 2).reshape(B, nq, C_)
+    out = torch.zeros(B, nq, C_, dtype=torch.int16, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_dec_attention(ptr(q.cuda()), ptr(k.cuda()), ptr(v.cuda()), ptr(out), B, nq, nk, heads, hd, shared, None))
+    assert (from_bf(out).double() - ref).abs().max().item() < 0.02
+
+
+@pytest.mark.parametrize("crop", [(0, 0, 1024, 1024), (100, 50, 597, 400), (700, 724, 300, 300), (10, 20, 200, 100)])
+def test_mask_post(gpu_lib, crop):
+    x0, y0, cw, ch = crop
+    H = W = 1024
+    g = torch.Generator().manual_seed(cw)
+    n = 5
+    low = F.interpolate(torch.randn(n, 1, 16, 16, generator=g) * 4, size=(256, 256), mode="bicubic")[:, 0].contiguous()
+    low[4] = -5.0  # empty mask
+    full = F.interpolate(low[:, None], size=(ch, cw), mode="bilinear", align_corners=False)[:, 0]
+    thr, off = 0.0, 0.7
+    ref_mask = torch.zeros(n, H, W, dtype=torch.bool)
+    ref_mask[:, y0:y0 + ch, x0:x0 + cw] = full > thr
+    bits = torch.zeros(n, H, W // 32, dtype=torch.int32, device="cuda")
+    stats = torch.zeros(n, 8, dtype=torch.int32, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_mask_post(ptr(low.cuda()), n, x0, y0, cw, ch, H, W, thr, off, ptr(bits), ptr(stats), None))
+    from saber_amd.engine import unpack_bits
+    got = unpack_bits(bits, W)
+    st = stats.cpu().numpy()
+    for i in range(n):
+        diff = np.logical_xor(got[i], ref_mask[i].numpy()).sum()
+        assert diff <= 3, (i, diff)  # pixels whose logit sits within fp32 rounding of the threshold
+        assert abs(int(st[i, 0]) - int(ref_mask[i].sum())) <= 3
+        assert abs(int(st[i, 1]) - int((full[i] > thr + off).sum())) <= 3
+        assert abs(int(st[i, 2]) - int((full[i] > thr - off).sum())) <= 3
+        assert int(st[i, 0]) == int(got[i].sum())
+        if got[i].any():
+            ys, xs = np.where(got[i])
+            assert (st[i, 3], st[i, 4], st[i, 5], st[i, 6]) == (xs.min(), ys.min(), xs.max(), ys.max())
+    assert st[4, 0] == 0 and st[4, 5] == -1
+
+
+@pytest.mark.parametrize("dtype", ["u16", "f32"])
+def test_prepare(gpu_lib, dtype):
+    from oracle import saber_ref
+    img = saber_ref.synthetic_slice(seed=0)
+    if dtype == "u16":
+        dev = torch.from_numpy(img).cuda()
+        ref = saber_ref.prepare(img.astype(np.float32))
+        dt = 0
+    else:
+        f = (img.astype(np.float32) - 30000.0) / 7.0
+        dev = torch.from_numpy(f).cuda()
+        ref = saber_ref.prepare(f)
+        dt = 1
+    out = torch.zeros(1024, 1024, device="cuda")
+    ws = torch.zeros(4, 1024, 1024, device="cuda")
+    mm = torch.zeros(2, dtype=torch.int32, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_prepare(ptr(dev), dt, 1024, 1024, ptr(out), ptr(ws), ptr(mm), None))
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < 2e-4, err
+    assert out.min().item() == 0.0 and abs(out.max().item() - 1.0) < 1e-6
+
+
+def test_perm_index_is_window_contiguous(lib):
+    # every Hiera-L window is a contiguous, aligned run of rows; 2x2 pooling groups are 4 consecutive rows
+    for stage, win in ((0, 8), (1, 4), (2, 16), (3, 8)):
+        g = 256 >> stage
+        idx = np.array([[lib.saber_k_perm_index(y, x, stage) for x in range(g)] for y in range(g)])
+        assert sorted(idx.ravel().tolist()) == list(range(g * g))
+        for wy in range(0, g, win):
+            for wx in range(0, g, win):
+                w = idx[wy:wy + win, wx:wx + win].ravel()
+                assert w.max() - w.min() == win * win - 1 and w.min() % (win * win) == 0
+        for y in range(0, g, 2):
+            for x in range(0, g, 2):
+                q = idx[y:y + 2, x:x + 2].ravel()
+                assert q.tolist() == list(range(q[0], q[0] + 4)) and q[0] % 4 == 0
