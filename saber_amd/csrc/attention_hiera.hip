@@ -321,11 +321,13 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     }
 }
 
-void hiera_attention_init_device() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+const char* hiera_attention_init_device() {
+    hipError_t st = hipSuccess;
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         K_LDS_BYTES + V_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         K_LDS_BYTES + V_LDS_BYTES);
+    return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
 const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int q_pool,

@@ -18,9 +18,11 @@ extern "C" const char* saber_k_last_error(void) { return g_kerr.c_str(); }
 
 extern "C" int saber_k_init(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return kfail("hipSetDevice failed");
-    gemm_init_device();
-    hiera_attention_init_device();
-    image_ops_init_device();
+    const char* m = gemm_init_device();
+    if (!m) m = hiera_attention_init_device();
+    if (!m) m = image_ops_init_device();
+    (void)hipGetLastError();
+    if (m) return kfail(m);
     return 0;
 }
 

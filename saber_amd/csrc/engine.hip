@@ -88,9 +88,13 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     e->max_images = max_images;
     e->max_prompts = max_prompts;
     hiera_large_spec(e);
-    gemm_init_device();
-    hiera_attention_init_device();
-    image_ops_init_device();
+    {
+        const char* m = gemm_init_device();
+        if (!m) m = hiera_attention_init_device();
+        if (!m) m = image_ops_init_device();
+        (void)hipGetLastError();
+        if (m) { delete e; return eng_fail(nullptr, SABER_ERR_HIP, std::string("kernel attribute setup: ") + m); }
+    }
     *out = e;
     return SABER_OK;
 }

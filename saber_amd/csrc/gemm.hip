@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
-void gemm_init_device() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+const char* gemm_init_device() {
+    hipError_t st = hipSuccess;
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
 const char* launch_gemm(const GemmParams& p, hipStream_t stream) {

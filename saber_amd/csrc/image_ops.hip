@@ -124,7 +124,7 @@ static const char* prepare_impl(const TIN* img, int H, int W, float* out, float*
     const int64_t n = (int64_t)H * W;
     float *t1 = ws, *t2 = ws + n, *mean = ws + 2 * n, *sq = ws + 3 * n;
     auto lds_bytes = [&](int L) { const int npad = ((L + size - 1 + 255) / 256) * 256; return (size_t)2 * (npad + 1) * sizeof(double); };
-    if (lds_bytes(H) > 160 * 1024 || lds_bytes(W) > 160 * 1024) return "prepare: image side too large for the LDS line buffer";
+    if (lds_bytes(H) > 152 * 1024 || lds_bytes(W) > 152 * 1024) return "prepare: image side too large for the LDS line buffer";
     // scipy filters axis 0 first (lines = columns), then axis 1 (lines = rows)
     hipLaunchKernelGGL((box_filter_lines_kernel<TIN, true>), dim3(W), dim3(256), lds_bytes(H), s, img, (const float*)nullptr, t1, t2, H,
                        (int64_t)1, (int64_t)W, size);
@@ -143,10 +143,12 @@ const char* launch_prepare_f32(const float* img, int H, int W, float* out, float
     return prepare_impl<float>(img, H, W, out, ws, minmax, s);
 }
 
-void image_ops_init_device() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(box_filter_lines_kernel<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(box_filter_lines_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(box_filter_lines_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+const char* image_ops_init_device() {
+    hipError_t st = hipSuccess;
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(box_filter_lines_kernel<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(box_filter_lines_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(box_filter_lines_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
 // ------------------------------------------------------------------------------------------------ K1a

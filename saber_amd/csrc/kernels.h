@@ -26,7 +26,7 @@ struct GemmParams {
     int batch = 1;
 };
 const char* launch_gemm(const GemmParams& p, hipStream_t stream);
-void gemm_init_device();
+const char* gemm_init_device();
 
 // ------------------------------------------------------------------ layernorm.hip
 struct LayerNormParams {
@@ -43,7 +43,7 @@ const char* launch_add_to_bf16(const float* x, const float* y, int ymod, bf16_t*
 // ------------------------------------------------------------------ attention_hiera.hip
 // qkv: bf16 [tokens][3*heads*72]; out: bf16 [tokens_q][heads*72]; windows are contiguous runs of nk rows.
 const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int q_pool, hipStream_t s);
-void hiera_attention_init_device();
+const char* hiera_attention_init_device();
 
 // ------------------------------------------------------------------ image_ops.hip
 const char* launch_prepare_u16(const uint16_t* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s);
@@ -52,7 +52,7 @@ const char* launch_resize_normalize(const float* img, int H, int W, int channels
                                     hipStream_t s);
 const char* launch_patch_embed(const float* pix, const float* wt, const float* bias, const float* pos, float* out, int n_images,
                                int C, int res, hipStream_t s);
-void image_ops_init_device();
+const char* image_ops_init_device();
 
 // ------------------------------------------------------------------ decoder_ops.hip
 struct PromptWeights {

@@ -58,7 +58,8 @@ def test_gemm(gpu_lib, M, N, K, act, use_res, pool4):
         ref = ref + res.double()
     out_f = torch.zeros(Mo, N, dtype=torch.float32, device="cuda")
     out_b = torch.zeros(Mo, N, dtype=torch.int16, device="cuda")
-    kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias.cuda()), ptr(res.cuda()) if use_res else None, ptr(out_f), ptr(out_b),
+    bias_d, res_d = bias.cuda(), (res.cuda() if use_res else None)  # keep device operands alive across the call
+    kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias_d), ptr(res_d), ptr(out_f), ptr(out_b),
                                         M, N, K, act, 0, pool4, 0, 0, None))
     scale = ref.abs().max().item() + 1e-6
     err = (out_f.cpu().double() - ref).abs().max().item() / scale
@@ -76,7 +77,8 @@ def test_gemm_act_last_and_res_mod(gpu_lib):
     res = torch.randn(160, N, generator=g)
     ref = F.gelu(A.double() @ W.double().T + bias.double() + res.double().repeat(4, 1))
     out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda")
-    kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias.cuda()), ptr(res.cuda()), ptr(out_f), None, M, N, K, 1, 1, 0, 0, 160, None))
+    bias_d, res_d = bias.cuda(), res.cuda()
+    kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias_d), ptr(res_d), ptr(out_f), None, M, N, K, 1, 1, 0, 0, 160, None))
     assert (out_f.cpu().double() - ref).abs().max().item() < 1e-4
 
 
@@ -90,7 +92,8 @@ def test_layernorm(gpu_lib, rows, C, act):
         ref = F.gelu(ref)
     of = torch.zeros(rows, C, device="cuda")
     ob = torch.zeros(rows, C, dtype=torch.int16, device="cuda")
-    kcall(gpu_lib, gpu_lib.saber_k_layernorm(ptr(x.cuda()), ptr(gam.cuda()), ptr(bet.cuda()), 1e-6, ptr(of), ptr(ob), rows, C, act, None))
+    xd, gd, bd = x.cuda(), gam.cuda(), bet.cuda()
+    kcall(gpu_lib, gpu_lib.saber_k_layernorm(ptr(xd), ptr(gd), ptr(bd), 1e-6, ptr(of), ptr(ob), rows, C, act, None))
     assert (of.cpu().double() - ref).abs().max().item() < 2e-5
     assert (from_bf(ob).double() - ref).abs().max().item() < 0.03 * ref.abs().max().item()
 
@@ -133,7 +136,8 @@ def test_dec_attention(gpu_lib, B, nq, nk, heads, hd, shared):
     vv = v.expand(B, -1, -1).reshape(B, nk, heads, hd).transpose(1, 2).double()
     ref = (torch.softmax(qq @ kk.transpose(-1, -2) / hd ** 0.5, -1) @ vv).transpose(1, 2).reshape(B, nq, C_)
     out = torch.zeros(B, nq, C_, dtype=torch.int16, device="cuda")
-    kcall(gpu_lib, gpu_lib.saber_k_dec_attention(ptr(q.cuda()), ptr(k.cuda()), ptr(v.cuda()), ptr(out), B, nq, nk, heads, hd, shared, None))
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    kcall(gpu_lib, gpu_lib.saber_k_dec_attention(ptr(qd), ptr(kd), ptr(vd), ptr(out), B, nq, nk, heads, hd, shared, None))
     assert (from_bf(out).double() - ref).abs().max().item() < 0.02
 
 
@@ -151,7 +155,8 @@ def test_mask_post(gpu_lib, crop):
     ref_mask[:, y0:y0 + ch, x0:x0 + cw] = full > thr
     bits = torch.zeros(n, H, W // 32, dtype=torch.int32, device="cuda")
     stats = torch.zeros(n, 8, dtype=torch.int32, device="cuda")
-    kcall(gpu_lib, gpu_lib.saber_k_mask_post(ptr(low.cuda()), n, x0, y0, cw, ch, H, W, thr, off, ptr(bits), ptr(stats), None))
+    low_d = low.cuda()
+    kcall(gpu_lib, gpu_lib.saber_k_mask_post(ptr(low_d), n, x0, y0, cw, ch, H, W, thr, off, ptr(bits), ptr(stats), None))
     from saber_amd.engine import unpack_bits
     got = unpack_bits(bits, W)
     st = stats.cpu().numpy()
@@ -200,7 +205,7 @@ def test_perm_index_is_window_contiguous(lib):
             for wx in range(0, g, win):
                 w = idx[wy:wy + win, wx:wx + win].ravel()
                 assert w.max() - w.min() == win * win - 1 and w.min() % (win * win) == 0
-        for y in range(0, g, 2):
+        for y in range(0, g if stage < 3 else 0, 2):  # no pooling happens out of the last stage
             for x in range(0, g, 2):
                 q = idx[y:y + 2, x:x + 2].ravel()
                 assert q.tolist() == list(range(q[0], q[0] + 4)) and q[0] % 4 == 0
