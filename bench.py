@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py - EM slices/sec (1024^2, Hiera-L) on N MI355X, plus the roofline of the dominant kernel and a
+CPU baseline timed beside it.
+
+A "step" is one pass of the hot path over one synthetic 1024x1024 uint16 EM slice already resident in HBM:
+K0 prepare (prep.prepare) -> automatic mask generation with SABER's cfgAMG defaults (crop_n_layers=2: 21 crops,
+3072 grid prompts + 9216 m2m refinements) -> host filter/sort of the reference's
+saber2D._apply_classifier (min area, duplicate removal, ascending-area sort) -> uint16 label plane
+(propagation.py:185-186).  That is BASELINE.json configs[1] ("single 1024x1024 slice, Hiera-L bf16,
+automatic-mask-generator (grid prompts) on 1 MI355X").  Weights are seeded synthetic tensors of the Hiera-L
+architecture (no checkpoint is available offline).
+
+N > 1: one process per GPU (torchrun), every rank segments its own K slices (weak scaling, no data-path
+collective per slice) and the K label planes per rank are all-gathered over RCCL at the end of the timed region,
+as the tomogram driver does for a z-sharded volume.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--crop-n-layers", type=int, default=2, help="cfgAMG.crop_n_layers (SABER default 2)")
+    ap.add_argument("--npoints", type=int, default=32)
+    ap.add_argument("--max-images", type=int, default=8, help="crops encoded per batched pass")
+    ap.add_argument("--max-prompts", type=int, default=128, help="prompts decoded per batched pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, weights, image01, crop_n_layers):
+    """Oracle ("port") timed on the host cores on a bounded sample: 1 Hiera-L encoder pass + one 64-prompt
+    first-pass decoder batch + its 192 m2m refinements + their full-res post-processing; extrapolated to one slice
+    by the reference's work counts (21 crops / 3072 + 9216 prompts for crop_n_layers=2)."""
+    from oracle import sam2_ref
+    from oracle.amg_ref import calculate_stability_score
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, 32))  # torch CPU GEMMs stop scaling (and thrash) far below the 256 logical CPUs of the GPU host
+    torch.set_num_threads(cores)
+    P = sam2_ref.ImagePredictorRef(weights, cfg)
+    img3 = np.repeat(image01[..., None], 3, 2)
+    t0 = time.perf_counter()
+    P.set_image(img3)
+    t_enc = time.perf_counter() - t0
+    g = (np.arange(8) + 0.5) / 8 * 1024.0
+    pts = torch.tensor(np.stack(np.meshgrid(g, g), -1).reshape(-1, 2).astype(np.float32))
+    lab = torch.ones(64, 1, dtype=torch.int64)
+    t0 = time.perf_counter()
+    masks, iou, low = P._predict(pts[:, None], lab, None, True)
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pts3 = pts.repeat_interleave(3, 0)
+    lowf = low.flatten(0, 1)
+    m2, i2, _ = P._predict(pts3[:64, None], torch.ones(64, 1, dtype=torch.int64), lowf[:64, None], False)
+    calculate_stability_score(m2.squeeze(1), 0.0, 0.7)
+    t_m2m = 3.0 * (time.perf_counter() - t0)  # one of the three 64-prompt m2m batches is timed
+    n_side = [2 ** (i + 1) for i in range(crop_n_layers)]
+    n_crops = 1 + sum(n * n for n in n_side)
+    n_first = sum((32 // (2 ** l)) ** 2 * (1 if l == 0 else (2 ** l) ** 2) for l in range(crop_n_layers + 1))
+    per_slice = n_crops * t_enc + n_first / 64.0 * (t_first + t_m2m)
+    return {"value": 1.0 / per_slice, "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 torch CPU, {cores} threads: 1 encoder pass ({t_enc:.2f}s) + 64 grid prompts ({t_first:.2f}s) + 64 of their 192 "
+                      f"m2m refinements incl. stability score (x3 = {t_m2m:.2f}s); extrapolated to {n_crops} crops / {n_first} grid prompts per slice",
+            "seconds_sampled": t_enc + t_first + t_m2m / 3.0}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from saber_amd.engine import Engine, make_amg_params
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    from saber_amd.segmenters.slice_driver import segment_slice_to_plane
+    from oracle import saber_ref  # synthetic input recipe only (data generation, not the measured path)
+
+    cfg = get_config("large")
+    weights = seeded_weights(cfg, 0)
+    eng = Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts)
+    amg = dict(npoints=a.npoints, crop_n_layers=a.crop_n_layers)
+    params = make_amg_params(amg)
+
+    pool = [torch.from_numpy(saber_ref.synthetic_slice(seed=1000 * rank + i)).cuda() for i in range(2)]
+    torch.cuda.synchronize()
+
+    def step(i, planes=None):
+        plane, n_masks = segment_slice_to_plane(eng, pool[i % len(pool)], params, min_mask_area=50)
+        if planes is not None:
+            planes[i] = plane
+        return n_masks
+
+    for i in range(a.warmup):
+        step(i)
+    planes = torch.zeros((a.steps, 1024, 1024), dtype=torch.uint16, device="cuda")
+    gathered = torch.zeros((world * a.steps, 1024, 1024), dtype=torch.uint16, device="cuda") if world > 1 else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_masks = 0
+    for i in range(a.steps):
+        n_masks += step(i, planes)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered.view(torch.int16), planes.view(torch.int16))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        n_side = [2 ** (i + 1) for i in range(a.crop_n_layers)]
+        n_crops = 1 + sum(n * n for n in n_side)
+        n_first = sum((a.npoints // (2 ** l)) ** 2 * (1 if l == 0 else (2 ** l) ** 2) for l in range(a.crop_n_layers + 1))
+        alg_flops_slice = n_crops * eng.encoder_flops() + 4 * n_first * 3.639e9
+        out = {
+            "metric": "EM slices/sec (1024^2, Hiera-L)", "value": world * a.steps / dt, "unit": "slices/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"1024x1024 uint16 EM slice -> prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults: npoints={a.npoints}, "
+                                   f"crop_n_layers={a.crop_n_layers} -> {n_crops} crops, {n_first} grid prompts + {3 * n_first} m2m refinements, multimask) "
+                                   f"-> dedup/sort -> uint16 label plane; BASELINE configs[1]",
+                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)", "slices_per_rank": a.steps,
+                       "parallelism": f"slice-sharded x{world}, all_gather of label planes" if world > 1 else "single GPU",
+                       "masks_per_slice": n_masks / max(1, a.steps), "algorithmic_tflop_per_slice": alg_flops_slice / 1e12},
+            "achieved_tflops_algorithmic": alg_flops_slice * world * a.steps / dt / 1e12,
+        }
+    if rank == 0 and world == 1 and not a.no_profile:
+        eng.profile_begin()
+        step(0)
+        prof = eng.profile_end()
+        g = prof["gemm_bf16"]
+        total_ms = sum(v["ms"] for v in prof.values())
+        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                           "kernel": "gemm_bf16_kernel", "launches_per_slice": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
+                           "kernel_ms_per_slice": g["ms"], "share_of_kernel_time": g["ms"] / total_ms if total_ms else None}
+        out["kernel_classes_ms_per_slice"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+        out["kernel_classes_launches"] = {k: v["launches"] for k, v in prof.items()}
+        mp = prof["mask_post"]
+        if mp["ms"] > 0:
+            out["mask_post_hbm"] = {"bound": "hbm", "achieved": mp["bytes"] / (mp["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"}
+        # encoder-only figure (the north star's roofline target is defined on the Hiera-L encoder)
+        img = eng.prepare(pool[0])
+        reps, nb = 3, a.max_images
+        crops = [[0, 0, 1024, 1024]] * nb
+        eng.encode(img, crops)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.encode(img, crops)
+        torch.cuda.synchronize()
+        te = (time.perf_counter() - t0) / (reps * nb)
+        out["encoder_only"] = {"passes_per_s": 1.0 / te, "ms_per_pass": te * 1e3, "batch": nb, "algorithmic_tflops": eng.encoder_flops() / te / 1e12,
+                               "frac_of_bf16_peak": eng.encoder_flops() / te / 2.5e15}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        img01 = eng.prepare(pool[0]).cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(cfg, weights, img01, a.crop_n_layers)
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

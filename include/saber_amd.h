@@ -114,6 +114,18 @@ int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int 
 int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, const int* order_host, int n, int H, int W,
                       uint16_t* plane_dev, void* stream);
 
+/* out_inter_dev[i*n+j] = |mask_i AND mask_j| in pixels for the n bit-packed masks: the integer counts behind
+ * remove_duplicate_masks' IoU (saber/segmenters/utils.py:21-29); IoU = inter / (area_i + area_j - inter). */
+int saber_mask_pair_intersections(saber_engine* e, const uint32_t* bits_dev, int n, int H, int W, int32_t* out_inter_dev, void* stream);
+
+/* Per-launch HIP-event profiling of the engine's own kernels, by kernel class (events are recorded on the
+ * stream the kernels are launched on).  Class order: 0 gemm_bf16, 1 hiera_attention, 2 layernorm,
+ * 3 decoder_attention, 4 elementwise, 5 image_ops, 6 mask_post.  flops / bytes are ALGORITHMIC. */
+typedef struct saber_profile_class { int64_t launches; double ms; double flops; double bytes; } saber_profile_class;
+#define SABER_PROFILE_CLASSES 7
+int saber_profile_begin(saber_engine* e);
+int saber_profile_end(saber_engine* e, saber_profile_class* out, int n_classes);
+
 /* Algorithmic work counters (FLOPs per call) for roofline reporting. */
 double saber_encoder_flops(const saber_engine* e);
 double saber_decoder_flops_per_prompt(void);

@@ -37,6 +37,12 @@ class MaskMeta(C.Structure):
                 ("stability_score", C.c_float), ("point_xy", C.c_float * 2), ("crop_box_xywh", C.c_float * 4)]
 
 
+class ProfileClass(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+PROFILE_CLASSES = ("gemm_bf16", "hiera_attention", "layernorm", "decoder_attention", "elementwise", "image_ops", "mask_post")
+
 # name -> (restype, argtypes); mirrors include/*.h one-to-one (tests/test_abi.py checks the symbol list)
 _vp, _i, _f, _i64p = C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_int64)
 SIGNATURES = {
@@ -51,6 +57,9 @@ SIGNATURES = {
     "saber_decode_points": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),
     "saber_label_plane": (_i, [_vp, _vp, C.POINTER(_i), _i, _i, _i, _vp, _vp]),
+    "saber_mask_pair_intersections": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "saber_profile_begin": (_i, [_vp]),
+    "saber_profile_end": (_i, [_vp, C.POINTER(ProfileClass), _i]),
     "saber_encoder_flops": (C.c_double, [_vp]),
     "saber_decoder_flops_per_prompt": (C.c_double, []),
     "saber_k_last_error": (C.c_char_p, []),

@@ -200,7 +200,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             TRY(crop_reserve((size_t)ns));
             uint32_t* crop_bits = e->amg_crop_bits;
             ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
-            ENG_K(e, launch_mask_post(masks, e->amg_idx, ns, box[0], box[1], cw, chh, H, W, prm->mask_threshold, prm->stability_score_offset,
+            ENG_KP(e, PC_MASK_POST, 0.0, (double)ns * (65536.0 * 4 + (double)mask_words * 4), launch_mask_post(masks, e->amg_idx, ns, box[0], box[1], cw, chh, H, W, prm->mask_threshold, prm->stability_score_offset,
                                       crop_bits, e->amg_stats, s));
             h_stats.resize(ns);
             ENG_HIP(e, hipMemcpyAsync(h_stats.data(), e->amg_stats, sizeof(MaskStats) * ns, hipMemcpyDeviceToHost, s));

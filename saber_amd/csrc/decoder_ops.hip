@@ -504,3 +504,37 @@ const char* launch_unpermute_nchw(const float* tok, int C, int stage, float* out
     hipLaunchKernelGGL(unpermute_nchw_kernel, dim3(blocks), dim3(256), 0, s, tok, C, stage, out);
     return nullptr;
 }
+
+// ------------------------------------------------------------------------------------------------
+// pairwise mask intersections on bit-packed masks: inter[i][j] = popcount(bits_i & bits_j), i <= j
+// (the integer counts behind reference remove_duplicate_masks' IoU, saber/segmenters/utils.py:21-29).
+__global__ __launch_bounds__(256) void pair_inter_kernel(const uint32_t* __restrict__ bits, int n, int64_t words, int* __restrict__ inter) {
+    const int i = blockIdx.y, j = blockIdx.x;
+    if (j < i) return;
+    const uint4* a = reinterpret_cast<const uint4*>(bits + (int64_t)i * words);
+    const uint4* b = reinterpret_cast<const uint4*>(bits + (int64_t)j * words);
+    const int64_t nv = (words & 3) ? 0 : (words >> 2);  // rows of other masks stay 16-B aligned only when words % 4 == 0
+    int acc = 0;
+    for (int64_t k = threadIdx.x; k < nv; k += 256) {
+        const uint4 x = a[k], y = b[k];
+        acc += __popc(x.x & y.x) + __popc(x.y & y.y) + __popc(x.z & y.z) + __popc(x.w & y.w);
+    }
+    for (int64_t k = (nv << 2) + threadIdx.x; k < words; k += 256) acc += __popc(bits[(int64_t)i * words + k] & bits[(int64_t)j * words + k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = part[0] + part[1] + part[2] + part[3];
+        inter[(int64_t)i * n + j] = t;
+        inter[(int64_t)j * n + i] = t;
+    }
+}
+
+const char* launch_pair_intersections(const uint32_t* bits, int n, int64_t words, int* inter, hipStream_t s) {
+    if (n <= 0) return nullptr;
+    if ((uintptr_t)bits & 15) return "pair_intersections: masks must be 16-byte aligned";
+    hipLaunchKernelGGL(pair_inter_kernel, dim3(n, n), dim3(256), 0, s, bits, n, words, inter);
+    return nullptr;
+}

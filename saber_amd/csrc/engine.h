@@ -20,6 +20,9 @@ struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
 struct AttnW { LinW q, k, v, o; };
 struct DecLayerW { AttnW self_attn, t2i, i2t; LnW n1, n2, n3, n4; LinW mlp1, mlp2; };
 
+enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_N };
+struct ProfRec { int cls; double flops; double bytes; hipEvent_t a, b; };
+
 struct saber_engine {
     int device = 0;
     std::string trunk;
@@ -87,7 +90,23 @@ struct saber_engine {
     uint32_t* amg_crop_bits = nullptr; size_t amg_crop_words = 0;   // one crop's pred_iou survivors
     MaskStats* amg_stats = nullptr; int* amg_idx = nullptr; size_t amg_stats_cap = 0;
     int* order_dev = nullptr; size_t order_cap = 0;
+
+    // optional per-launch HIP-event profiling (saber_profile_begin / saber_profile_end)
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
 };
+
+void prof_begin(saber_engine* e, int cls, double flops, double bytes, hipStream_t s);
+void prof_end(saber_engine* e, hipStream_t s);
+// profiled launch: records a HIP event pair around `call` on stream `s` when profiling is on
+#define ENG_KP(e, cls, flops, bytes, call)                               \
+    do {                                                                 \
+        prof_begin((e), (cls), (flops), (bytes), s);                     \
+        const char* _m = (call);                                         \
+        prof_end((e), s);                                                \
+        if (_m) return eng_fail((e), SABER_ERR_INVALID, _m);             \
+    } while (0)
 
 int eng_fail(saber_engine* e, int code, const std::string& msg);
 #define ENG_HIP(e, call)                                                                              \

@@ -469,6 +469,38 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     return SABER_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ profiling
+void prof_begin(saber_engine* e, int cls, double flops, double bytes, hipStream_t s) {
+    if (!e->prof_on) return;
+    while (e->ev_pool.size() < e->ev_used + 2) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { e->prof_on = false; return; } e->ev_pool.push_back(ev); }
+    ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = e->ev_pool[e->ev_used++]; r.b = e->ev_pool[e->ev_used++];
+    (void)hipEventRecord(r.a, s);
+    e->prof.push_back(r);
+}
+void prof_end(saber_engine* e, hipStream_t s) {
+    if (!e->prof_on || e->prof.empty()) return;
+    (void)hipEventRecord(e->prof.back().b, s);
+}
+extern "C" int saber_profile_begin(saber_engine* e) {
+    if (!e) return SABER_ERR_INVALID;
+    e->prof.clear(); e->ev_used = 0; e->prof_on = true;
+    return SABER_OK;
+}
+extern "C" int saber_profile_end(saber_engine* e, saber_profile_class* out, int n_classes) {
+    if (!e || !out || n_classes < PC_N) return e ? eng_fail(e, SABER_ERR_INVALID, "profile_end: need room for all classes") : SABER_ERR_INVALID;
+    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_HIP(e, hipDeviceSynchronize());
+    e->prof_on = false;
+    for (int i = 0; i < n_classes; ++i) { out[i].launches = 0; out[i].ms = 0.0; out[i].flops = 0.0; out[i].bytes = 0.0; }
+    for (const ProfRec& r : e->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes;
+    }
+    e->prof.clear(); e->ev_used = 0;
+    return SABER_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ helpers
 static GemmParams mk_gemm(const bf16_t* A, int64_t lda, int M, const LinW& w) {
     GemmParams p;
@@ -495,8 +527,8 @@ extern "C" int saber_prepare(saber_engine* e, const void* img_dev, int dtype, in
         TRY(eng_alloc(e, &e->prep_ws, need));
         e->prep_ws_elems = need;
     }
-    if (dtype == SABER_U16) ENG_K(e, launch_prepare_u16((const uint16_t*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
-    else if (dtype == SABER_F32) ENG_K(e, launch_prepare_f32((const float*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
+    if (dtype == SABER_U16) ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_prepare_u16((const uint16_t*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
+    else if (dtype == SABER_F32) ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_prepare_f32((const float*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
     else return eng_fail(e, SABER_ERR_INVALID, "prepare: dtype must be SABER_U16 or SABER_F32");
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;
@@ -512,8 +544,8 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         if (c[0] < 0 || c[1] < 0 || c[2] > W || c[3] > H || c[2] <= c[0] || c[3] <= c[1]) return eng_fail(e, SABER_ERR_INVALID, "encode: crop box outside the image");
     }
     ENG_HIP(e, hipMemcpyAsync(e->crops_dev, crops_host, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
-    ENG_K(e, launch_resize_normalize(img_dev, H, W, channels, e->crops_dev, n, e->pix, 1024, s));
-    ENG_K(e, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
+    ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_resize_normalize(img_dev, H, W, channels, e->crops_dev, n, e->pix, 1024, s));
+    ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
     float* x = e->xa;
     float* xalt = e->xb;
     int tokens = 65536;  // per image, current stage
@@ -522,62 +554,62 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         const BlockSpec& bs = e->blocks[i];
         const BlockW& w = e->bw[i];
         const int N = n * tokens;
-        ENG_K(e, ln_run(x, w.n1, 1e-6f, N, bs.din, nullptr, e->xn, ACT_NONE, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, w.n1, 1e-6f, N, bs.din, nullptr, e->xn, ACT_NONE, s));
         float* xres = x;
         int Nq = N;
         if (bs.din != bs.dout) {
             GemmParams g = mk_gemm(e->xn, bs.din, N, w.sc);
             g.Cf = xalt; g.ldcf = bs.dout; g.pool4 = 1;
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
             xres = xalt;
             Nq = N / 4;
         }
         {
             GemmParams g = mk_gemm(e->xn, bs.din, N, w.qkv);
             g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
         const int nk = bs.window > 0 ? bs.window * bs.window : tokens;
-        ENG_K(e, launch_hiera_attention(e->qkv, e->att, N / nk, nk, bs.heads, bs.q_stride > 1, s));
+        ENG_KP(e, PC_HIERA_ATTN, 4.0 * 72.0 * (double)N * (bs.q_stride > 1 ? nk / 4 : nk) * bs.heads, 0.0, launch_hiera_attention(e->qkv, e->att, N / nk, nk, bs.heads, bs.q_stride > 1, s));
         {
             GemmParams g = mk_gemm(e->att, bs.dout, Nq, w.proj);
             g.Cf = xres; g.ldcf = bs.dout; g.res = xres; g.ldres = bs.dout;
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
         if (bs.din != bs.dout) { std::swap(x, xalt); tokens /= 4; ++stage; }
-        ENG_K(e, ln_run(x, w.n2, 1e-6f, Nq, bs.dout, nullptr, e->xn, ACT_NONE, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, w.n2, 1e-6f, Nq, bs.dout, nullptr, e->xn, ACT_NONE, s));
         {
             GemmParams g = mk_gemm(e->xn, bs.dout, Nq, w.fc1);
             g.Cb = e->hid; g.ldcb = 4 * bs.dout; g.act = ACT_GELU;
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
         {
             GemmParams g = mk_gemm(e->hid, 4 * bs.dout, Nq, w.fc2);
             g.Cf = x; g.ldcf = bs.dout; g.res = x; g.ldres = bs.dout;
             if ((int)i == e->stage_ends[stage]) { g.Cb = e->sb[stage]; g.ldcb = bs.dout; }
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
     }
     // neck
     {
         GemmParams g = mk_gemm(e->sb[3], e->stage_dims[3], n * 1024, e->neck3);
         g.Cf = e->lat3; g.ldcf = 256;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[2], e->stage_dims[2], n * 4096, e->neck2);
         g.Cf = e->emb + (size_t)slot0 * 4096 * 256; g.ldcf = 256; g.res = e->lat3; g.ldres = 256; g.res_shift = 2;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[1], e->stage_dims[1], n * 16384, e->s1);
         g.Cf = e->fs1 + (size_t)slot0 * 16384 * 64; g.ldcf = 64;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[0], e->stage_dims[0], n * 65536, e->s0);
         g.Cf = e->fs0 + (size_t)slot0 * 65536 * 32; g.ldcf = 32;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
     for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
     ENG_HIP(e, hipGetLastError());
@@ -597,9 +629,9 @@ extern "C" int saber_get_features(saber_engine* e, int slot, float* image_embed,
     if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot]) return eng_fail(e, SABER_ERR_STATE, "get_features: slot holds no encoded image; call saber_encode first");
     ENG_HIP(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    if (image_embed) ENG_K(e, launch_unpermute_nchw(e->emb + (size_t)slot * 4096 * 256, 256, 2, image_embed, s));
-    if (feat_s1) ENG_K(e, launch_unpermute_nchw(e->fs1 + (size_t)slot * 16384 * 64, 64, 1, feat_s1, s));
-    if (feat_s0) ENG_K(e, launch_unpermute_nchw(e->fs0 + (size_t)slot * 65536 * 32, 32, 0, feat_s0, s));
+    if (image_embed) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_unpermute_nchw(e->emb + (size_t)slot * 4096 * 256, 256, 2, image_embed, s));
+    if (feat_s1) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_unpermute_nchw(e->fs1 + (size_t)slot * 16384 * 64, 64, 1, feat_s1, s));
+    if (feat_s0) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_unpermute_nchw(e->fs0 + (size_t)slot * 65536 * 32, 32, 0, feat_s0, s));
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;
 }
@@ -608,17 +640,17 @@ extern "C" int saber_get_features(saber_engine* e, int slot, float* image_embed,
 static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
     if (e->slot_shared_valid[slot]) return SABER_OK;
     const size_t o256 = (size_t)slot * 4096 * 256, o128 = (size_t)slot * 4096 * 128;
-    ENG_K(e, launch_add_to_bf16(e->emb + o256, e->no_mask_embed, 1, e->src0_bf + o256, e->src0_f + o256, 4096, 256, s));
-    ENG_K(e, launch_add_to_bf16(e->src0_f + o256, e->dense_pe, 4096, e->src0pos_bf + o256, nullptr, 4096, 256, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->emb + o256, e->no_mask_embed, 1, e->src0_bf + o256, e->src0_f + o256, 4096, 256, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->src0_f + o256, e->dense_pe, 4096, e->src0pos_bf + o256, nullptr, 4096, 256, s));
     GemmParams g = mk_gemm(e->src0pos_bf + o256, 256, 4096, e->dl[0].t2i.k);
     g.Cf = e->k0 + o128; g.ldcf = 128;
-    ENG_K(e, launch_gemm(g, s));
+    ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     g = mk_gemm(e->src0_bf + o256, 256, 4096, e->dl[0].t2i.v);
     g.Cf = e->v0 + o128; g.ldcf = 128;
-    ENG_K(e, launch_gemm(g, s));
+    ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     g = mk_gemm(e->src0pos_bf + o256, 256, 4096, e->dl[0].i2t.q);
     g.Cf = e->qi0 + o128; g.ldcf = 128;
-    ENG_K(e, launch_gemm(g, s));
+    ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     e->slot_shared_valid[slot] = 1;
     return SABER_OK;
 }
@@ -629,86 +661,86 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
     const int PT = P * T;
     const size_t o256 = (size_t)slot * 4096 * 256, o128 = (size_t)slot * 4096 * 128;
     const bool shared = (mask_in == nullptr);
-    ENG_K(e, launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
     ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
     if (shared) TRY(ensure_shared(e, slot, s));
-    else ENG_K(e, launch_mask_embed_src(mask_in, P, e->emb + o256, e->dense_pe, e->mw, e->keys, e->keys_bf, e->keyspos_bf, s));
+    else ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_embed_src(mask_in, P, e->emb + o256, e->dense_pe, e->mw, e->keys, e->keys_bf, e->keyspos_bf, s));
 
     auto t2i = [&](const AttnW& a, const LnW& ln, bool use_shared) -> int {
-        ENG_K(e, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         GemmParams g = mk_gemm(e->t_bf0, 256, PT, a.q);
         g.Cf = e->tq; g.ldcf = 128;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         const float *K, *V;
         int64_t kbs;
         if (use_shared) { K = e->k0 + o128; V = e->v0 + o128; kbs = 0; }
         else {
             g = mk_gemm(e->keyspos_bf, 256, P * 4096, a.k);
             g.Cf = e->kp; g.ldcf = 128;
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
             g = mk_gemm(e->keys_bf, 256, P * 4096, a.v);
             g.Cf = e->vp; g.ldcf = 128;
-            ENG_K(e, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
             K = e->kp; V = e->vp; kbs = (int64_t)4096 * 128;
         }
-        ENG_K(e, launch_dec_attention(e->tq, K, V, e->t_att, P, T, 4096, 8, 16, T * 128, kbs, kbs, T * 128, s));
+        ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(e->tq, K, V, e->t_att, P, T, 4096, 8, 16, T * 128, kbs, kbs, T * 128, s));
         g = mk_gemm(e->t_att, 128, PT, a.o);
         g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
-        ENG_K(e, launch_gemm(g, s));
-        ENG_K(e, ln_run(e->queries, ln, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, ln, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         return SABER_OK;
     };
 
     for (int l = 0; l < 2; ++l) {
         const DecLayerW& w = e->dl[l];
         // (1) self attention of the tokens
-        ENG_K(e, launch_add_to_bf16(e->queries, l == 0 ? nullptr : e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, l == 0 ? nullptr : e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         const bf16_t* vin = e->t_bf0;
-        if (l > 0) { ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s)); vin = e->t_bf1; }
-        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_K(e, launch_gemm(g, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_K(e, launch_gemm(g, s));
-        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_K(e, launch_gemm(g, s));
-        ENG_K(e, launch_dec_attention(e->tq, e->tk, e->tv, e->t_att, P, T, T, 8, 32, T * 256, T * 256, T * 256, T * 256, s));
+        if (l > 0) { ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s)); vin = e->t_bf1; }
+        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(e->tq, e->tk, e->tv, e->t_att, P, T, T, 8, 32, T * 256, T * 256, T * 256, T * 256, s));
         g = mk_gemm(e->t_att, 256, PT, w.self_attn.o);
         g.Cf = e->queries; g.ldcf = 256;
         if (l > 0) { g.res = e->queries; g.ldres = 256; }
-        ENG_K(e, launch_gemm(g, s));
-        ENG_K(e, ln_run(e->queries, w.n1, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, w.n1, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         // (2) tokens -> image
         TRY(t2i(w.t2i, w.n2, shared && l == 0));
         // (3) MLP
-        ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_K(e, launch_gemm(g, s));
-        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_K(e, launch_gemm(g, s));
-        ENG_K(e, ln_run(e->queries, w.n3, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, w.n3, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         // (4) image -> tokens
-        ENG_K(e, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
-        ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_K(e, launch_gemm(g, s));
-        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         const float* Q;
         int64_t qbs;
         if (shared && l == 0) { Q = e->qi0 + o128; qbs = 0; }
         else {
-            g = mk_gemm(e->keyspos_bf, 256, P * 4096, w.i2t.q); g.Cf = e->qp; g.ldcf = 128; ENG_K(e, launch_gemm(g, s));
+            g = mk_gemm(e->keyspos_bf, 256, P * 4096, w.i2t.q); g.Cf = e->qp; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
             Q = e->qp; qbs = (int64_t)4096 * 128;
         }
-        ENG_K(e, launch_dec_attention(Q, e->tk, e->tv, e->iatt_bf, P, 4096, T, 8, 16, qbs, T * 128, T * 128, (int64_t)4096 * 128, s));
+        ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(Q, e->tk, e->tv, e->iatt_bf, P, 4096, T, 8, 16, qbs, T * 128, T * 128, (int64_t)4096 * 128, s));
         g = mk_gemm(e->iatt_bf, 128, P * 4096, w.i2t.o);
         g.Cf = e->keys; g.ldcf = 256; g.ldres = 256;
         if (shared && l == 0) { g.res = e->src0_f + o256; g.res_mod = 4096; }
         else g.res = e->keys;
-        ENG_K(e, launch_gemm(g, s));
-        ENG_K(e, ln_run(e->keys, w.n4, 1e-5f, P * 4096, 256, e->keys, e->keys_bf, ACT_NONE, s, e->keyspos_bf, e->dense_pe, 4096));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->keys, w.n4, 1e-5f, P * 4096, 256, e->keys, e->keys_bf, ACT_NONE, s, e->keyspos_bf, e->dense_pe, 4096));
     }
     TRY(t2i(e->final_attn, e->final_ln, false));
 
     // heads
-    ENG_K(e, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
     auto mlp3 = [&](const LinW* L, const bf16_t* A, int last_act, float* outf, int ldo) -> int {
-        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_K(e, launch_gemm(g, s));
-        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_K(e, launch_gemm(g, s));
-        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_K(e, launch_gemm(g, s));
+        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         return SABER_OK;
     };
     TRY(mlp3(e->iou_head, e->t_bf0 + 1 * 256, ACT_SIGMOID, e->iou4, 4));
@@ -717,31 +749,31 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
         GemmParams g = mk_gemm(e->t_bf0 + 2 * 256, T * 256, P, e->hyper[0]);
         g.batch = 4; g.strideA = 256; g.strideW = 256 * 256; g.strideBias = 256;
         g.Cb = e->head_bf0; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         g = mk_gemm(e->head_bf0, 256, P, e->hyper[1]);
         g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 256 * 256; g.strideBias = 256;
         g.Cb = e->head_bf1; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         g = mk_gemm(e->head_bf1, 256, P, e->hyper[2]);
         g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 32 * 256; g.strideBias = 32;
         g.Cf = e->hyper_out; g.ldcf = 128; g.strideCf = 32;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
     // upscaling: dc1 + feat_s1 -> LN2d -> GELU -> dc2 + feat_s0 -> GELU
     {
         GemmParams g = mk_gemm(e->keys_bf, 256, P * 4096, e->dc1);
         g.Cf = e->u1; g.ldcf = 256; g.res = e->fs1 + (size_t)slot * 16384 * 64; g.ldres = 256; g.res_mod = 4096;
-        ENG_K(e, launch_gemm(g, s));
-        ENG_K(e, ln_run(e->u1, e->up_ln, 1e-6f, P * 16384, 64, nullptr, e->u1b, ACT_GELU, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->u1, e->up_ln, 1e-6f, P * 16384, 64, nullptr, e->u1b, ACT_GELU, s));
         g = mk_gemm(e->u1b, 64, P * 16384, e->dc2);
         g.Cb = e->up2; g.ldcb = 128; g.res = e->fs0 + (size_t)slot * 65536 * 32; g.ldres = 128; g.res_mod = 16384;
         g.act = ACT_GELU; g.act_last = 1;
-        ENG_K(e, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
-    ENG_K(e, launch_mask_dot(e->up2, e->hyper_out, P, e->masks4, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_dot(e->up2, e->hyper_out, P, e->masks4, s));
     float* om = out_lowres ? out_lowres : e->dec_out_masks;
     float* oi = out_iou ? out_iou : e->dec_out_iou;
-    ENG_K(e, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
     return SABER_OK;
 }
 
@@ -783,7 +815,18 @@ extern "C" int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, cons
         ENG_HIP(e, hipMemcpyAsync(e->order_dev, order_host, sizeof(int) * n, hipMemcpyHostToDevice, s));
         od = e->order_dev;
     }
-    ENG_K(e, launch_label_plane(bits_dev, od, n, H, W, plane_dev, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_label_plane(bits_dev, od, n, H, W, plane_dev, s));
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ duplicate-mask support
+extern "C" int saber_mask_pair_intersections(saber_engine* e, const uint32_t* bits_dev, int n, int H, int W, int32_t* out_inter_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (n < 0 || H <= 0 || W <= 0 || (n > 0 && (!bits_dev || !out_inter_dev))) return eng_fail(e, SABER_ERR_INVALID, "mask_pair_intersections: bad argument");
+    ENG_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    ENG_KP(e, PC_MASK_POST, 0.0, (double)n * n * 0.5 * H * ((W + 31) / 32) * 8.0, launch_pair_intersections(bits_dev, n, (int64_t)H * ((W + 31) >> 5), out_inter_dev, s));
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;
 }

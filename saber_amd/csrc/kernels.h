@@ -89,5 +89,7 @@ const char* launch_mask_post(const float* lowres, const int* idx, int n, int cro
                              int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s);
 // paint label planes: plane[y][x] = max over i (in order) ... later masks overwrite earlier ones (propagation.py:185-186)
 const char* launch_label_plane(const uint32_t* bits, const int* order, int n, int H, int W, uint16_t* plane, hipStream_t s);
+// inter[i][j] = popcount(mask_i & mask_j) on bit-packed masks (n x words uint32)
+const char* launch_pair_intersections(const uint32_t* bits, int n, int64_t words, int* inter, hipStream_t s);
 // gather token-major [tokens][C] (engine order, stage s grid) -> NCHW fp32 for inspection / parity tests
 const char* launch_unpermute_nchw(const float* tok, int C, int stage, float* out, hipStream_t s);

@@ -139,6 +139,22 @@ class Engine:
         self._check(self.lib.saber_label_plane(self.h, _ptr(bits) if n else None, arr, n, H, W, _ptr(plane), _stream()))
         return plane
 
+    def pair_intersections(self, bits: torch.Tensor, H: int, W: int) -> torch.Tensor:
+        n = bits.shape[0]
+        inter = torch.empty((n, n), dtype=torch.int32, device=self.device)
+        self._check(self.lib.saber_mask_pair_intersections(self.h, _ptr(bits) if n else None, n, H, W, _ptr(inter) if n else None, _stream()))
+        return inter
+
+    def profile_begin(self):
+        self._check(self.lib.saber_profile_begin(self.h))
+
+    def profile_end(self) -> dict:
+        n = len(_lib.PROFILE_CLASSES)
+        arr = (_lib.ProfileClass * n)()
+        self._check(self.lib.saber_profile_end(self.h, arr, n))
+        return {name: {"launches": int(arr[i].launches), "ms": float(arr[i].ms), "flops": float(arr[i].flops), "bytes": float(arr[i].bytes)}
+                for i, name in enumerate(_lib.PROFILE_CLASSES)}
+
     def encoder_flops(self) -> float:
         return float(self.lib.saber_encoder_flops(self.h))
 

@@ -1,0 +1,92 @@
+"""Device-resident slice pipeline and the z-sharded volume driver.
+
+`segment_slice_to_plane` is one iteration of the reference's volumetric hot loop
+(propagationSegmenter.slice_by_slice, saber/segmenters/propagation.py:180-188) with every array kept in HBM:
+
+    segment_image (base.py:143-149) -> adapter.segment_image_2d (adapters/sam2/predictor.py:48-70)
+        prep.prepare            -> K0 on device
+        mask_generator.generate -> saber_amg_generate (bit-packed masks + per-mask scalars)
+        FilteredSAM2MaskGenerator area filter (amg.py:87-110, min_area_filter = min_mask_area)
+    _apply_classifier (base.py:159-176): area >= min_mask_area, remove_duplicate_masks, ascending-area sort
+    paint idx+1 in list order (later masks overwrite), np.maximum with the zero plane (:185-188)
+
+`segment_volume_sharded` is the multi-GPU form: rank r owns a contiguous z-chunk, planes are all-gathered
+(RCCL when the process group is NCCL, gloo in the CPU tests) and rank 0 (or every rank) stitches with separate_masks.
+"""
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import utils
+
+
+def select_and_order(meta, inter: np.ndarray, min_mask_area: int, remove_repeating_masks: bool = True):
+    """Host decisions of saber2D._apply_classifier (classifier=None) on per-mask scalars.
+    Returns indices into `meta` in final (paint) order."""
+    idx = [i for i, m in enumerate(meta) if m.area >= min_mask_area]
+    if remove_repeating_masks and idx:
+        sub = inter[np.ix_(idx, idx)]
+        keep = utils.duplicate_groups_from_counts([meta[i].area for i in idx], sub, [meta[i].stability_score for i in idx])
+        idx = [idx[k] for k in keep]
+    idx.sort(key=lambda i: meta[i].area)  # sorted() is stable: ties keep AMG order
+    return idx
+
+
+def segment_slice_to_plane(engine, raw_slice: torch.Tensor, params, min_mask_area: int = 50,
+                           remove_repeating_masks: bool = True, max_masks: int = 1024) -> Tuple[torch.Tensor, int]:
+    """raw_slice: (H,W) uint16/float32 device tensor.  Returns ((H,W) uint16 label plane on device, n masks)."""
+    H, W = raw_slice.shape
+    img = engine.prepare(raw_slice)
+    bits, meta = engine.amg_generate(img, params, max_masks=max_masks)
+    if len(meta) == 0:
+        return torch.zeros((H, W), dtype=torch.uint16, device=raw_slice.device), 0
+    inter = engine.pair_intersections(bits, H, W).cpu().numpy() if remove_repeating_masks else None
+    order = select_and_order(meta, inter, min_mask_area, remove_repeating_masks)
+    plane = engine.label_plane(bits, order, H, W)
+    return plane, len(order)
+
+
+def shard_bounds(Z: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous z-chunks, remainder spread over the first ranks."""
+    base, rem = divmod(Z, world)
+    z0 = rank * base + min(rank, rem)
+    return z0, z0 + base + (1 if rank < rem else 0)
+
+
+def segment_volume_sharded(volume, slice_fn: Callable[[int], torch.Tensor], stitch: bool = True, min_mask_area: int = 100,
+                           group=None) -> Optional[np.ndarray]:
+    """Slice-parallel slice_by_slice.  `volume` only supplies the shape (Z,H,W); `slice_fn(z)` returns the uint16
+    label plane of slice z as a tensor on this rank's device.  All ranks receive every plane (all_gather of equal,
+    zero-padded chunks); the (Z,H,W) uint32 stitched labels are returned (reference: utils.separate_masks)."""
+    import torch.distributed as dist
+    Z, H, W = volume.shape
+    dist_on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if dist_on else 1
+    rank = dist.get_rank(group) if dist_on else 0
+    z0, z1 = shard_bounds(Z, world, rank)
+    chunk = (Z + world - 1) // world
+    dev = None
+    local = None
+    for i, z in enumerate(range(z0, z1)):
+        p = slice_fn(z)
+        if local is None:
+            dev = p.device
+            local = torch.zeros((chunk, H, W), dtype=torch.int16, device=dev)
+        local[i] = p.view(torch.int16) if p.dtype == torch.uint16 else p.to(torch.int16)
+    if local is None:  # rank without slices
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and dist_on and dist.get_backend(group) == "nccl" else torch.device("cpu")
+        local = torch.zeros((chunk, H, W), dtype=torch.int16, device=dev)
+    if world > 1:
+        full = torch.empty((world * chunk, H, W), dtype=torch.int16, device=dev)
+        dist.all_gather_into_tensor(full, local, group=group)
+    else:
+        full = local
+    planes = np.empty((Z, H, W), dtype=np.uint16)
+    full_np = full.cpu().numpy().view(np.uint16)
+    for r in range(world):
+        a, b = shard_bounds(Z, world, r)
+        planes[a:b] = full_np[r * chunk: r * chunk + (b - a)]
+    if not stitch:
+        return planes
+    return utils.separate_masks(planes, min_mask_area=min_mask_area)
