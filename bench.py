@@ -126,7 +126,7 @@ def main():
     for i in range(a.steps):
         n_masks += step(i, planes)
     if world > 1:
-        dist.all_gather_into_tensor(gathered.view(torch.int16), planes.view(torch.int16))
+        dist.all_gather_into_tensor(gathered.view(torch.uint8), planes.view(torch.uint8))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

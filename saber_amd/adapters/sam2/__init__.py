@@ -1,0 +1,3 @@
+from saber_amd.adapters.sam2.predictor import SAM2Adapter
+
+__all__ = ["SAM2Adapter"]

@@ -1,0 +1,88 @@
+"""Mask-generator construction (reference: saber/adapters/sam2/automask.py).
+
+build_amg (:49-86) returns FilteredSAM2MaskGenerator(base=<generator>, min_area_filter=min_mask_area) where the
+base generator is built with SABER's AMG parameters (:66-78).  Here the base generator is EngineMaskGenerator:
+`generate(image)` calls saber_amg_generate and unpacks the bit-packed masks into the SAM-AMG dict schema at the
+API edge."""
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from saber_amd import pretrained_weights
+from saber_amd.adapters.sam2 import amg as fmask
+
+_ENGINES: Dict[Any, Any] = {}
+
+
+def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 8, max_prompts: int = 128):
+    """One engine per (device, trunk, weights): the reference builds a second SAM2 copy for AMG;
+    here adapter and generator share one handle."""
+    from saber_amd.engine import Engine
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type != "cuda":
+        raise RuntimeError(f"the MI355X engine needs a ROCm device, got '{dev}' (there is no CPU fallback)")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    src = pretrained_weights.resolve_weights(sam2_cfg, checkpoint)
+    key = (idx, sam2_cfg, tuple(sorted(src.items())))
+    if key not in _ENGINES:
+        _ENGINES[key] = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, **src)
+    return _ENGINES[key]
+
+
+def get_default() -> Dict[str, Any]:
+    """Default AMG parameters of the reference (automask.py:29-46)."""
+    return {"npoints": 32, "points_per_batch": 64, "pred_iou_thresh": 0.7, "stability_score_thresh": 0.92,
+            "stability_score_offset": 0.7, "crop_n_layers": 2, "box_nms_thresh": 0.7, "crop_n_points_downscale_factor": 2,
+            "use_m2m": True, "multimask_output": True}
+
+
+class EngineMaskGenerator:
+    """generate(image) with the contract of sam2.SAM2AutomaticMaskGenerator.generate."""
+
+    def __init__(self, engine, amg_params: Dict[str, Any], max_masks: int = 2048):
+        from saber_amd.engine import make_amg_params
+        self.engine = engine
+        self.params = make_amg_params(amg_params)
+        self.max_masks = max_masks
+
+    @torch.inference_mode()
+    def generate_device(self, image):
+        """image: (H,W)/(H,W,3) float32 in [0,1], numpy or device tensor -> (bits, meta) on the device."""
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(self.engine.device)
+        return self.engine.amg_generate(image.contiguous(), self.params, max_masks=self.max_masks)
+
+    def generate(self, image) -> List[Dict[str, Any]]:
+        from saber_amd.engine import unpack_bits
+        W = image.shape[1]
+        bits, meta = self.generate_device(image)
+        masks = unpack_bits(bits, W) if len(meta) else []
+        return [{"segmentation": masks[i], "area": int(m.area), "bbox": [float(v) for v in m.bbox_xywh],
+                 "predicted_iou": float(m.predicted_iou), "point_coords": [[float(m.point_xy[0]), float(m.point_xy[1])]],
+                 "stability_score": float(m.stability_score), "crop_box": [float(v) for v in m.crop_box_xywh]}
+                for i, m in enumerate(meta)]
+
+
+def build_amg(amg_params: Dict[str, Any], min_mask_area: int, device="cuda", checkpoint: Optional[str] = None):
+    engine = get_engine(amg_params["sam2_cfg"], device, checkpoint)
+    return fmask.FilteredSAM2MaskGenerator(base_generator=EngineMaskGenerator(engine, amg_params), min_area_filter=min_mask_area)
+
+
+def amg_cli():
+    """click options of the reference's amg_cli decorator (automask.py:9-24), same flags and defaults."""
+    import click
+
+    def decorator(f):
+        f = click.option("-cfg", "--sam2-cfg", required=False, default="small", help="SAM2 Model Config",
+                         type=click.Choice(["large", "base", "small", "tiny"], case_sensitive=False))(f)
+        f = click.option("-npts", "--npoints", type=int, default=32, help="Number of points per side")(f)
+        f = click.option("-nbatch", "--points-per-batch", type=int, default=64, help="Number of points per batch")(f)
+        f = click.option("-iou", "--pred-iou-thresh", type=float, default=0.7, help="Prediction IOU threshold")(f)
+        f = click.option("-nlayers", "--crop-n-layers", type=int, default=2, help="Number of crop layers")(f)
+        f = click.option("-box", "--box-nms-thresh", type=float, default=0.7, help="Box NMS threshold")(f)
+        f = click.option("-crop", "--crop-n-points", type=int, default=2, help="Crop N Points Downscale Factor")(f)
+        f = click.option("-m2m", "--use-m2m", type=bool, default=True, help="Use M2M")(f)
+        f = click.option("-multi", "--multimask", type=bool, default=True, help="Multimask Output")(f)
+        return f
+    return decorator

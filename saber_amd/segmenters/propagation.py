@@ -1,0 +1,91 @@
+"""propagationSegmenter (reference: saber/segmenters/propagation.py): volume segmenters for FIB / light / any
+stack.  `slice_by_slice` (:163-189) is the volumetric hot loop this build accelerates: every z-slice is segmented
+independently, painted into a uint16 label plane (idx+1, later masks overwrite), merged with np.maximum and the
+stack is stitched by 3-D connected components.
+
+Two implementations with identical results:
+  * slice_by_slice           - the reference's loop shape over the adapter API (numpy dict lists at the edge);
+  * slice_by_slice_device    - the device-resident, z-sharded form (saber_amd.segmenters.slice_driver): masks stay
+                               bit-packed in HBM, label planes are painted by a HIP kernel and all-gathered over
+                               RCCL when torch.distributed is initialised.
+The seed-and-propagate entry points (segment / single_segment / multiclass_segment) need the video predictor and
+are a 'next' row."""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from saber_amd.adapters.base import AdapterConfig
+from saber_amd.adapters.sam2.amg import cfgAMG
+from saber_amd.segmenters import utils
+from saber_amd.segmenters.base import saber3D
+
+
+class propagationSegmenter(saber3D):
+    def __init__(self, deviceID: int = 0, cfg: Optional[AdapterConfig] = None, amg_cfg: Optional[cfgAMG] = None,
+                 min_mask_area: int = 100, min_rel_box_size: float = 0.025):
+        self.min_rel_box_size = min_rel_box_size
+        super().__init__(deviceID=deviceID, cfg=cfg, amg_cfg=amg_cfg, min_mask_area=min_mask_area)
+        self.ini_depth = 10
+
+    @torch.inference_mode()
+    def segment_3d(self, vol, masks, ann_frame_idx: int = None):
+        if not self._vol_loaded:
+            self.video_predictor.set_volume(vol)
+            self._vol_loaded = True
+        self.masks = masks
+        nx = vol.shape[0]
+        ny, nz = self.masks[0].shape[0], self.masks[0].shape[1]
+        self.ann_frame_idx = ann_frame_idx if ann_frame_idx is not None else nx // 2
+        return self.propagate((nx, ny, nz))
+
+    def segment(self, volume: np.ndarray, ini_depth: int, nframes: int = None, target_class: int = 1,
+                text_prompt: str = None, display: bool = False):
+        self.ini_depth, self.nframes, self.target_class, self.display = ini_depth, nframes, target_class, display
+        return self.single_segment(volume, text_prompt=text_prompt)
+
+    @torch.inference_mode()
+    def single_segment(self, volume: np.ndarray, text_prompt: str = None):
+        final = np.zeros(volume.shape, dtype=np.uint16)
+        for ii in range(2, volume.shape[0], self.ini_depth):
+            masks = self.segment_image(volume[ii], display=False, target_class=self.target_class, text_prompt=text_prompt)
+            if len(masks) == 0:
+                continue
+            masks3d = self.segment_3d(volume, [m["segmentation"] for m in masks], ann_frame_idx=ii)
+            if self.target_class > 0:
+                masks3d = (masks3d > 0).astype(np.uint8)
+            np.maximum(final, masks3d, out=final)
+        return utils.separate_masks(final)
+
+    @torch.inference_mode()
+    def slice_by_slice(self, volume: np.ndarray, text_prompt: str = None):
+        """Independent 2-D segmentation of every slice, stitched in 3-D (reference :163-189)."""
+        final = np.zeros(volume.shape, dtype=np.uint16)
+        plane = np.zeros(volume.shape[1:], dtype=np.uint16)
+        for z in range(volume.shape[0]):
+            masks = self.segment_image(volume[z], display=False, text_prompt=text_prompt)
+            if len(masks) == 0:
+                continue
+            for idx, m in enumerate(masks):
+                plane[m["segmentation"]] = idx + 1
+            np.maximum(final[z], plane, out=final[z])
+            plane[:] = 0
+        return utils.separate_masks(final)
+
+    @torch.inference_mode()
+    def slice_by_slice_device(self, volume, text_prompt: str = None, stitch: bool = True):
+        """Same result as slice_by_slice, computed with device-resident masks and z-sharded over the ranks of the
+        default torch.distributed process group (single process: all slices)."""
+        from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
+        gen = self.adapter._generator()
+        eng, params = gen.base_generator.engine, gen.base_generator.params
+
+        def one(z):
+            sl = volume[z]
+            if isinstance(sl, np.ndarray):
+                sl = torch.from_numpy(np.ascontiguousarray(sl if sl.dtype == np.uint16 else sl.astype(np.float32))).to(eng.device)
+            plane, _ = segment_slice_to_plane(eng, sl, params, min_mask_area=self.min_mask_area,
+                                              remove_repeating_masks=self.remove_repeating_masks)
+            return plane
+
+        return segment_volume_sharded(volume, one, stitch=stitch)

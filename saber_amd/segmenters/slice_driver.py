@@ -79,7 +79,8 @@ def segment_volume_sharded(volume, slice_fn: Callable[[int], torch.Tensor], stit
         local = torch.zeros((chunk, H, W), dtype=torch.int16, device=dev)
     if world > 1:
         full = torch.empty((world * chunk, H, W), dtype=torch.int16, device=dev)
-        dist.all_gather_into_tensor(full, local, group=group)
+        # byte view: gloo (CPU tests) has no int16 collectives; RCCL moves the same bytes
+        dist.all_gather_into_tensor(full.view(torch.uint8), local.view(torch.uint8), group=group)
     else:
         full = local
     planes = np.empty((Z, H, W), dtype=np.uint16)

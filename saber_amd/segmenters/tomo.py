@@ -1,0 +1,63 @@
+"""tomoSegmenter (reference: saber/segmenters/tomo.py:14-139).  segment_slab's 2-D path (z-smoothing -> normalise ->
+slab projection -> segment_image) is kept; segment_vol continues into SAM2 video propagation, which is a 'next' row
+ and raises through the adapter.  The z Gaussian (filters/gaussian.py:17-74, sigma 5, conv1d) is host
+glue outside the per-slice loop and is evaluated with scipy's separable filter of the same kernel."""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from saber_amd.adapters.base import AdapterConfig
+from saber_amd.adapters.sam2.amg import cfgAMG
+from saber_amd.segmenters.base import saber3D
+from saber_amd.utils import preprocessing as preprocess
+
+
+def make_gaussian_kernel(sigma: float) -> np.ndarray:
+    """Kernel of the reference (filters/gaussian.py:7-15): odd size max(round(3 sigma), 3), taps on linspace(-ks/2, ks/2, ks)."""
+    ks = max(round(sigma * 3), 3)
+    ks += 1 - ks % 2
+    ts = np.linspace(-ks / 2, ks / 2, ks, dtype=np.float32)
+    g = np.exp(-(ts / np.float32(sigma)) ** 2 / 2).astype(np.float32)
+    return g / g.sum()
+
+
+def gaussian_smoothing_z(vol: np.ndarray, sigma: float, dim: int = 0) -> np.ndarray:
+    """1-D Gaussian along `dim`: conv1d with zero 'same' padding of the reference kernel (filters/gaussian.py:17-74)."""
+    from scipy.ndimage import correlate1d
+    return correlate1d(np.asarray(vol, dtype=np.float32), make_gaussian_kernel(sigma), axis=dim, mode="constant", cval=0.0)
+
+
+class tomoSegmenter(saber3D):
+    def __init__(self, deviceID: int = 0, cfg: Optional[AdapterConfig] = None, amg_cfg: Optional[cfgAMG] = None, min_mask_area: int = 50):
+        super().__init__(deviceID=deviceID, cfg=cfg, amg_cfg=amg_cfg, min_mask_area=min_mask_area)
+        self.filter_threshold = 0.5
+
+    @torch.inference_mode()
+    def segment_slab(self, vol, slab_thickness: int = 10, zSlice: Optional[int] = None, display: bool = True,
+                     text: Optional[str] = None, target_class: Optional[int] = 1):
+        self.vol = preprocess.normalize(gaussian_smoothing_z(vol, 5, dim=0))
+        if zSlice is None:
+            zSlice = int(self.vol.shape[0] // 2)
+        self.image0 = preprocess.project_tomogram(self.vol, zSlice, slab_thickness)
+        self.segment_image(self.image0, display=display, text_prompt=text, target_class=target_class)
+        return self.masks
+
+    def segment(self, vol, thickness: int = 10, zSlice: int = None, text: Optional[str] = None, target_class: Optional[int] = 1,
+                save_run: str = None, display: bool = False):
+        return self.segment_vol(vol, thickness, zSlice, text, target_class, save_run, display)
+
+    @torch.inference_mode()
+    def segment_vol(self, vol, thickness: int, zSlice: int = None, text: Optional[str] = None, target_class: Optional[int] = 1,
+                    save_run: str = None, display: bool = False):
+        self.is_tomogram_mode = True
+        self.segment_slab(vol, thickness, zSlice, display=False, text=text, target_class=target_class)
+        if len(self.masks) == 0:
+            return None
+        if not self._vol_loaded:
+            self.video_predictor.set_volume(self.vol)   # raises NotImplementedError: propagation is a next row
+            self._vol_loaded = True
+        nx = self.vol.shape[0]
+        ny, nz = self.masks[0]["segmentation"].shape
+        self.ann_frame_idx = zSlice if zSlice is not None else nx // 2
+        return self.propagate((nx, ny, nz))

@@ -1,0 +1,146 @@
+"""CPU: the oracle and the product's host glue against fixtures captured from the REFERENCE's own code
+(tests/golden/saber_glue.npz, written by oracle/make_golden.py importing /root/reference) and against
+HF-validated model outputs (tests/golden/sam2_tiny_seed0.npz, oracle/make_golden_model.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "saber_glue.npz"), allow_pickle=False)
+
+
+def test_oracle_prepare_matches_reference():
+    from oracle import saber_ref
+    raw = saber_ref.synthetic_slice(seed=int(G["prep_raw_seed"]))
+    p = saber_ref.prepare(raw.astype(np.float32), to_rgb=True)
+    assert p.dtype == np.float32 and p.shape == (1024, 1024, 3)
+    assert np.array_equal(p[::16, ::16, 0], G["prep_out_sub"])          # bit-exact: same scipy calls
+    assert np.allclose([p.min(), p.max(), p.mean(), p.std()], G["prep_out_stats"], rtol=0, atol=1e-7)
+    assert bool(G["prep_out_rgb_equal"])
+    small = G["prep_small_in"]
+    assert np.array_equal(saber_ref.contrast(small, 3), G["prep_small_contrast"])
+    assert np.array_equal(saber_ref.prepare(small), G["prep_small_out"])
+
+
+def test_host_normalize_project_match_reference():
+    from saber_amd.utils import preprocessing as prep
+    from oracle import saber_ref
+    vol = G["vol_in"]
+    for fn in (prep.project_tomogram, saber_ref.project_tomogram):
+        assert np.array_equal(fn(vol, 10, 3), G["proj_z10_d3"])
+        assert np.array_equal(fn(vol, 1, 5), G["proj_z1_d5"])
+        assert np.array_equal(fn(vol, 7, None), G["proj_z7"])
+        assert np.array_equal(fn(vol), G["proj_all"])
+    assert np.array_equal(prep.normalize(vol), G["vol_normalized"])
+
+
+def test_z_gaussian_matches_reference():
+    from saber_amd.segmenters.tomo import gaussian_smoothing_z, make_gaussian_kernel
+    assert np.allclose(make_gaussian_kernel(5), G["gauss_kernel_s5"], rtol=0, atol=1e-7)
+    out = gaussian_smoothing_z(G["vol_in"], 5, dim=0)
+    assert np.allclose(out, G["gauss_z_s5"], rtol=0, atol=2e-6)  # conv1d vs correlate1d summation order
+
+
+def test_remove_duplicate_masks_matches_reference():
+    from saber_amd.segmenters import utils
+    masks, stab = G["dedup_masks"], G["dedup_stab"]
+    dicts = [{"segmentation": m, "area": int(m.sum()), "stability_score": float(s), "id": i} for i, (m, s) in enumerate(zip(masks, stab))]
+    kept = utils.remove_duplicate_masks(dicts)
+    assert [d["id"] for d in kept] == G["dedup_kept_ids"].tolist()
+    assert len(kept) < len(dicts)  # the fixture does contain duplicates
+    # the count-driven form used by the device path decides identically
+    flat = masks.reshape(len(masks), -1).astype(np.float32)
+    inter = np.rint(flat @ flat.T).astype(np.int64)
+    keep = utils.duplicate_groups_from_counts([int(m.sum()) for m in masks], inter, stab.tolist())
+    assert keep == G["dedup_kept_ids"].tolist()
+    assert utils.remove_duplicate_masks([]) == []
+
+
+def test_separate_masks_matches_reference():
+    from saber_amd.segmenters import utils
+    assert np.array_equal(utils.separate_masks(G["sep_in"]), G["sep_out_default"])
+    out5 = utils.separate_masks(G["sep_in"], min_mask_area=5)
+    assert out5.dtype == np.uint32 and np.array_equal(out5, G["sep_out_min5"])
+    assert out5.max() > 0
+    assert np.array_equal(utils.separate_masks(np.zeros((3, 8, 8), np.uint16)), G["sep_out_empty"])
+
+
+class _FakeAdapter:
+    def __init__(self):
+        self.masks, self.stab = G["sbs_masks"], G["sbs_stab"]
+
+    def segment_image_2d(self, image, text_prompt=None, threshold=None):
+        z = int(round(float(image[0, 0])))
+        return [{"segmentation": m, "area": int(m.sum()), "stability_score": float(s), "bbox": [0, 0, 1, 1]}
+                for m, s in zip(self.masks[z], self.stab[z])]
+
+    def reset_state(self):
+        pass
+
+
+@pytest.fixture()
+def fake_segmenter(monkeypatch):
+    import saber_amd.segmenters.base as sbase
+    from saber_amd.segmenters.propagation import propagationSegmenter
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    monkeypatch.setattr(sbase, "get_adapter", lambda cfg, dev: _FakeAdapter())
+    return propagationSegmenter(amg_cfg=cfgAMG(), min_mask_area=30)
+
+
+def test_slice_by_slice_matches_reference(fake_segmenter):
+    volume = np.zeros((6, 48, 64), dtype=np.float32)
+    for z in range(6):
+        volume[z] = z
+    out = fake_segmenter.slice_by_slice(volume, None)
+    assert out.dtype == np.uint32 and np.array_equal(out, G["sbs_out"])
+    planes = np.zeros((6, 48, 64), dtype=np.uint16)
+    for z in range(6):
+        for idx, m in enumerate(fake_segmenter.segment_image(volume[z], display=False)):
+            planes[z][m["segmentation"]] = idx + 1
+    assert np.array_equal(planes, G["sbs_planes"])  # filter + dedup + ascending-area order + overwrite order
+
+
+def test_sliding_windows_and_config_defaults(fake_segmenter):
+    for shp in [(1024, 1024), (600, 900), (300, 300)]:
+        assert np.array_equal(np.array(fake_segmenter.get_sliding_windows(shp)), G[f"windows_{shp[0]}x{shp[1]}"])
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    d = cfgAMG().dict()
+    assert sorted(d.keys()) == G["cfgamg_defaults_keys"].tolist()
+    assert [str(d[k]) for k in sorted(d.keys())] == G["cfgamg_defaults_vals"].tolist()
+    c = SAM2AdapterConfig()
+    assert [c.model_type, c.cfg, str(c.checkpoint), str(c.num_maskmem), str(c.light_modality), str(c.min_mask_area)] == G["adaptercfg_defaults"].tolist()
+    with pytest.raises(ValueError):
+        SAM2AdapterConfig(cfg="huge")
+    with pytest.raises(ValueError):
+        cfgAMG(sam2_cfg="huge")
+    with pytest.raises(ValueError):
+        cfgAMG(npoints=0)
+
+
+def test_oracle_model_reproduces_hf_validated_outputs():
+    """BASELINE config 1: 512x512 micrograph, Hiera-tiny, one centre point prompt, CPU."""
+    from oracle import sam2_ref
+    from oracle.make_golden_model import config1_image
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    M = np.load(os.path.join(os.path.dirname(__file__), "golden", "sam2_tiny_seed0.npz"))
+    assert M["hf_max_abs_diff"].max() < 5e-4  # the fixture was accepted only after agreeing with the HF restatement
+    cfg = get_config("tiny")
+    P = sam2_ref.ImagePredictorRef(seeded_weights(cfg, 0), cfg)
+    P.set_image(config1_image())
+    pts = P.transform_coords(torch.tensor([[256.0, 256.0]]), True, (512, 512))
+    lab = torch.ones(1, 1, dtype=torch.int64)
+    low, iou, obj, _, _ = P.predict_lowres(pts[:, None], lab, None, True)
+    masks, _, lowc = P._predict(pts[:, None], lab, None, True)
+    low2, iou2, _, _, _ = P.predict_lowres(pts[:, None], lab, lowc[:, :1], False)
+    tol = dict(rtol=0, atol=2e-4)
+    assert np.allclose(P.feats["image_embed"][0, ::8, ::4, ::4].numpy(), M["image_embed_sub"], **tol)
+    assert np.allclose(P.feats["feat_s0"][0, ::4, ::16, ::16].numpy(), M["feat_s0_sub"], **tol)
+    assert np.allclose(P.feats["feat_s1"][0, ::8, ::8, ::8].numpy(), M["feat_s1_sub"], **tol)
+    assert np.allclose(low[0, :, ::4, ::4].numpy(), M["low_res_sub"], rtol=0, atol=1e-3)
+    assert np.allclose(iou.numpy(), M["iou"], rtol=0, atol=1e-5) and np.allclose(obj.numpy(), M["obj"], rtol=0, atol=1e-4)
+    assert np.allclose(low2[0, :, ::4, ::4].numpy(), M["m2m_low_res_sub"], rtol=0, atol=1e-3)
+    assert masks.shape == (1, 3, 512, 512)
+    assert np.abs((masks[0] > 0).sum((-1, -2)).numpy() - M["mask_area"]).max() <= 2
