@@ -1,0 +1,403 @@
+// Fused image-side kernels of the two-way transformer.
+//
+// The cross attentions between the 8 prompt tokens and the 4096 image tokens are algebraically folded so
+// that the 4096x256 image-token matrix X of a prompt is streamed from HBM once per attention and never
+// projected to q/k/v in memory:
+//
+//  tokens -> image  (cross_attn_token_to_image, final_attn_token_to_image), head h, token t, c = 8h + t:
+//      score[c][n] = q_{t,h} . (W_k (x_n + pe_n) + b_k)_h = Qt[c] . (x_n + pe_n) + const(c)    Qt[c] = s W_k,h^T q_{t,h}
+//      (the constant is softmax-invariant over n and dropped);  out_{t,h} = W_v,h (sum_n p[c][n] x_n) + b_v,h
+//      => one "attention" with 64 query rows of dimension 256 over keys X+PE and values X      (dec_t2i_kernel)
+//  image -> tokens  (cross_attn_image_to_token) + residual + LayerNorm (norm4):
+//      score[n][c] = (x_n + pe_n) . Kt[c] + cb[c],  softmax over the 8 tokens of each head,
+//      y_n = sum_c p[n][c] Vt[c] + b_o,   Kt[c] = s W_q,h^T k_{t,h},  cb[c] = s b_q,h . k_{t,h},  Vt[c] = W_o[:,h] v_{t,h}
+//      x_n <- LN(x_n + y_n)                                                                      (dec_i2t_kernel)
+//
+// Same arithmetic as the unfolded form up to fp reassociation; 1.9 instead of 3.6 GFLOP per prompt and ~17 MB
+// instead of ~60 MB of HBM traffic per prompt.  MFMA layouts follow attention_hiera.hip (S^T = K.Q^T,
+// O^T = V^T.P^T, V^T fragments via ds_read_b64_tr_b16).
+#include "common.h"
+#include "kernels.h"
+
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+__device__ __forceinline__ bf16x4 tr_read_d(const char* p) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ bf16x8 cat4_d(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ bf16x8 pack8_d(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+    uint4 u = make_uint4(pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(b0, b1), pack_bf16(b2, b3));
+    return __builtin_bit_cast(bf16x8, u);
+}
+// 8 packed bf16 + 8 packed bf16 -> 8 packed bf16 (fp32 add, RNE)
+__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+    uint4 r;
+    uint32_t* pr = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(pa[i] << 16) + __uint_as_float(pb[i] << 16);
+        const float hi = __uint_as_float(pa[i] & 0xffff0000u) + __uint_as_float(pb[i] & 0xffff0000u);
+        pr[i] = pack_bf16(lo, hi);
+    }
+    return r;
+}
+
+#define DC 256           // channels of the decoder
+#define ROW_B 512        // bytes per 256-channel bf16 row
+#define VT_STRIDE 544    // padded LDS row stride for tr reads: 8 rows x 32 B hit disjoint banks
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * ROW_B + ((chunk ^ (row & 15)) << 4); }
+
+// ------------------------------------------------------------------------------------------------ fold
+// out[p][8h+t][d] = scale * sum_j a[p][t][16h+j] * W(16h+j, d);  W row-major [128][256] (mode 0: k_proj / q_proj
+// weight) or [256][128] indexed W[d][16h+j] (mode 1: out_proj weight).  cb[p][8h+t] = scale * sum_j a . bias[16h+j].
+__global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__ a, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                       int mode, float scale, bf16_t* __restrict__ out, float* __restrict__ cb) {
+    __shared__ float as[8 * 128];
+    const int p = blockIdx.x, d = threadIdx.x;
+    for (int i = d; i < 8 * 128; i += 256) as[i] = a[(int64_t)p * 1024 + i];
+    __syncthreads();
+    for (int h = 0; h < 8; ++h) {
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = mode == 0 ? bf2f(W[(16 * h + j) * 256 + d]) : bf2f(W[d * 128 + 16 * h + j]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += as[t * 128 + 16 * h + j] * w[j];
+            out[((int64_t)p * 64 + 8 * h + t) * 256 + d] = f2bf(acc * scale);
+        }
+    }
+    if (cb && d < 64) {
+        const int h = d >> 3, t = d & 7;
+        float acc = 0.f;
+        for (int j = 0; j < 16; ++j) acc += as[t * 128 + 16 * h + j] * bias[16 * h + j];
+        cb[(int64_t)p * 64 + d] = acc * scale;
+    }
+}
+
+const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, int mode, float scale, bf16_t* out, float* cb, int P,
+                            hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(dec_fold_kernel, dim3(P), dim3(256), 0, s, a, W, bias, mode, scale, out, cb);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ tokens -> image
+#define T2I_KB 64
+#define T2I_LDS (T2I_KB * ROW_B + T2I_KB * VT_STRIDE)
+
+// grid = P * split.  Each block: 64 folded query rows (4 waves x 16) over 4096/split keys of prompt p.
+// Writes un-normalised partial O [P][split][64][256] and (m, l) [P][split][64][2] (log2 domain).
+__global__ __launch_bounds__(256) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
+                                                      const bf16_t* __restrict__ Qt, float* __restrict__ Opart, float* __restrict__ ML,
+                                                      int split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ks_ = smem;
+    char* vs = smem + T2I_KB * ROW_B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.x / split, sp = blockIdx.x - p * split;
+    const int nkeys = 4096 / split, key0 = sp * nkeys, nkb = nkeys / T2I_KB;
+    const bf16_t* Xp = X + (int64_t)p * x_bs;
+
+    bf16x8 qf[8];
+    {
+        const bf16_t* qrow = Qt + ((int64_t)p * 64 + wave * 16 + fi) * DC;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
+    }
+    float m = -3.0e38f, l = 0.f;
+    f32x4 o[16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 rx[8], rp[8];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+            const int64_t off = (int64_t)(key0 + kb * T2I_KB + row) * DC + ch * 8;
+            rx[j] = *reinterpret_cast<const uint4*>(Xp + off);
+            rp[j] = *reinterpret_cast<const uint4*>(pe + off);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+            *reinterpret_cast<uint4*>(ks_ + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
+            *reinterpret_cast<uint4*>(vs + row * VT_STRIDE + ch * 16) = rx[j];
+        }
+    };
+
+    gload(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (kb + 1 < nkb) gload(kb + 1);
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = 16 * kt + fi;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + kswz(row, 4 * ks + fg));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(s[kt][r] - mn);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * alpha + sum;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+            pf[k2] = pack8_d(s[2 * k2][0], s[2 * k2][1], s[2 * k2][2], s[2 * k2][3], s[2 * k2 + 1][0], s[2 * k2 + 1][1], s[2 * k2 + 1][2],
+                             s[2 * k2 + 1][3]);
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const char* base = vs + (32 * k2 + 4 * fg + (fi >> 2)) * VT_STRIDE + (16 * dt + 4 * (fi & 3)) * 2;
+                const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * VT_STRIDE));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[k2], o[dt], 0, 0, 0);
+            }
+    }
+    const int q = wave * 16 + fi;
+    float* op = Opart + (((int64_t)p * split + sp) * 64 + q) * DC;
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) *reinterpret_cast<float4*>(op + 16 * dt + 4 * fg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    if (fg == 0) {
+        float* mlp = ML + (((int64_t)p * split + sp) * 64 + q) * 2;
+        mlp[0] = m;
+        mlp[1] = l;
+    }
+}
+
+// combine the split partials and apply v_proj per head: out[p][t][16h+i] = W_v[16h+i] . Z[p][8h+t] + b_v[16h+i]  (bf16)
+// one block per (prompt, head)
+__global__ __launch_bounds__(256) void dec_t2i_finish_kernel(const float* __restrict__ Opart, const float* __restrict__ ML, int split,
+                                                             const bf16_t* __restrict__ Wv, const float* __restrict__ bv,
+                                                             bf16_t* __restrict__ out) {
+    __shared__ float z[8][DC + 1];
+    __shared__ float wgt[8][8];
+    const int p = blockIdx.x >> 3, h = blockIdx.x & 7, tid = threadIdx.x;
+    if (tid < 8) {
+        const int c = 8 * h + tid;
+        float mm = -3.0e38f;
+        for (int s = 0; s < split; ++s) mm = fmaxf(mm, ML[(((int64_t)p * split + s) * 64 + c) * 2]);
+        float L = 0.f;
+        for (int s = 0; s < split; ++s) {
+            const float* mlp = ML + (((int64_t)p * split + s) * 64 + c) * 2;
+            const float w = exp2f(mlp[0] - mm);
+            wgt[tid][s] = w;
+            L += w * mlp[1];
+        }
+        const float inv = 1.0f / L;
+        for (int s = 0; s < split; ++s) wgt[tid][s] *= inv;
+    }
+    __syncthreads();
+    for (int t = 0; t < 8; ++t) {
+        float acc = 0.f;
+        for (int s = 0; s < split; ++s) acc += wgt[t][s] * Opart[(((int64_t)p * split + s) * 64 + 8 * h + t) * DC + tid];
+        z[t][tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) {  // (t, i): out feature 16h + i of token t
+        const int t = tid >> 4, oo = 16 * h + (tid & 15);
+        const bf16_t* w = Wv + oo * 256;
+        float acc = bv[oo];
+        for (int d = 0; d < DC; ++d) acc += bf2f(w[d]) * z[t][d];
+        out[(int64_t)p * 1024 + t * 128 + oo] = f2bf(acc);
+    }
+}
+
+const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
+                           const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
+    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(256), T2I_LDS, s, X, x_bs, pe, Qt, Opart, ML, split);
+    hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ image -> tokens
+#define I2T_ROWS 64
+#define I2T_TILES 8   // row tiles per block (512 rows), folded operands stay in LDS across them
+#define I2T_LDS (64 * ROW_B + 64 * VT_STRIDE + 2 * I2T_ROWS * ROW_B)
+
+// grid = P * (4096 / (I2T_ROWS * I2T_TILES)).  X_out[p][n] = LN(x_n + softmax_heads((x_n + pe_n).Kt + cb).Vt + b_o)
+__global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
+                                                      const bf16_t* __restrict__ Kt, const float* __restrict__ cb,
+                                                      const bf16_t* __restrict__ Vt, const float* __restrict__ bo,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      bf16_t* __restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kt_s = smem;                                  // [64 c][256] swizzled   (A operand of GEMM1)
+    char* vt_s = kt_s + 64 * ROW_B;                     // [64 c][256] stride 544 (tr-read source of GEMM2)
+    char* xp_s = vt_s + 64 * VT_STRIDE;                 // [64 rows][256] swizzled: bf16(x + pe)  (B operand of GEMM1)
+    char* x_s = xp_s + I2T_ROWS * ROW_B;                // [64 rows][256] linear: x (residual)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int blocks_per_p = 4096 / (I2T_ROWS * I2T_TILES);
+    const int p = blockIdx.x / blocks_per_p, seg = blockIdx.x - p * blocks_per_p;
+    const bf16_t* Xp = X + (int64_t)p * x_bs;
+    bf16_t* Xo = Xout + (int64_t)p * 4096 * DC;
+
+    // folded operands of this prompt
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+        *reinterpret_cast<uint4*>(kt_s + kswz(row, ch)) = *reinterpret_cast<const uint4*>(Kt + ((int64_t)p * 64 + row) * DC + ch * 8);
+        *reinterpret_cast<uint4*>(vt_s + row * VT_STRIDE + ch * 16) = *reinterpret_cast<const uint4*>(Vt + ((int64_t)p * 64 + row) * DC + ch * 8);
+    }
+    // per-lane constants: cb for c = 16ct + 4g + r ; bo/gamma/beta for d = 16dt + 4g + r are re-read per tile from L1
+    float cbv[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const float4 v = *reinterpret_cast<const float4*>(cb + (int64_t)p * 64 + 16 * ct + 4 * fg);
+        cbv[ct][0] = v.x; cbv[ct][1] = v.y; cbv[ct][2] = v.z; cbv[ct][3] = v.w;
+    }
+
+    uint4 rx[8], rp[8];
+    auto gload = [&](int t) {
+        const int row0 = (seg * I2T_TILES + t) * I2T_ROWS;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+            const int64_t off = (int64_t)(row0 + row) * DC + ch * 8;
+            rx[j] = *reinterpret_cast<const uint4*>(Xp + off);
+            rp[j] = *reinterpret_cast<const uint4*>(pe + off);
+        }
+    };
+    gload(0);
+    for (int t = 0; t < I2T_TILES; ++t) {
+        __syncthreads();  // previous tile consumed (first time: folded operands visible after the 2nd barrier)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+            *reinterpret_cast<uint4*>(xp_s + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
+            *reinterpret_cast<uint4*>(x_s + row * ROW_B + ch * 16) = rx[j];
+        }
+        __syncthreads();
+        if (t + 1 < I2T_TILES) gload(t + 1);
+        const int mrow = wave * 16 + fi;  // row of this lane within the tile
+
+        // GEMM1 (swapped): S^T[c][m] = Kt[c] . xpos[m]
+        f32x4 s[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) s[ct] = (f32x4){cbv[ct][0], cbv[ct][1], cbv[ct][2], cbv[ct][3]};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp_s + kswz(mrow, 4 * ks + fg));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt_s + kswz(16 * ct + fi, 4 * ks + fg));
+                s[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, xf, s[ct], 0, 0, 0);
+            }
+        }
+        // softmax over the 8 tokens of a head: c = 16ct + 4g + r -> head = 2ct + (g >> 1); members: r = 0..3 and lane ^ 16
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float mx = fmaxf(fmaxf(s[ct][0], s[ct][1]), fmaxf(s[ct][2], s[ct][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[ct][r] = exp2f(s[ct][r] - mx); sum += s[ct][r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[ct][r] *= inv;
+        }
+        bf16x8 pf[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+            pf[k2] = pack8_d(s[2 * k2][0], s[2 * k2][1], s[2 * k2][2], s[2 * k2][3], s[2 * k2 + 1][0], s[2 * k2 + 1][1], s[2 * k2 + 1][2],
+                             s[2 * k2 + 1][3]);
+        // GEMM2: Y^T[d][m] = Vt^T[d][c] . P^T[c][m]
+        f32x4 y[16];
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            y[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const char* base = vt_s + (32 * k2 + 4 * fg + (fi >> 2)) * VT_STRIDE + (16 * dt + 4 * (fi & 3)) * 2;
+                const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * VT_STRIDE));
+                y[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[k2], y[dt], 0, 0, 0);
+            }
+        }
+        // residual + LayerNorm over the 256 channels of row m (lane holds d = 16dt + 4g + r; partners: lane ^ 16, ^ 32)
+        float sum = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            const uint2 xr = *reinterpret_cast<const uint2*>(x_s + mrow * ROW_B + (16 * dt + 4 * fg) * 2);
+            const float4 b4 = *reinterpret_cast<const float4*>(bo + 16 * dt + 4 * fg);
+            y[dt][0] += __uint_as_float(xr.x << 16) + b4.x;
+            y[dt][1] += __uint_as_float(xr.x & 0xffff0000u) + b4.y;
+            y[dt][2] += __uint_as_float(xr.y << 16) + b4.z;
+            y[dt][3] += __uint_as_float(xr.y & 0xffff0000u) + b4.w;
+            sum += (y[dt][0] + y[dt][1]) + (y[dt][2] + y[dt][3]);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / DC);
+        float var = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float dlt = y[dt][r] - mean; var += dlt * dlt; }
+        var += __shfl_xor(var, 16, 64);
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = 1.0f / sqrtf(var * (1.0f / DC) + eps);
+        bf16_t* orow = Xo + (int64_t)((seg * I2T_TILES + t) * I2T_ROWS + mrow) * DC;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + 16 * dt + 4 * fg);
+            const float4 e4 = *reinterpret_cast<const float4*>(beta + 16 * dt + 4 * fg);
+            const float v0 = (y[dt][0] - mean) * rstd * g4.x + e4.x, v1 = (y[dt][1] - mean) * rstd * g4.y + e4.y;
+            const float v2 = (y[dt][2] - mean) * rstd * g4.z + e4.z, v3 = (y[dt][3] - mean) * rstd * g4.w + e4.w;
+            *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * fg) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+        }
+    }
+}
+
+const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt,
+                           const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * (4096 / (I2T_ROWS * I2T_TILES))), dim3(256), I2T_LDS, s, X, x_bs, pe, Kt, cb, Vt, bo, gamma,
+                       beta, eps, Xout);
+    return nullptr;
+}
+
+const char* decoder_fused_init_device() {
+    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2I_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I2T_LDS);
+    return st == hipSuccess ? nullptr : hipGetErrorString(st);
+}

@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
     const float4 pe = *reinterpret_cast<const float4*>(pos + (int64_t)tok * DEC_C + lane * 4);
     o[0] += ie.x; o[1] += ie.y; o[2] += ie.z; o[3] += ie.w;
     const int64_t off = gw * DEC_C + lane * 4;
-    *reinterpret_cast<float4*>(src_f + off) = make_float4(o[0], o[1], o[2], o[3]);
+    if (src_f) *reinterpret_cast<float4*>(src_f + off) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<uint2*>(src_bf + off) = make_uint2(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]));
-    *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_bf16(o[0] + pe.x, o[1] + pe.y), pack_bf16(o[2] + pe.z, o[3] + pe.w));
+    if (srcpos_bf) *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_bf16(o[0] + pe.x, o[1] + pe.y), pack_bf16(o[2] + pe.z, o[3] + pe.w));
 }
 
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, const float* pos, MaskEmbedWeights w,

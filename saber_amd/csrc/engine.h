@@ -20,7 +20,7 @@ struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
 struct AttnW { LinW q, k, v, o; };
 struct DecLayerW { AttnW self_attn, t2i, i2t; LnW n1, n2, n3, n4; LinW mlp1, mlp2; };
 
-enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_N };
+enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_DEC_T2I, PC_DEC_I2T, PC_N };
 struct ProfRec { int cls; double flops; double bytes; hipEvent_t a, b; };
 
 struct saber_engine {
@@ -49,6 +49,7 @@ struct saber_engine {
     MaskEmbedWeights mw{};
     const float* no_mask_embed = nullptr;
     const float* dense_pe = nullptr;  // [4096][256], engine token order
+    const bf16_t* dense_pe_bf = nullptr;
     DecLayerW dl[2];
     AttnW final_attn; LnW final_ln;
     LinW dc1, dc2; LnW up_ln;
@@ -63,15 +64,15 @@ struct saber_engine {
     // resident features per slot
     float *emb = nullptr, *fs1 = nullptr, *fs0 = nullptr;
     // per-slot first-pass shared tensors (src0 = image_embed + no_mask_embed)
-    float* src0_f = nullptr; bf16_t *src0_bf = nullptr, *src0pos_bf = nullptr;
-    float *k0 = nullptr, *v0 = nullptr, *qi0 = nullptr;
+    bf16_t* src0_bf = nullptr;
     std::vector<char> slot_valid, slot_shared_valid;
 
     // decoder workspace (per chunk of max_prompts prompts)
     float *tok_pe = nullptr, *queries = nullptr, *tq = nullptr, *tk = nullptr, *tv = nullptr;
     bf16_t *t_bf0 = nullptr, *t_bf1 = nullptr, *t_att = nullptr, *t_hid = nullptr;
-    float *keys = nullptr, *kp = nullptr, *vp = nullptr, *qp = nullptr;
-    bf16_t *keys_bf = nullptr, *keyspos_bf = nullptr, *iatt_bf = nullptr;
+    bf16_t* keys_bf = nullptr;                                   // image tokens of each prompt [P][4096][256]
+    bf16_t *fold_q = nullptr, *fold_k = nullptr, *fold_v = nullptr;  // folded operands [P][64][256]
+    float *fold_cb = nullptr, *t2i_part = nullptr, *t2i_ml = nullptr;
     float* u1 = nullptr; bf16_t *u1b = nullptr, *up2 = nullptr;
     float *masks4 = nullptr, *hyper_out = nullptr, *iou4 = nullptr, *head_tmp = nullptr;
     bf16_t *head_bf0 = nullptr, *head_bf1 = nullptr;

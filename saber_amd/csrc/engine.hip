@@ -92,6 +92,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
         const char* m = gemm_init_device();
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();
+        if (!m) m = decoder_fused_init_device();
         (void)hipGetLastError();
         if (m) { delete e; return eng_fail(nullptr, SABER_ERR_HIP, std::string("kernel attribute setup: ") + m); }
     }
@@ -342,6 +343,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
                 }
             }
         e->dense_pe = F.up_f32(dpe);
+        e->dense_pe_bf = F.up_bf16(dpe);
         const std::string m = p + "mask_downscaling.";
         const HostTensor *w1 = F.get(m + "0.weight", {4, 1, 2, 2}), *b1 = F.get(m + "0.bias", {4});
         const HostTensor *g1 = F.get(m + "1.weight", {4}), *be1 = F.get(m + "1.bias", {4});
@@ -425,12 +427,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->emb, B * 4096 * 256));
     TRY(eng_alloc(e, &e->fs1, B * 16384 * 64));
     TRY(eng_alloc(e, &e->fs0, B * 65536 * 32));
-    TRY(eng_alloc(e, &e->src0_f, B * 4096 * 256));
     TRY(eng_alloc(e, &e->src0_bf, B * 4096 * 256));
-    TRY(eng_alloc(e, &e->src0pos_bf, B * 4096 * 256));
-    TRY(eng_alloc(e, &e->k0, B * 4096 * 128));
-    TRY(eng_alloc(e, &e->v0, B * 4096 * 128));
-    TRY(eng_alloc(e, &e->qi0, B * 4096 * 128));
     e->slot_valid.assign(B, 0);
     e->slot_shared_valid.assign(B, 0);
 
@@ -443,13 +440,13 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->t_bf1, P * 8 * 256));
     TRY(eng_alloc(e, &e->t_att, P * 8 * 256));
     TRY(eng_alloc(e, &e->t_hid, P * 8 * 2048));
-    TRY(eng_alloc(e, &e->keys, P * 4096 * 256));
     TRY(eng_alloc(e, &e->keys_bf, P * 4096 * 256));
-    TRY(eng_alloc(e, &e->keyspos_bf, P * 4096 * 256));
-    TRY(eng_alloc(e, &e->kp, P * 4096 * 128));
-    TRY(eng_alloc(e, &e->vp, P * 4096 * 128));
-    TRY(eng_alloc(e, &e->qp, P * 4096 * 128));
-    TRY(eng_alloc(e, &e->iatt_bf, P * 4096 * 128));
+    TRY(eng_alloc(e, &e->fold_q, P * 64 * 256));
+    TRY(eng_alloc(e, &e->fold_k, P * 64 * 256));
+    TRY(eng_alloc(e, &e->fold_v, P * 64 * 256));
+    TRY(eng_alloc(e, &e->fold_cb, P * 64));
+    TRY(eng_alloc(e, &e->t2i_part, P * 8 * 64 * 256));
+    TRY(eng_alloc(e, &e->t2i_ml, P * 8 * 64 * 2));
     TRY(eng_alloc(e, &e->u1, P * 4096 * 256));
     TRY(eng_alloc(e, &e->u1b, P * 4096 * 256));
     TRY(eng_alloc(e, &e->up2, P * 16384 * 128));
@@ -639,18 +636,9 @@ extern "C" int saber_get_features(saber_engine* e, int slot, float* image_embed,
 // ------------------------------------------------------------------------------------------------ decoder
 static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
     if (e->slot_shared_valid[slot]) return SABER_OK;
-    const size_t o256 = (size_t)slot * 4096 * 256, o128 = (size_t)slot * 4096 * 128;
-    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->emb + o256, e->no_mask_embed, 1, e->src0_bf + o256, e->src0_f + o256, 4096, 256, s));
-    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->src0_f + o256, e->dense_pe, 4096, e->src0pos_bf + o256, nullptr, 4096, 256, s));
-    GemmParams g = mk_gemm(e->src0pos_bf + o256, 256, 4096, e->dl[0].t2i.k);
-    g.Cf = e->k0 + o128; g.ldcf = 128;
-    ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-    g = mk_gemm(e->src0_bf + o256, 256, 4096, e->dl[0].t2i.v);
-    g.Cf = e->v0 + o128; g.ldcf = 128;
-    ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-    g = mk_gemm(e->src0pos_bf + o256, 256, 4096, e->dl[0].i2t.q);
-    g.Cf = e->qi0 + o128; g.ldcf = 128;
-    ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+    const size_t o256 = (size_t)slot * 4096 * 256;
+    // src0 = image_embed + no_mask_embed (identical for every first-pass prompt of this crop)
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->emb + o256, e->no_mask_embed, 1, e->src0_bf + o256, nullptr, 4096, 256, s));
     e->slot_shared_valid[slot] = 1;
     return SABER_OK;
 }
@@ -659,34 +647,32 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
                         float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
     const int T = 8;
     const int PT = P * T;
-    const size_t o256 = (size_t)slot * 4096 * 256, o128 = (size_t)slot * 4096 * 128;
+    const size_t o256 = (size_t)slot * 4096 * 256;
     const bool shared = (mask_in == nullptr);
+    const float kScale = 0.25f * 1.4426950408889634f;  // head_dim 16 ^ -0.5 * log2(e): scores live in the exp2 domain
+    int split = 1;
+    while (split < 8 && P * split < 512) split *= 2;
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
     ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
-    if (shared) TRY(ensure_shared(e, slot, s));
-    else ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_embed_src(mask_in, P, e->emb + o256, e->dense_pe, e->mw, e->keys, e->keys_bf, e->keyspos_bf, s));
+    const bf16_t* X;      // image tokens of each prompt, bf16 [4096][256], engine order
+    int64_t x_bs;
+    if (shared) { TRY(ensure_shared(e, slot, s)); X = e->src0_bf + o256; x_bs = 0; }
+    else {
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, s));
+        X = e->keys_bf; x_bs = (int64_t)4096 * 256;
+    }
 
-    auto t2i = [&](const AttnW& a, const LnW& ln, bool use_shared) -> int {
+    // tokens -> image: fold q into 64 rows of dimension 256, stream X once (dec_t2i), un-fold with v_proj
+    auto t2i = [&](const AttnW& a, const LnW& ln) -> int {
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         GemmParams g = mk_gemm(e->t_bf0, 256, PT, a.q);
         g.Cf = e->tq; g.ldcf = 128;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        const float *K, *V;
-        int64_t kbs;
-        if (use_shared) { K = e->k0 + o128; V = e->v0 + o128; kbs = 0; }
-        else {
-            g = mk_gemm(e->keyspos_bf, 256, P * 4096, a.k);
-            g.Cf = e->kp; g.ldcf = 128;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-            g = mk_gemm(e->keys_bf, 256, P * 4096, a.v);
-            g.Cf = e->vp; g.ldcf = 128;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-            K = e->kp; V = e->vp; kbs = (int64_t)4096 * 128;
-        }
-        ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(e->tq, K, V, e->t_att, P, T, 4096, 8, 16, T * 128, kbs, kbs, T * 128, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tq, a.k.w, nullptr, 0, kScale, e->fold_q, nullptr, P, s));
+        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, x_bs, e->dense_pe_bf, e->fold_q, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
         g = mk_gemm(e->t_att, 128, PT, a.o);
         g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, ln, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         return SABER_OK;
     };
@@ -697,50 +683,40 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, l == 0 ? nullptr : e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         const bf16_t* vin = e->t_bf0;
         if (l > 0) { ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s)); vin = e->t_bf1; }
-        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(e->tq, e->tk, e->tv, e->t_att, P, T, T, 8, 32, T * 256, T * 256, T * 256, T * 256, s));
         g = mk_gemm(e->t_att, 256, PT, w.self_attn.o);
         g.Cf = e->queries; g.ldcf = 256;
         if (l > 0) { g.res = e->queries; g.ldres = 256; }
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, w.n1, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         // (2) tokens -> image
-        TRY(t2i(w.t2i, w.n2, shared && l == 0));
+        TRY(t2i(w.t2i, w.n2));
         // (3) MLP
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, w.n3, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
-        // (4) image -> tokens
+        // (4) image -> tokens, fused with the residual and norm4: X <- LN(X + attn)
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        const float* Q;
-        int64_t qbs;
-        if (shared && l == 0) { Q = e->qi0 + o128; qbs = 0; }
-        else {
-            g = mk_gemm(e->keyspos_bf, 256, P * 4096, w.i2t.q); g.Cf = e->qp; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-            Q = e->qp; qbs = (int64_t)4096 * 128;
-        }
-        ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(Q, e->tk, e->tv, e->iatt_bf, P, 4096, T, 8, 16, qbs, T * 128, T * 128, (int64_t)4096 * 128, s));
-        g = mk_gemm(e->iatt_bf, 128, P * 4096, w.i2t.o);
-        g.Cf = e->keys; g.ldcf = 256; g.ldres = 256;
-        if (shared && l == 0) { g.res = e->src0_f + o256; g.res_mod = 4096; }
-        else g.res = e->keys;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->keys, w.n4, 1e-5f, P * 4096, 256, e->keys, e->keys_bf, ACT_NONE, s, e->keyspos_bf, e->dense_pe, 4096));
+        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tk, w.i2t.q.w, w.i2t.q.b, 0, kScale, e->fold_k, e->fold_cb, P, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tv, w.i2t.o.w, nullptr, 1, 1.0f, e->fold_v, nullptr, P, s));
+        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, x_bs, e->dense_pe_bf, e->fold_k, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
+        X = e->keys_bf; x_bs = (int64_t)4096 * 256;
     }
-    TRY(t2i(e->final_attn, e->final_ln, false));
+    TRY(t2i(e->final_attn, e->final_ln));
 
     // heads
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
     auto mlp3 = [&](const LinW* L, const bf16_t* A, int last_act, float* outf, int ldo) -> int {
-        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         return SABER_OK;
     };
     TRY(mlp3(e->iou_head, e->t_bf0 + 1 * 256, ACT_SIGMOID, e->iou4, 4));
@@ -749,26 +725,26 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
         GemmParams g = mk_gemm(e->t_bf0 + 2 * 256, T * 256, P, e->hyper[0]);
         g.batch = 4; g.strideA = 256; g.strideW = 256 * 256; g.strideBias = 256;
         g.Cb = e->head_bf0; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
         g = mk_gemm(e->head_bf0, 256, P, e->hyper[1]);
         g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 256 * 256; g.strideBias = 256;
         g.Cb = e->head_bf1; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
         g = mk_gemm(e->head_bf1, 256, P, e->hyper[2]);
         g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 32 * 256; g.strideBias = 32;
         g.Cf = e->hyper_out; g.ldcf = 128; g.strideCf = 32;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
     }
     // upscaling: dc1 + feat_s1 -> LN2d -> GELU -> dc2 + feat_s0 -> GELU
     {
-        GemmParams g = mk_gemm(e->keys_bf, 256, P * 4096, e->dc1);
+        GemmParams g = mk_gemm(X, 256, P * 4096, e->dc1);
         g.Cf = e->u1; g.ldcf = 256; g.res = e->fs1 + (size_t)slot * 16384 * 64; g.ldres = 256; g.res_mod = 4096;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->u1, e->up_ln, 1e-6f, P * 16384, 64, nullptr, e->u1b, ACT_GELU, s));
         g = mk_gemm(e->u1b, 64, P * 16384, e->dc2);
         g.Cb = e->up2; g.ldcb = 128; g.res = e->fs0 + (size_t)slot * 65536 * 32; g.ldres = 128; g.res_mod = 16384;
         g.act = ACT_GELU; g.act_last = 1;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
     }
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_dot(e->up2, e->hyper_out, P, e->masks4, s));
     float* om = out_lowres ? out_lowres : e->dec_out_masks;

@@ -83,6 +83,14 @@ const char* launch_mask_dot(const bf16_t* up, const float* hyper, int P, float* 
 const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,
                                int* counts_ws, hipStream_t s);
 
+// ------------------------------------------------------------------ decoder_fused.hip
+const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, int mode, float scale, bf16_t* out, float* cb, int P, hipStream_t s);
+const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
+                           const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
+const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt, const float* bo,
+                           const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s);
+const char* decoder_fused_init_device();
+
 // K8: bilinear upsample of 256x256 logits to the crop, threshold / stability counts / bbox / bit-packing.
 struct MaskStats { int area; int inter; int uni; int x0; int y0; int x1; int y1; int pad; };
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
