@@ -396,8 +396,212 @@ const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
     return nullptr;
 }
 
+
+// ------------------------------------------------------------------------------------------------ upscaling head
+// Fused output_upscaling + hypernetwork product:
+//   u1 = GELU(LN64(ConvT1(x) + feat_s1));  u2 = GELU(ConvT2(u1) + feat_s0);  masks[k] = hyper[k] . u2
+// One block = 64 consecutive tokens (a 4x16 token patch = 16x64 output pixels) of one prompt.
+// Phase A: [64 tok] x [256 = pos*64+ch] GEMM over K=256; wave w owns pos = w, so its LayerNorm groups are
+// wave-local and its GELU outputs feed phase B straight from registers (k-slot permutation, W2 pre-permuted).
+// Phase B: [(pos w, 64 tok)] x [128 = pos2*32+ch2] GEMM over K=64, epilogue = +feat_s0, GELU, 4 dot products.
+// The 32-channel 256x256 upscaled embedding (8 MB fp32 per prompt) never exists in memory.
+#define UP_XS (64 * ROW_B)            // X tile   [64][256] bf16, kswz
+#define UP_W1S (256 * 128)            // W1 slice [256 n][64 k] bf16, 128-B rows swizzled
+#define UP_W2S (128 * 128)            // W2p      [128 n2][64] bf16 (k-slots pre-permuted)
+#define UP_OUT (4 * 16 * 64 * 4)      // output tile [4 masks][16 rows][64 cols] fp32
+#define UP_LDS (UP_XS + UP_W1S + UP_W2S)   // the output tile aliases the X tile (dead after phase A)
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                          const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
+                                                          const float* __restrict__ fs1, const float* __restrict__ fs0,
+                                                          const float* __restrict__ hyper, float* __restrict__ masks4) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    char* w1s = xs + UP_XS;
+    char* w2s = w1s + UP_W1S;
+    float* outs = reinterpret_cast<float*>(xs);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.x >> 6, tile = blockIdx.x & 63;
+    const bf16_t* Xt = X + ((int64_t)p * 4096 + tile * 64) * DC;
+
+    // stage X tile and W2p once
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+        *reinterpret_cast<uint4*>(xs + kswz(row, ch)) = *reinterpret_cast<const uint4*>(Xt + (int64_t)row * DC + ch * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
+        *reinterpret_cast<uint4*>(w2s + swz128(row, ch)) = *reinterpret_cast<const uint4*>(W2p + row * 64 + ch * 8);
+    }
+    // ---------------- phase A
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 rw[8];
+    auto wload = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
+            rw[j] = *reinterpret_cast<const uint4*>(W1 + row * 256 + kt * 64 + ch * 8);
+        }
+    };
+    wload(0);
+    for (int kt = 0; kt < 4; ++kt) {
+        __syncthreads();  // previous slice consumed (first: nothing pending)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
+            *reinterpret_cast<uint4*>(w1s + swz128(row, ch)) = rw[j];
+        }
+        __syncthreads();
+        if (kt + 1 < 4) wload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(w1s + swz128(wave * 64 + i * 16 + fi, ks * 4 + fg));
+                xf[i] = *reinterpret_cast<const bf16x8*>(xs + kswz(i * 16 + fi, kt * 8 + ks * 4 + fg));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    // epilogue A: + bias + feat_s1, LayerNorm over the 64 channels of (tok, pos = wave), GELU, pack as phase-B operand
+    bf16x8 uf[4][2];
+    {
+        float4 bb[4], gg[4], be[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            bb[ni] = *reinterpret_cast<const float4*>(b1 + wave * 64 + ni * 16 + 4 * fg);
+            gg[ni] = *reinterpret_cast<const float4*>(ln_g + ni * 16 + 4 * fg);
+            be[ni] = *reinterpret_cast<const float4*>(ln_b + ni * 16 + 4 * fg);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int tok = tile * 64 + mi * 16 + fi;
+            const float* f1 = fs1 + ((int64_t)tok * 4 + wave) * 64;
+            float v[4][4], sum = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float4 r4 = *reinterpret_cast<const float4*>(f1 + ni * 16 + 4 * fg);
+                v[ni][0] = acc[mi][ni][0] + bb[ni].x + r4.x; v[ni][1] = acc[mi][ni][1] + bb[ni].y + r4.y;
+                v[ni][2] = acc[mi][ni][2] + bb[ni].z + r4.z; v[ni][3] = acc[mi][ni][3] + bb[ni].w + r4.w;
+                sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / 64.0f);
+            float var = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
+            var += __shfl_xor(var, 16, 64);
+            var += __shfl_xor(var, 32, 64);
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 64.0f) + 1e-6f);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                v[ni][0] = gelu_erf((v[ni][0] - mean) * rstd * gg[ni].x + be[ni].x);
+                v[ni][1] = gelu_erf((v[ni][1] - mean) * rstd * gg[ni].y + be[ni].y);
+                v[ni][2] = gelu_erf((v[ni][2] - mean) * rstd * gg[ni].z + be[ni].z);
+                v[ni][3] = gelu_erf((v[ni][3] - mean) * rstd * gg[ni].w + be[ni].w);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                uf[mi][ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
+                                     v[2 * ks + 1][3]);
+        }
+    }
+    __syncthreads();  // every wave is done reading the X tile: its LDS now holds the output tile
+    // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
+    const float* hp = hyper + (int64_t)p * 128;
+    float4 hy[2][4];  // [ch2 half][k]
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hp + k * 32 + hh * 16 + 4 * fg);
+    const int dy1 = wave >> 1, dx1 = wave & 1;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        f32x4 c2[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nl = 0; nl < 4; ++nl) c2[mi][nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 w2f[4];
+#pragma unroll
+            for (int nl = 0; nl < 4; ++nl) w2f[nl] = *reinterpret_cast<const bf16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nl = 0; nl < 4; ++nl) c2[mi][nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[nl], uf[mi][ks], c2[mi][nl], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int tl = mi * 16 + fi;               // token within the tile
+            const int tok = tile * 64 + tl;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
+                const int pos2 = 2 * hb + pp;
+                const float* f0 = fs0 + (((int64_t)tok * 4 + wave) * 4 + pos2) * 32;
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int nl = 2 * pp + hh;
+                    const float4 bb = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
+                    const float4 r4 = *reinterpret_cast<const float4*>(f0 + hh * 16 + 4 * fg);
+                    const float u0 = gelu_erf(c2[mi][nl][0] + bb.x + r4.x), u1 = gelu_erf(c2[mi][nl][1] + bb.y + r4.y);
+                    const float u2 = gelu_erf(c2[mi][nl][2] + bb.z + r4.z), u3 = gelu_erf(c2[mi][nl][3] + bb.w + r4.w);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) part[k] += (u0 * hy[hh][k].x + u1 * hy[hh][k].y) + (u2 * hy[hh][k].z + u3 * hy[hh][k].w);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    part[k] += __shfl_xor(part[k], 16, 64);
+                    part[k] += __shfl_xor(part[k], 32, 64);
+                }
+                // local pixel: token (ty, tx) inside the 4x16 patch, sub-pixel from (pos, pos2)
+                const int ty = ((tl >> 5) & 1) * 2 + ((tl >> 1) & 1), tx = ((tl >> 2) & 7) * 2 + (tl & 1);
+                const int py = ty * 4 + dy1 * 2 + (pos2 >> 1), px = tx * 4 + dx1 * 2 + (pos2 & 1);
+                const float mine = fg == 0 ? part[0] : fg == 1 ? part[1] : fg == 2 ? part[2] : part[3];
+                outs[(fg * 16 + py) * 64 + px] = mine;
+            }
+        }
+    }
+    __syncthreads();
+    int ty0, tx0;
+    perm_coords(tile * 64, 2, &ty0, &tx0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;            // 1024 float4: [k][row][col/4]
+        const int k = idx >> 8, row = (idx >> 4) & 15, c4 = idx & 15;
+        const float4 v = *reinterpret_cast<const float4*>(outs + (k * 16 + row) * 64 + c4 * 4);
+        *reinterpret_cast<float4*>(masks4 + (((int64_t)p * 4 + k) * 256 + (ty0 * 4 + row)) * 256 + tx0 * 4 + c4 * 4) = v;
+    }
+}
+
+const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
+                               const float* b2, const float* fs1, const float* fs0, const float* hyper, float* masks4, int P, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(P * 64), dim3(256), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, hyper, masks4);
+    return nullptr;
+}
+
 const char* decoder_fused_init_device() {
     hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2I_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I2T_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }

@@ -39,93 +39,94 @@ const char* launch_prompt_tokens(const float* pts, const int* labels, int P, Pro
 
 // ------------------------------------------------------------------------------------------------
 // mask_downscaling (conv k2s2 1->4, LN2d, GELU, conv k2s2 4->16, LN2d, GELU, conv 1x1 16->256) fused
-// with "src = image_embed + dense".  One wave per token; lane owns 4 output channels.
+// with "src = image_embed + dense".  One block = 64 consecutive tokens of one prompt: phase 1, one thread per
+// token computes the 16-channel hidden vector from its 4x4 logit patch; phase 2, thread d produces channel d
+// of every token (coalesced 512-B rows).
 __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
                                                              const float* __restrict__ image_embed, const float* __restrict__ pos,
                                                              MaskEmbedWeights w, float* __restrict__ src_f,
                                                              bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf) {
-    const int lane = threadIdx.x & 63;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= (int64_t)P * 4096) return;
-    const int p = (int)(gw >> 12), tok = (int)(gw & 4095);
-    int ty, tx;
-    perm_coords(tok, 2, &ty, &tx);
-    const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4) * 256 + tx * 4;
-    float in[4][4];
+    __shared__ float h2s[64][17];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x >> 6, tok0 = (blockIdx.x & 63) * 64;
+    if (tid < 64) {
+        const int tok = tok0 + tid;
+        int ty, tx;
+        perm_coords(tok, 2, &ty, &tx);
+        const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4) * 256 + tx * 4;
+        float in[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float4 v = *reinterpret_cast<const float4*>(mp + r * 256);
-        in[r][0] = v.x; in[r][1] = v.y; in[r][2] = v.z; in[r][3] = v.w;
-    }
-    // stage 1: for each of the 2x2 positions, 4 channels
-    float h1[2][2][4];
+        for (int r = 0; r < 4; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(mp + r * 256);
+            in[r][0] = v.x; in[r][1] = v.y; in[r][2] = v.z; in[r][3] = v.w;
+        }
+        float h1[2][2][4];
 #pragma unroll
-    for (int py = 0; py < 2; ++py)
+        for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int px = 0; px < 2; ++px) {
-            float v[4], mu = 0.f;
+            for (int px = 0; px < 2; ++px) {
+                float v[4], mu = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float a = w.b1[c];
+                for (int c = 0; c < 4; ++c) {
+                    float a = w.b1[c];
+#pragma unroll
+                    for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 2; ++kx) a += w.w1[c * 4 + ky * 2 + kx] * in[py * 2 + ky][px * 2 + kx];
+                    v[c] = a;
+                    mu += a;
+                }
+                mu *= 0.25f;
+                float var = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) var += (v[c] - mu) * (v[c] - mu);
+                const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h1[py][px][c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
+            }
+        float h2[16], mu = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float a = w.b2[c];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
                 for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 2; ++kx) a += w.w1[c * 4 + ky * 2 + kx] * in[py * 2 + ky][px * 2 + kx];
-                v[c] = a;
-                mu += a;
-            }
-            mu *= 0.25f;
-            float var = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) var += (v[c] - mu) * (v[c] - mu);
-            const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) h1[py][px][c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
+                    for (int kx = 0; kx < 2; ++kx) a += w.w2[((c * 4 + ci) * 2 + ky) * 2 + kx] * h1[ky][kx][ci];
+            h2[c] = a;
+            mu += a;
         }
-    // stage 2: 16 channels from (4 ch x 2 x 2)
-    float h2[16], mu = 0.f;
+        mu *= (1.0f / 16.0f);
+        float var = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float a = w.b2[c];
+        for (int c = 0; c < 16; ++c) var += (h2[c] - mu) * (h2[c] - mu);
+        const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-            for (int ky = 0; ky < 2; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 2; ++kx) a += w.w2[((c * 4 + ci) * 2 + ky) * 2 + kx] * h1[ky][kx][ci];
-        h2[c] = a;
-        mu += a;
+        for (int c = 0; c < 16; ++c) h2s[tid][c] = gelu_erf((h2[c] - mu) * rstd * w.g2[c] + w.be2[c]);
     }
-    mu *= (1.0f / 16.0f);
-    float var = 0.f;
+    __syncthreads();
+    float w3[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) var += (h2[c] - mu) * (h2[c] - mu);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
+    for (int k = 0; k < 16; ++k) w3[k] = w.w3[tid * 16 + k];
+    const float b3 = w.b3[tid];
+    for (int t = 0; t < 64; ++t) {
+        const int tok = tok0 + t;
+        float a = b3;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) h2[c] = gelu_erf((h2[c] - mu) * rstd * w.g2[c] + w.be2[c]);
-    // stage 3: lane's 4 output channels
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = lane * 4 + j;
-        float a = w.b3[c];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a += w.w3[c * 16 + k] * h2[k];
-        o[j] = a;
+        for (int k = 0; k < 16; ++k) a += w3[k] * h2s[t][k];
+        a += image_embed[(int64_t)tok * DEC_C + tid];
+        const int64_t off = ((int64_t)p * 4096 + tok) * DEC_C + tid;
+        if (src_f) src_f[off] = a;
+        src_bf[off] = f2bf(a);
+        if (srcpos_bf) srcpos_bf[off] = f2bf(a + pos[(int64_t)tok * DEC_C + tid]);
     }
-    const float4 ie = *reinterpret_cast<const float4*>(image_embed + (int64_t)tok * DEC_C + lane * 4);
-    const float4 pe = *reinterpret_cast<const float4*>(pos + (int64_t)tok * DEC_C + lane * 4);
-    o[0] += ie.x; o[1] += ie.y; o[2] += ie.z; o[3] += ie.w;
-    const int64_t off = gw * DEC_C + lane * 4;
-    if (src_f) *reinterpret_cast<float4*>(src_f + off) = make_float4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<uint2*>(src_bf + off) = make_uint2(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]));
-    if (srcpos_bf) *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_bf16(o[0] + pe.x, o[1] + pe.y), pack_bf16(o[2] + pe.z, o[3] + pe.w));
 }
 
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, const float* pos, MaskEmbedWeights w,
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s) {
     if (P <= 0) return nullptr;
-    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(P * 1024), dim3(256), 0, s, mask_in, P, image_embed, pos, w, src_f, src_bf, srcpos_bf);
+    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(P * 64), dim3(256), 0, s, mask_in, P, image_embed, pos, w, src_f, src_bf, srcpos_bf);
     return nullptr;
 }
 

@@ -20,7 +20,7 @@ struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
 struct AttnW { LinW q, k, v, o; };
 struct DecLayerW { AttnW self_attn, t2i, i2t; LnW n1, n2, n3, n4; LinW mlp1, mlp2; };
 
-enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_DEC_T2I, PC_DEC_I2T, PC_N };
+enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_DEC_T2I, PC_DEC_I2T, PC_DEC_UPSCALE, PC_N };
 struct ProfRec { int cls; double flops; double bytes; hipEvent_t a, b; };
 
 struct saber_engine {
@@ -52,7 +52,7 @@ struct saber_engine {
     const bf16_t* dense_pe_bf = nullptr;
     DecLayerW dl[2];
     AttnW final_attn; LnW final_ln;
-    LinW dc1, dc2; LnW up_ln;
+    LinW dc1, dc2; LnW up_ln; const bf16_t* dc2p = nullptr;
     LinW hyper[3];  // stacked over the 4 mask tokens (batched GEMM)
     LinW iou_head[3], obj_head[3];
 
@@ -73,7 +73,6 @@ struct saber_engine {
     bf16_t* keys_bf = nullptr;                                   // image tokens of each prompt [P][4096][256]
     bf16_t *fold_q = nullptr, *fold_k = nullptr, *fold_v = nullptr;  // folded operands [P][64][256]
     float *fold_cb = nullptr, *t2i_part = nullptr, *t2i_ml = nullptr;
-    float* u1 = nullptr; bf16_t *u1b = nullptr, *up2 = nullptr;
     float *masks4 = nullptr, *hyper_out = nullptr, *iou4 = nullptr, *head_tmp = nullptr;
     bf16_t *head_bf0 = nullptr, *head_bf1 = nullptr;
     int* counts_ws = nullptr;

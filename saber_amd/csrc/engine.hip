@@ -390,6 +390,22 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         convT(d + "output_upscaling.0", 256, 64, &e->dc1);
         e->up_ln = F.ln(d + "output_upscaling.1", 64);
         convT(d + "output_upscaling.3", 64, 32, &e->dc2);
+        {   // dc2 weight with the contraction index permuted to the k-slot order phase A leaves in registers:
+            // slot 8g+j of k-step ks <- channel 32ks + 4g + j (j<4) | 32ks + 16 + 4g + (j-4) (j>=4)
+            const HostTensor* w = F.get(d + "output_upscaling.3.weight", {64, 32, 2, 2});
+            if (w) {
+                std::vector<float> wp((size_t)128 * 64);
+                for (int pos = 0; pos < 4; ++pos)
+                    for (int co = 0; co < 32; ++co)
+                        for (int ks = 0; ks < 2; ++ks)
+                            for (int g = 0; g < 4; ++g)
+                                for (int jj = 0; jj < 8; ++jj) {
+                                    const int ci = jj < 4 ? 32 * ks + 4 * g + jj : 32 * ks + 16 + 4 * g + (jj - 4);
+                                    wp[((size_t)pos * 32 + co) * 64 + ks * 32 + g * 8 + jj] = w->data[(((size_t)ci * 32 + co) * 2 + (pos >> 1)) * 2 + (pos & 1)];
+                                }
+                e->dc2p = F.up_bf16(wp);
+            }
+        }
         const int hdims[3][2] = {{256, 256}, {256, 256}, {32, 256}};
         for (int l = 0; l < 3; ++l) {
             std::vector<float> w, b;
@@ -447,9 +463,6 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->fold_cb, P * 64));
     TRY(eng_alloc(e, &e->t2i_part, P * 8 * 64 * 256));
     TRY(eng_alloc(e, &e->t2i_ml, P * 8 * 64 * 2));
-    TRY(eng_alloc(e, &e->u1, P * 4096 * 256));
-    TRY(eng_alloc(e, &e->u1b, P * 4096 * 256));
-    TRY(eng_alloc(e, &e->up2, P * 16384 * 128));
     TRY(eng_alloc(e, &e->masks4, P * 4 * 65536));
     TRY(eng_alloc(e, &e->hyper_out, P * 128));
     TRY(eng_alloc(e, &e->iou4, P * 4));
@@ -735,18 +748,10 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
         g.Cf = e->hyper_out; g.ldcf = 128; g.strideCf = 32;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
     }
-    // upscaling: dc1 + feat_s1 -> LN2d -> GELU -> dc2 + feat_s0 -> GELU
-    {
-        GemmParams g = mk_gemm(X, 256, P * 4096, e->dc1);
-        g.Cf = e->u1; g.ldcf = 256; g.res = e->fs1 + (size_t)slot * 16384 * 64; g.ldres = 256; g.res_mod = 4096;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->u1, e->up_ln, 1e-6f, P * 16384, 64, nullptr, e->u1b, ACT_GELU, s));
-        g = mk_gemm(e->u1b, 64, P * 16384, e->dc2);
-        g.Cb = e->up2; g.ldcb = 128; g.res = e->fs0 + (size_t)slot * 65536 * 32; g.ldres = 128; g.res_mod = 16384;
-        g.act = ACT_GELU; g.act_last = 1;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-    }
-    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_dot(e->up2, e->hyper_out, P, e->masks4, s));
+    // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
+    ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
+           launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot * 16384 * 64,
+                              e->fs0 + (size_t)slot * 65536 * 32, e->hyper_out, e->masks4, P, s));
     float* om = out_lowres ? out_lowres : e->dec_out_masks;
     float* oi = out_iou ? out_iou : e->dec_out_iou;
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));

@@ -89,6 +89,8 @@ const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
                            const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
 const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt, const float* bo,
                            const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s);
+const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
+                               const float* b2, const float* fs1, const float* fs0, const float* hyper, float* masks4, int P, hipStream_t s);
 const char* decoder_fused_init_device();
 
 // K8: bilinear upsample of 256x256 logits to the crop, threshold / stability counts / bbox / bit-packing.
