@@ -19,7 +19,7 @@
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -32,16 +32,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 
     const int c = tid & 7, r0 = tid >> 3;
     uint4 ra[4], rw[4];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto gload = [&](int kt) {
+    // Loads are unconditional from clamped in-bounds addresses and zeroed by value selects afterwards: a
+    // "load or zero" written as a branch makes hipcc wait vmcnt(0) per load and serialises the prefetch.
+    int64_t aoff[4], woff[4];
+    bool aok[4], wok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
+        aok[i] = row < p.M;
+        wok[i] = n < p.N;
+        aoff[i] = (int64_t)(aok[i] ? row : p.M - 1) * p.lda;
+        woff[i] = (int64_t)(wok[i] ? n : p.N - 1) * p.ldw;
+    }
+    bool kok_cur = true;
+    auto gload = [&](int kt) {   // raw loads only: nothing consumes the registers until lstore()
         const int k = kt * BK + c * 8;
-        const bool kok = k < p.K;
+        kok_cur = k < p.K;
+        const int kc = kok_cur ? k : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + r0 + 32 * i;
-            ra[i] = (kok && row < p.M) ? *reinterpret_cast<const uint4*>(A + (int64_t)row * p.lda + k) : zero4;
-            const int n = n0 + r0 + 32 * i;
-            rw[i] = (kok && n < p.N) ? *reinterpret_cast<const uint4*>(W + (int64_t)n * p.ldw + k) : zero4;
+            ra[i] = *reinterpret_cast<const uint4*>(A + aoff[i] + kc);
+            rw[i] = *reinterpret_cast<const uint4*>(W + woff[i] + kc);
         }
     };
     auto lstore = [&](int buf) {
@@ -51,8 +62,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 32 * i;
             const int off = swz(row, c);
-            *reinterpret_cast<uint4*>(sa + off) = ra[i];
-            *reinterpret_cast<uint4*>(sw + off) = rw[i];
+            uint4 va = ra[i], vw = rw[i];
+            const bool oa = kok_cur && aok[i], ow = kok_cur && wok[i];
+            va.x = oa ? va.x : 0u; va.y = oa ? va.y : 0u; va.z = oa ? va.z : 0u; va.w = oa ? va.w : 0u;
+            vw.x = ow ? vw.x : 0u; vw.y = ow ? vw.y : 0u; vw.z = ow ? vw.z : 0u; vw.w = ow ? vw.w : 0u;
+            *reinterpret_cast<uint4*>(sa + off) = va;
+            *reinterpret_cast<uint4*>(sw + off) = vw;
         }
     };
 
