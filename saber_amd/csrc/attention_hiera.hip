@@ -211,17 +211,15 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     const float sc = 0.11785113019775793f * 1.4426950408889634f;
 
     // staging: 128 rows x 9 chunks = 1152 16-B chunks per operand, 4.5 per thread
-    uint4 rk[5], rv[5];
+    u32x4 rk[5], rv[5];
     auto gload = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int idx = tid + 256 * j;
-            if (idx < KB * 9) {
-                const int row = idx / 9, ch = idx - row * 9;
-                const bf16_t* p = qkv + (tok0 + (int64_t)kb * KB + row) * rs + h * HD + ch * 8;
-                rk[j] = *reinterpret_cast<const uint4*>(p + os);
-                rv[j] = *reinterpret_cast<const uint4*>(p + 2 * os);
-            }
+            const int idx = min(tid + 256 * j, KB * 9 - 1);  // unconditional (clamped) loads keep rk/rv in registers
+            const int row = idx / 9, ch = idx - row * 9;
+            const bf16_t* p = qkv + (tok0 + (int64_t)kb * KB + row) * rs + h * HD + ch * 8;
+            rk[j] = *reinterpret_cast<const u32x4*>(p + os);
+            rv[j] = *reinterpret_cast<const u32x4*>(p + 2 * os);
         }
     };
     auto lstore = [&]() {
@@ -230,8 +228,8 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
             const int idx = tid + 256 * j;
             if (idx < KB * 9) {
                 const int row = idx / 9, ch = idx - row * 9;
-                *reinterpret_cast<uint4*>(ks_ + row * 256 + ((ch ^ (row & 15)) << 4)) = rk[j];
-                *reinterpret_cast<uint4*>(vs + row * VSTRIDE + ch * 16) = rv[j];
+                *reinterpret_cast<u32x4*>(ks_ + row * 256 + ((ch ^ (row & 15)) << 4)) = rk[j];
+                *reinterpret_cast<u32x4*>(vs + row * VSTRIDE + ch * 16) = rv[j];
             }
         }
     };

@@ -30,16 +30,13 @@ __device__ __forceinline__ bf16x8 pack8_d(float a0, float a1, float a2, float a3
     return __builtin_bit_cast(bf16x8, u);
 }
 // 8 packed bf16 + 8 packed bf16 -> 8 packed bf16 (fp32 add, RNE)
-__device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) {
-    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
-    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
-    uint4 r;
-    uint32_t* pr = reinterpret_cast<uint32_t*>(&r);
+__device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b) {
+    u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float lo = __uint_as_float(pa[i] << 16) + __uint_as_float(pb[i] << 16);
-        const float hi = __uint_as_float(pa[i] & 0xffff0000u) + __uint_as_float(pb[i] & 0xffff0000u);
-        pr[i] = pack_bf16(lo, hi);
+        const float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+        const float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
+        r[i] = pack_bf16(lo, hi);
     }
     return r;
 }
@@ -114,22 +111,22 @@ __global__ __launch_bounds__(256) void dec_t2i_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int dt = 0; dt < 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 rx[8], rp[8];
+    u32x4 rx[8], rp[8];
     auto gload = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
             const int64_t off = (int64_t)(key0 + kb * T2I_KB + row) * DC + ch * 8;
-            rx[j] = *reinterpret_cast<const uint4*>(Xp + off);
-            rp[j] = *reinterpret_cast<const uint4*>(pe + off);
+            rx[j] = *reinterpret_cast<const u32x4*>(Xp + off);
+            rp[j] = *reinterpret_cast<const u32x4*>(pe + off);
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            *reinterpret_cast<uint4*>(ks_ + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
-            *reinterpret_cast<uint4*>(vs + row * VT_STRIDE + ch * 16) = rx[j];
+            *reinterpret_cast<u32x4*>(ks_ + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
+            *reinterpret_cast<u32x4*>(vs + row * VT_STRIDE + ch * 16) = rx[j];
         }
     };
 
@@ -286,25 +283,26 @@ __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__
         cbv[ct][0] = v.x; cbv[ct][1] = v.y; cbv[ct][2] = v.z; cbv[ct][3] = v.w;
     }
 
-    uint4 rx[8], rp[8];
+    u32x4 rx[8], rp[8];
     auto gload = [&](int t) {
         const int row0 = (seg * I2T_TILES + t) * I2T_ROWS;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
             const int64_t off = (int64_t)(row0 + row) * DC + ch * 8;
-            rx[j] = *reinterpret_cast<const uint4*>(Xp + off);
-            rp[j] = *reinterpret_cast<const uint4*>(pe + off);
+            rx[j] = *reinterpret_cast<const u32x4*>(Xp + off);
+            rp[j] = *reinterpret_cast<const u32x4*>(pe + off);
         }
     };
     gload(0);
+#pragma unroll 1
     for (int t = 0; t < I2T_TILES; ++t) {
         __syncthreads();  // previous tile consumed (first time: folded operands visible after the 2nd barrier)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            *reinterpret_cast<uint4*>(xp_s + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
-            *reinterpret_cast<uint4*>(x_s + row * ROW_B + ch * 16) = rx[j];
+            *reinterpret_cast<u32x4*>(xp_s + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
+            *reinterpret_cast<u32x4*>(x_s + row * ROW_B + ch * 16) = rx[j];
         }
         __syncthreads();
         if (t + 1 < I2T_TILES) gload(t + 1);
@@ -444,24 +442,23 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint4 rw[8];
-    auto wload = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
-            rw[j] = *reinterpret_cast<const uint4*>(W1 + row * 256 + kt * 64 + ch * 8);
-        }
-    };
-    wload(0);
+    u32x4 rw[8];
+#define UP_WLOAD(KT)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
+        const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;                                   \
+        rw[j] = *reinterpret_cast<const u32x4*>(W1 + row * 256 + (KT) * 64 + ch * 8);                  \
+    }
+    UP_WLOAD(0)
+#pragma unroll 1
     for (int kt = 0; kt < 4; ++kt) {
         __syncthreads();  // previous slice consumed (first: nothing pending)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
-            *reinterpret_cast<uint4*>(w1s + swz128(row, ch)) = rw[j];
+            *reinterpret_cast<u32x4*>(w1s + swz128(row, ch)) = rw[j];
         }
         __syncthreads();
-        if (kt + 1 < 4) wload(kt + 1);
+        if (kt + 1 < 4) { UP_WLOAD(kt + 1) }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 wf[4], xf[4];

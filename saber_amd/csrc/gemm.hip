@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const bf16_t* __restrict__ W = p.W + z * p.strideW;
 
     const int c = tid & 7, r0 = tid >> 3;
-    uint4 ra[4], rw[4];
+    u32x4 ra[4], rw[4];
     // Loads are unconditional from clamped in-bounds addresses and zeroed by value selects afterwards: a
     // "load or zero" written as a branch makes hipcc wait vmcnt(0) per load and serialises the prefetch.
     int64_t aoff[4], woff[4];
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         const int kc = kok_cur ? k : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const uint4*>(A + aoff[i] + kc);
-            rw[i] = *reinterpret_cast<const uint4*>(W + woff[i] + kc);
+            ra[i] = *reinterpret_cast<const u32x4*>(A + aoff[i] + kc);
+            rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + kc);
         }
     };
     auto lstore = [&](int buf) {
@@ -62,12 +62,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 32 * i;
             const int off = swz(row, c);
-            uint4 va = ra[i], vw = rw[i];
-            const bool oa = kok_cur && aok[i], ow = kok_cur && wok[i];
-            va.x = oa ? va.x : 0u; va.y = oa ? va.y : 0u; va.z = oa ? va.z : 0u; va.w = oa ? va.w : 0u;
-            vw.x = ow ? vw.x : 0u; vw.y = ow ? vw.y : 0u; vw.z = ow ? vw.z : 0u; vw.w = ow ? vw.w : 0u;
-            *reinterpret_cast<uint4*>(sa + off) = va;
-            *reinterpret_cast<uint4*>(sw + off) = vw;
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(sa + off) = (kok_cur && aok[i]) ? ra[i] : z4;
+            *reinterpret_cast<u32x4*>(sw + off) = (kok_cur && wok[i]) ? rw[i] : z4;
         }
     };
 
