@@ -248,7 +248,7 @@ const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
 // ------------------------------------------------------------------------------------------------ image -> tokens
 #define I2T_ROWS 64
 #define I2T_TILES 8   // row tiles per block (512 rows), folded operands stay in LDS across them
-#define I2T_LDS (64 * ROW_B + 64 * VT_STRIDE + 2 * I2T_ROWS * ROW_B)
+#define I2T_LDS (64 * ROW_B + 64 * VT_STRIDE + I2T_ROWS * ROW_B + I2T_ROWS * VT_STRIDE)
 
 // grid = P * (4096 / (I2T_ROWS * I2T_TILES)).  X_out[p][n] = LN(x_n + softmax_heads((x_n + pe_n).Kt + cb).Vt + b_o)
 __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__
     char* kt_s = smem;                                  // [64 c][256] swizzled   (A operand of GEMM1)
     char* vt_s = kt_s + 64 * ROW_B;                     // [64 c][256] stride 544 (tr-read source of GEMM2)
     char* xp_s = vt_s + 64 * VT_STRIDE;                 // [64 rows][256] swizzled: bf16(x + pe)  (B operand of GEMM1)
-    char* x_s = xp_s + I2T_ROWS * ROW_B;                // [64 rows][256] linear: x (residual)
+    char* x_s = xp_s + I2T_ROWS * ROW_B;                // [64 rows][256] x (residual), padded rows: the 16 rows a wave reads hit different banks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     const int blocks_per_p = 4096 / (I2T_ROWS * I2T_TILES);
@@ -283,26 +283,30 @@ __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__
         cbv[ct][0] = v.x; cbv[ct][1] = v.y; cbv[ct][2] = v.z; cbv[ct][3] = v.w;
     }
 
-    u32x4 rx[8], rp[8];
+    u32x4 rx[8];
     auto gload = [&](int t) {
         const int row0 = (seg * I2T_TILES + t) * I2T_ROWS;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            const int64_t off = (int64_t)(row0 + row) * DC + ch * 8;
-            rx[j] = *reinterpret_cast<const u32x4*>(Xp + off);
-            rp[j] = *reinterpret_cast<const u32x4*>(pe + off);
+            rx[j] = *reinterpret_cast<const u32x4*>(Xp + (int64_t)(row0 + row) * DC + ch * 8);
         }
     };
     gload(0);
 #pragma unroll 1
     for (int t = 0; t < I2T_TILES; ++t) {
+        u32x4 rp[8];   // positional encoding of this tile: shared by every prompt, L2-resident
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
+            rp[j] = *reinterpret_cast<const u32x4*>(pe + (int64_t)((seg * I2T_TILES + t) * I2T_ROWS + row) * DC + ch * 8);
+        }
         __syncthreads();  // previous tile consumed (first time: folded operands visible after the 2nd barrier)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
             *reinterpret_cast<u32x4*>(xp_s + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
-            *reinterpret_cast<u32x4*>(x_s + row * ROW_B + ch * 16) = rx[j];
+            *reinterpret_cast<u32x4*>(x_s + row * VT_STRIDE + ch * 16) = rx[j];
         }
         __syncthreads();
         if (t + 1 < I2T_TILES) gload(t + 1);
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__
         float sum = 0.f;
 #pragma unroll
         for (int dt = 0; dt < 16; ++dt) {
-            const uint2 xr = *reinterpret_cast<const uint2*>(x_s + mrow * ROW_B + (16 * dt + 4 * fg) * 2);
+            const uint2 xr = *reinterpret_cast<const uint2*>(x_s + mrow * VT_STRIDE + (16 * dt + 4 * fg) * 2);
             const float4 b4 = *reinterpret_cast<const float4*>(bo + 16 * dt + 4 * fg);
             y[dt][0] += __uint_as_float(xr.x << 16) + b4.x;
             y[dt][1] += __uint_as_float(xr.x & 0xffff0000u) + b4.y;

@@ -164,12 +164,20 @@ struct Finalizer {
         if (hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { status = eng_fail(e, SABER_ERR_HIP, "weight upload failed"); return nullptr; }
         return d;
     }
+    // [rows][cols] fp32 -> bf16 with every row zero-padded to a multiple of 64 (direct-to-LDS GEMM contract)
+    void up_lin(LinW* l, const std::vector<float>& w, int rows, int cols) {
+        const int ld = (cols + 63) / 64 * 64;
+        std::vector<float> padded((size_t)rows * ld, 0.0f);
+        for (int r = 0; r < rows; ++r) std::copy(w.begin() + (size_t)r * cols, w.begin() + (size_t)(r + 1) * cols, padded.begin() + (size_t)r * ld);
+        l->w = up_bf16(padded);
+        l->out = rows; l->in = cols; l->ldw = ld;
+    }
     LinW lin(const std::string& prefix, int out, int in) {
         LinW l; l.out = out; l.in = in;
         const HostTensor* w = get(prefix + ".weight", {out, in});
         const HostTensor* b = get(prefix + ".bias", {out});
         if (!w || !b) return l;
-        l.w = up_bf16(w->data); l.b = up_f32(b->data);
+        up_lin(&l, w->data, out, in); l.b = up_f32(b->data);
         return l;
     }
     LinW lin_conv1x1(const std::string& prefix, int out, int in) {
@@ -177,7 +185,7 @@ struct Finalizer {
         const HostTensor* w = get(prefix + ".weight", {out, in, 1, 1});
         const HostTensor* b = get(prefix + ".bias", {out});
         if (!w || !b) return l;
-        l.w = up_bf16(w->data); l.b = up_f32(b->data);
+        up_lin(&l, w->data, out, in); l.b = up_f32(b->data);
         return l;
     }
     LnW ln(const std::string& prefix, int c) {
@@ -284,10 +292,10 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         const HostTensor* s1w = F.get("sam_mask_decoder.conv_s1.weight", {64, 256, 1, 1});
         const HostTensor* s1b = F.get("sam_mask_decoder.conv_s1.bias", {64});
         if (F.status != SABER_OK) return F.status;
-        e->neck3.out = 256; e->neck3.in = dims[0]; e->neck3.w = F.up_bf16(nw[0]->data); e->neck3.b = F.up_f32(nb[0]->data);
+        F.up_lin(&e->neck3, nw[0]->data, 256, dims[0]); e->neck3.b = F.up_f32(nb[0]->data);
         std::vector<float> b2(nb[1]->data);
         for (int c = 0; c < 256; ++c) b2[c] += nm->data[c];
-        e->neck2.out = 256; e->neck2.in = dims[1]; e->neck2.w = F.up_bf16(nw[1]->data); e->neck2.b = F.up_f32(b2);
+        F.up_lin(&e->neck2, nw[1]->data, 256, dims[1]); e->neck2.b = F.up_f32(b2);
         auto compose = [&](const HostTensor* sw, const HostTensor* sbias, int so, const HostTensor* lw, const HostTensor* lb, int li, LinW* out) {
             std::vector<float> w((size_t)so * li), b(so);
             for (int o = 0; o < so; ++o) {
@@ -300,7 +308,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
                     w[(size_t)o * li + k] = (float)a;
                 }
             }
-            out->out = so; out->in = li; out->w = F.up_bf16(w); out->b = F.up_f32(b);
+            F.up_lin(out, w, so, li); out->b = F.up_f32(b);
         };
         compose(s1w, s1b, 64, nw[2], nb[2], dims[2], &e->s1);
         compose(s0w, s0b, 32, nw[3], nb[3], dims[3], &e->s0);
@@ -385,7 +393,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
                     for (int ci = 0; ci < cin; ++ci)
                         wt[((size_t)pos * cout + co) * cin + ci] = w->data[(((size_t)ci * cout + co) * 2 + (pos >> 1)) * 2 + (pos & 1)];
                 }
-            out->out = 4 * cout; out->in = cin; out->w = F.up_bf16(wt); out->b = F.up_f32(bt);
+            F.up_lin(out, wt, 4 * cout, cin); out->b = F.up_f32(bt);
         };
         convT(d + "output_upscaling.0", 256, 64, &e->dc1);
         e->up_ln = F.ln(d + "output_upscaling.1", 64);
@@ -417,8 +425,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
                 w.insert(w.end(), wk->data.begin(), wk->data.end());
                 b.insert(b.end(), bk->data.begin(), bk->data.end());
             }
-            e->hyper[l].out = hdims[l][0]; e->hyper[l].in = hdims[l][1];
-            e->hyper[l].w = F.up_bf16(w); e->hyper[l].b = F.up_f32(b);
+            F.up_lin(&e->hyper[l], w, 4 * hdims[l][0], hdims[l][1]); e->hyper[l].out = hdims[l][0]; e->hyper[l].b = F.up_f32(b);
         }
         const int iou_out[3] = {256, 256, 4}, obj_out[3] = {256, 256, 1};
         for (int l = 0; l < 3; ++l) {
@@ -514,7 +521,7 @@ extern "C" int saber_profile_end(saber_engine* e, saber_profile_class* out, int 
 // ------------------------------------------------------------------------------------------------ helpers
 static GemmParams mk_gemm(const bf16_t* A, int64_t lda, int M, const LinW& w) {
     GemmParams p;
-    p.A = A; p.lda = lda; p.W = w.w; p.ldw = w.in; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in;
+    p.A = A; p.lda = lda; p.W = w.w; p.ldw = w.ldw; p.w_kpad = 1; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in;
     return p;
 }
 static const char* ln_run(const float* x, const LnW& w, float eps, int rows, int C, float* out_f, bf16_t* out_bf, int act, hipStream_t s,

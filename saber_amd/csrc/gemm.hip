@@ -19,88 +19,7 @@
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int64_t z = blockIdx.z;
-    const bf16_t* __restrict__ A = p.A + z * p.strideA;
-    const bf16_t* __restrict__ W = p.W + z * p.strideW;
-
-    const int c = tid & 7, r0 = tid >> 3;
-    u32x4 ra[4], rw[4];
-    // Loads are unconditional from clamped in-bounds addresses and zeroed by value selects afterwards: a
-    // "load or zero" written as a branch makes hipcc wait vmcnt(0) per load and serialises the prefetch.
-    int64_t aoff[4], woff[4];
-    bool aok[4], wok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
-        aok[i] = row < p.M;
-        wok[i] = n < p.N;
-        aoff[i] = (int64_t)(aok[i] ? row : p.M - 1) * p.lda;
-        woff[i] = (int64_t)(wok[i] ? n : p.N - 1) * p.ldw;
-    }
-    bool kok_cur = true;
-    auto gload = [&](int kt) {   // raw loads only: nothing consumes the registers until lstore()
-        const int k = kt * BK + c * 8;
-        kok_cur = k < p.K;
-        const int kc = kok_cur ? k : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const u32x4*>(A + aoff[i] + kc);
-            rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + kc);
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sw = sa + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = r0 + 32 * i;
-            const int off = swz(row, c);
-            const u32x4 z4 = {0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(sa + off) = (kok_cur && aok[i]) ? ra[i] : z4;
-            *reinterpret_cast<u32x4*>(sw + off) = (kok_cur && wok[i]) ? rw[i] : z4;
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int fi = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
-        const char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
-        const char* sw = sa + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
-                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) lstore((kt + 1) & 1);
-        __syncthreads();
-    }
-
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fi, int fg, int64_t z) {
     // ---------------- epilogue: lane owns C[m][n..n+3]
     const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
     const float* res = p.res ? p.res + z * p.strideRes : nullptr;
@@ -184,9 +103,200 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int64_t z = blockIdx.z;
+    const bf16_t* __restrict__ A = p.A + z * p.strideA;
+    const bf16_t* __restrict__ W = p.W + z * p.strideW;
+
+    const int c = tid & 7, r0 = tid >> 3;
+    u32x4 ra[4], rw[4];
+    // Loads are unconditional from clamped in-bounds addresses and zeroed by value selects afterwards: a
+    // "load or zero" written as a branch makes hipcc wait vmcnt(0) per load and serialises the prefetch.
+    int64_t aoff[4], woff[4];
+    bool aok[4], wok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
+        aok[i] = row < p.M;
+        wok[i] = n < p.N;
+        aoff[i] = (int64_t)(aok[i] ? row : p.M - 1) * p.lda;
+        woff[i] = (int64_t)(wok[i] ? n : p.N - 1) * p.ldw;
+    }
+    bool kok_cur = true;
+    auto gload = [&](int kt) {   // raw loads only: nothing consumes the registers until lstore()
+        const int k = kt * BK + c * 8;
+        kok_cur = k < p.K;
+        const int kc = kok_cur ? k : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const u32x4*>(A + aoff[i] + kc);
+            rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + kc);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 32 * i;
+            const int off = swz(row, c);
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(sa + off) = (kok_cur && aok[i]) ? ra[i] : z4;
+            *reinterpret_cast<u32x4*>(sw + off) = (kok_cur && wok[i]) ? rw[i] : z4;
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fi = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    gemm_epilogue(p, acc, m0, n0, wm, wn, fi, fg, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Same tile, but operands go global -> LDS directly (global_load_lds_dwordx4, no staging VGPRs, no ds_write) through a
+// 3-stage ring with counted vmcnt and raw s_barrier, so two K-tiles of loads stay in flight across the barrier
+// (cdna_hip_programming.md "Pipelining across barriers").  The XOR swizzle is applied on the SOURCE address (the LDS
+// image of one wave-instruction is lane-linear).  Out-of-range rows are clamped instead of zeroed: rows >= M / >= N
+// only feed outputs that are never stored.  Requires W rows zero-padded to a multiple of 64 in K (p.w_kpad).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// WM wave-rows x 2 wave-columns, each wave 64x64: WM = 2 -> 128x128 tile (4 waves), WM = 4 -> 256x128 tile (8 waves,
+// two per SIMD, so one wave's ds_read latency hides under the other's MFMAs).
+template <int WM>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) {
+    constexpr int TBM = WM * 64;
+    constexpr int A_BYTES = TBM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int NW = WM * 2;                 // waves
+    constexpr int WI = 16 / NW;                // W wave-instructions per wave per K-tile (A: always 4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * TBM, n0 = tn * BN;
+    const int64_t z = blockIdx.z;
+    const bf16_t* __restrict__ A = p.A + z * p.strideA;
+    const bf16_t* __restrict__ W = p.W + z * p.strideW;
+    const int fi = lane & 15, fg = lane >> 4;
+
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[WI];
+    int achunk[4], wchunk[WI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        achunk[i] = (lane & 7) ^ ((row >> 1) & 7);      // logical 16-B chunk that lands at physical slot lane&7
+        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave * WI + i) * 8 + (lane >> 3);
+        wchunk[i] = (lane & 7) ^ ((row >> 1) & 7);
+        wsrc[i] = W + (int64_t)min(n0 + row, p.N - 1) * p.ldw;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = kt * BK + achunk[i] * 8;
+            const int ka = k < p.K ? k : 0;              // K tail of A: any finite data, W supplies the zeros
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + ka), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK + wchunk[i] * 8), (lptr_t)(sa + A_BYTES + (wave * WI + i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    issue(0, 0);
+    if (nk > 1) {
+        issue(1, 1);
+        if (WI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        if (more) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+        const char* sa = smem + stage * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        // tile kt+1 must have landed (this wave's part) before the barrier; tile kt+2's loads may stay in flight
+        if (more) { if (WI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    gemm_epilogue(p, acc, m0, n0, wm, wn, fi, fg, z);
+}
+#define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2))
+#define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2))
+
 const char* gemm_init_device() {
     hipError_t st = hipSuccess;
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_128);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_256);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
@@ -203,6 +313,13 @@ const char* launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.pool4 && (p.M & 3)) return "gemm: pool4 needs M % 4 == 0";
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
-    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+    const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
+    const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+    if (direct_ok && tiles256 >= 256 && !p.pool4) {
+        // big problems: 256x128 tiles, 8 waves, operands straight into a 3-stage LDS ring
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<4>, dim3(tiles256, 1, grid.z), dim3(512), GS_LDS_256, stream, p);
+    } else {
+        hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+    }
     return nullptr;
 }
