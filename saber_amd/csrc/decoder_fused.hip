@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
                                                           const float* __restrict__ fs1, const float* __restrict__ fs0,
-                                                          const float* __restrict__ hyper, float* __restrict__ masks4) {
+                                                          const float* __restrict__ hyper, float* __restrict__ masks4, int P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     char* w1s = xs + UP_XS;
@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
     float* outs = reinterpret_cast<float*>(xs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
-    const int p = blockIdx.x >> 6, tile = blockIdx.x & 63;
+    // tile-major order: the blocks in flight together share one token tile, so its feat_s0 / feat_s1 rows are L2 hits
+    const int tile = blockIdx.x / P, p = blockIdx.x - tile * P;
     const bf16_t* Xt = X + ((int64_t)p * 4096 + tile * 64) * DC;
 
     // stage X tile and W2p once
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, const float* hyper, float* masks4, int P, hipStream_t s) {
     if (P <= 0) return nullptr;
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(P * 64), dim3(256), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, hyper, masks4);
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(P * 64), dim3(256), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, hyper, masks4, P);
     return nullptr;
 }
 
