@@ -26,7 +26,7 @@ __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)(pack_bf16(x, 0
 // SAM2 is evaluated ~5e10 times per slice, so libm erff alone would cost tens of ms of pure VALU time.
 __device__ __forceinline__ float fast_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp); an IEEE divide costs ~10 VALU ops
     float p = 1.061405429f;
     p = fmaf(p, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);

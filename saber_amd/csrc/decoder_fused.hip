@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[ct][r] = exp2f(s[ct][r] - mx); sum += s[ct][r]; }
             sum += __shfl_xor(sum, 16, 64);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[ct][r] *= inv;
         }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__
             for (int r = 0; r < 4; ++r) { const float dlt = y[dt][r] - mean; var += dlt * dlt; }
         var += __shfl_xor(var, 16, 64);
         var += __shfl_xor(var, 32, 64);
-        const float rstd = 1.0f / sqrtf(var * (1.0f / DC) + eps);
+        const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / DC) + eps);
         bf16_t* orow = Xo + (int64_t)((seg * I2T_TILES + t) * I2T_ROWS + mrow) * DC;
 #pragma unroll
         for (int dt = 0; dt < 16; ++dt) {
@@ -402,102 +402,118 @@ const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
 // ------------------------------------------------------------------------------------------------ upscaling head
 // Fused output_upscaling + hypernetwork product:
 //   u1 = GELU(LN64(ConvT1(x) + feat_s1));  u2 = GELU(ConvT2(u1) + feat_s0);  masks[k] = hyper[k] . u2
-// One block = 64 consecutive tokens (a 4x16 token patch = 16x64 output pixels) of one prompt.
-// Phase A: [64 tok] x [256 = pos*64+ch] GEMM over K=256; wave w owns pos = w, so its LayerNorm groups are
-// wave-local and its GELU outputs feed phase B straight from registers (k-slot permutation, W2 pre-permuted).
-// Phase B: [(pos w, 64 tok)] x [128 = pos2*32+ch2] GEMM over K=64, epilogue = +feat_s0, GELU, 4 dot products.
+// Persistent blocks: one block owns a tile of 32 consecutive tokens (2x16 tokens = 8x64 output pixels) and walks over
+// the prompts.  Both ConvTranspose weights stay resident in LDS (128 KB + 16 KB), the tile's feat_s1 / feat_s0 rows and
+// the LayerNorm parameters stay in registers, and the next prompt's 16-KB X tile is prefetched while the current one is
+// computed - per prompt the block touches HBM only for X (read) and the 8-KB logit tile (write).
+// Phase A: [32 tok] x [256 = pos*64+ch] over K=256; wave w owns pos = w, so its LayerNorm groups are wave-local and its
+// GELU outputs feed phase B straight from registers (k-slot permutation, W2 pre-permuted on the host).
+// Phase B: [(pos w, 32 tok)] x [128 = pos2*32+ch2] over K=64, epilogue = +feat_s0, GELU, 4 dot products with hyper.
 // The 32-channel 256x256 upscaled embedding (8 MB fp32 per prompt) never exists in memory.
-#define UP_XS (64 * ROW_B)            // X tile   [64][256] bf16, kswz
-#define UP_W1S (256 * 128)            // W1 slice [256 n][64 k] bf16, 128-B rows swizzled
-#define UP_W2S (128 * 128)            // W2p      [128 n2][64] bf16 (k-slots pre-permuted)
-#define UP_OUT (4 * 16 * 64 * 4)      // output tile [4 masks][16 rows][64 cols] fp32
-#define UP_LDS (UP_XS + UP_W1S + UP_W2S)   // the output tile aliases the X tile (dead after phase A)
+#define UP_TOK 32
+#define UP_W1S (256 * ROW_B)          // W1 [256 n][256 k] bf16, kswz
+#define UP_W2S (128 * 128)            // W2p [128 n2][64] bf16 (k-slots pre-permuted), swz128
+#define UP_XS (UP_TOK * ROW_B)        // X tile [32][256] bf16, kswz; reused as the output tile [4][8][64] fp32
+#define UP_LDS (UP_W1S + UP_W2S + UP_XS)
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+__global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
                                                           const float* __restrict__ fs1, const float* __restrict__ fs0,
-                                                          const float* __restrict__ hyper, float* __restrict__ masks4, int P) {
+                                                          const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xs = smem;
-    char* w1s = xs + UP_XS;
+    char* w1s = smem;
     char* w2s = w1s + UP_W1S;
+    char* xs = w2s + UP_W2S;
     float* outs = reinterpret_cast<float*>(xs);
+    // 8 waves (two per SIMD: the epilogues are VALU-bound, a lone wave would issue at half rate):
+    // wave = (token half mw) * 4 + (pos = ConvT1 output position)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = wave & 3, mw = wave >> 2;
     const int fi = lane & 15, fg = lane >> 4;
-    // tile-major order: the blocks in flight together share one token tile, so its feat_s0 / feat_s1 rows are L2 hits
-    const int tile = blockIdx.x / P, p = blockIdx.x - tile * P;
-    const bf16_t* Xt = X + ((int64_t)p * 4096 + tile * 64) * DC;
+    const int tile = blockIdx.x % 128, grp = blockIdx.x / 128;
 
-    // stage X tile and W2p once
+    // resident weights
+    for (int idx = tid; idx < 256 * 32; idx += 512) {
+        const int row = idx >> 5, ch = idx & 31;
+        *reinterpret_cast<u32x4*>(w1s + kswz(row, ch)) = *reinterpret_cast<const u32x4*>(W1 + row * 256 + ch * 8);
+    }
+    for (int idx = tid; idx < 128 * 8; idx += 512) {
+        const int row = idx >> 3, ch = idx & 7;
+        *reinterpret_cast<u32x4*>(w2s + swz128(row, ch)) = *reinterpret_cast<const u32x4*>(W2p + row * 64 + ch * 8);
+    }
+    // per-lane constants of this tile: feat_s1 + b1 (fp32), feat_s0 + b2 (packed bf16), LN parameters
+    const int tl = mw * 16 + fi;                        // token within the tile: bits [X3 X2 X1][Y0][X0]
+    const int tok = tile * UP_TOK + tl;
+    float4 f1[4], gg[4], be[4];
+    uint2 f0[4][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-        *reinterpret_cast<uint4*>(xs + kswz(row, ch)) = *reinterpret_cast<const uint4*>(Xt + (int64_t)row * DC + ch * 8);
+    for (int ni = 0; ni < 4; ++ni) {
+        gg[ni] = *reinterpret_cast<const float4*>(ln_g + ni * 16 + 4 * fg);
+        be[ni] = *reinterpret_cast<const float4*>(ln_b + ni * 16 + 4 * fg);
+        const float4 r = *reinterpret_cast<const float4*>(fs1 + ((int64_t)tok * 4 + pos) * 64 + ni * 16 + 4 * fg);
+        const float4 b = *reinterpret_cast<const float4*>(b1 + pos * 64 + ni * 16 + 4 * fg);
+        f1[ni] = make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
-        *reinterpret_cast<uint4*>(w2s + swz128(row, ch)) = *reinterpret_cast<const uint4*>(W2p + row * 64 + ch * 8);
-    }
-    // ---------------- phase A
-    f32x4 acc[4][4];
+    for (int pos2 = 0; pos2 < 4; ++pos2)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int hh = 0; hh < 2; ++hh) {
+            const float4 r = *reinterpret_cast<const float4*>(fs0 + (((int64_t)tok * 4 + pos) * 4 + pos2) * 32 + hh * 16 + 4 * fg);
+            const float4 b = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
+            f0[pos2][hh] = make_uint2(pack_bf16(r.x + b.x, r.y + b.y), pack_bf16(r.z + b.z, r.w + b.w));
+        }
+    const int dy1 = pos >> 1, dx1 = pos & 1;
+    const int ty = (tl >> 1) & 1, tx = ((tl >> 2) & 7) * 2 + (tl & 1);
+    int ty0, tx0;
+    perm_coords(tile * UP_TOK, 2, &ty0, &tx0);
+
+    u32x4 rx[2];
+    auto xload = [&](int p) {
+        const bf16_t* Xt = X + ((int64_t)p * 4096 + tile * UP_TOK) * DC;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4 rw[8];
-#define UP_WLOAD(KT)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                    \
-        const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;                                   \
-        rw[j] = *reinterpret_cast<const u32x4*>(W1 + row * 256 + (KT) * 64 + ch * 8);                  \
-    }
-    UP_WLOAD(0)
-#pragma unroll 1
-    for (int kt = 0; kt < 4; ++kt) {
-        __syncthreads();  // previous slice consumed (first: nothing pending)
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 512 * j;
+            rx[j] = *reinterpret_cast<const u32x4*>(Xt + (int64_t)(idx >> 5) * DC + (idx & 31) * 8);
+        }
+    };
+    if (grp < P) xload(grp);
+    for (int p = grp; p < P; p += groups) {
+        __syncthreads();  // weights visible (first pass) / previous output tile fully stored
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 3, ch = idx & 7;
-            *reinterpret_cast<u32x4*>(w1s + swz128(row, ch)) = rw[j];
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 512 * j;
+            *reinterpret_cast<u32x4*>(xs + kswz(idx >> 5, idx & 31)) = rx[j];
         }
         __syncthreads();
-        if (kt + 1 < 4) { UP_WLOAD(kt + 1) }
+        if (p + groups < P) xload(p + groups);
+        float4 hy[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], xf[4];
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(w1s + swz128(wave * 64 + i * 16 + fi, ks * 4 + fg));
-                xf[i] = *reinterpret_cast<const bf16x8*>(xs + kswz(i * 16 + fi, kt * 8 + ks * 4 + fg));
+            for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hyper + (int64_t)p * 128 + k * 32 + hh * 16 + 4 * fg);
+        // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256
+        f32x4 acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + kswz(tl, ks * 4 + fg));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1s + kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg));
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[ni], 0, 0, 0);
             }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
         }
-    }
-    // epilogue A: + bias + feat_s1, LayerNorm over the 64 channels of (tok, pos = wave), GELU, pack as phase-B operand
-    bf16x8 uf[4][2];
-    {
-        float4 bb[4], gg[4], be[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            bb[ni] = *reinterpret_cast<const float4*>(b1 + wave * 64 + ni * 16 + 4 * fg);
-            gg[ni] = *reinterpret_cast<const float4*>(ln_g + ni * 16 + 4 * fg);
-            be[ni] = *reinterpret_cast<const float4*>(ln_b + ni * 16 + 4 * fg);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int tok = tile * 64 + mi * 16 + fi;
-            const float* f1 = fs1 + ((int64_t)tok * 4 + wave) * 64;
+        // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
+        bf16x8 uf[2];
+        {
             float v[4][4], sum = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const float4 r4 = *reinterpret_cast<const float4*>(f1 + ni * 16 + 4 * fg);
-                v[ni][0] = acc[mi][ni][0] + bb[ni].x + r4.x; v[ni][1] = acc[mi][ni][1] + bb[ni].y + r4.y;
-                v[ni][2] = acc[mi][ni][2] + bb[ni].z + r4.z; v[ni][3] = acc[mi][ni][3] + bb[ni].w + r4.w;
+                v[ni][0] = acc[ni][0] + f1[ni].x; v[ni][1] = acc[ni][1] + f1[ni].y;
+                v[ni][2] = acc[ni][2] + f1[ni].z; v[ni][3] = acc[ni][3] + f1[ni].w;
                 sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
             }
             sum += __shfl_xor(sum, 16, 64);
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
                 for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
             var += __shfl_xor(var, 16, 64);
             var += __shfl_xor(var, 32, 64);
-            const float rstd = 1.0f / sqrtf(var * (1.0f / 64.0f) + 1e-6f);
+            const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / 64.0f) + 1e-6f);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 v[ni][0] = gelu_erf((v[ni][0] - mean) * rstd * gg[ni].x + be[ni].x);
@@ -520,52 +536,33 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                uf[mi][ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
-                                     v[2 * ks + 1][3]);
+                uf[ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
+                                 v[2 * ks + 1][3]);
         }
-    }
-    __syncthreads();  // every wave is done reading the X tile: its LDS now holds the output tile
-    // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
-    const float* hp = hyper + (int64_t)p * 128;
-    float4 hy[2][4];  // [ch2 half][k]
+        __syncthreads();  // every wave is done reading the X tile: its LDS now holds the output tile
+        // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+        for (int hb = 0; hb < 2; ++hb) {
+            f32x4 c2[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hp + k * 32 + hh * 16 + 4 * fg);
-    const int dy1 = wave >> 1, dx1 = wave & 1;
+            for (int nl = 0; nl < 4; ++nl) c2[nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        f32x4 c2[4][4];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int nl = 0; nl < 4; ++nl) c2[mi][nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 w2f[4];
-#pragma unroll
-            for (int nl = 0; nl < 4; ++nl) w2f[nl] = *reinterpret_cast<const bf16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int nl = 0; nl < 4; ++nl) c2[mi][nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[nl], uf[mi][ks], c2[mi][nl], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int tl = mi * 16 + fi;               // token within the tile
-            const int tok = tile * 64 + tl;
+                for (int nl = 0; nl < 4; ++nl) {
+                    const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
+                    c2[nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, uf[ks], c2[nl], 0, 0, 0);
+                }
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
                 const int pos2 = 2 * hb + pp;
-                const float* f0 = fs0 + (((int64_t)tok * 4 + wave) * 4 + pos2) * 32;
                 float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int nl = 2 * pp + hh;
-                    const float4 bb = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
-                    const float4 r4 = *reinterpret_cast<const float4*>(f0 + hh * 16 + 4 * fg);
-                    const float u0 = gelu_erf(c2[mi][nl][0] + bb.x + r4.x), u1 = gelu_erf(c2[mi][nl][1] + bb.y + r4.y);
-                    const float u2 = gelu_erf(c2[mi][nl][2] + bb.z + r4.z), u3 = gelu_erf(c2[mi][nl][3] + bb.w + r4.w);
+                    const uint2 fb = f0[pos2][hh];
+                    const float u0 = gelu_erf(c2[nl][0] + __uint_as_float(fb.x << 16)), u1 = gelu_erf(c2[nl][1] + __uint_as_float(fb.x & 0xffff0000u));
+                    const float u2 = gelu_erf(c2[nl][2] + __uint_as_float(fb.y << 16)), u3 = gelu_erf(c2[nl][3] + __uint_as_float(fb.y & 0xffff0000u));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) part[k] += (u0 * hy[hh][k].x + u1 * hy[hh][k].y) + (u2 * hy[hh][k].z + u3 * hy[hh][k].w);
                 }
@@ -574,30 +571,25 @@ __global__ __launch_bounds__(256) void dec_upscale_kernel(const bf16_t* __restri
                     part[k] += __shfl_xor(part[k], 16, 64);
                     part[k] += __shfl_xor(part[k], 32, 64);
                 }
-                // local pixel: token (ty, tx) inside the 4x16 patch, sub-pixel from (pos, pos2)
-                const int ty = ((tl >> 5) & 1) * 2 + ((tl >> 1) & 1), tx = ((tl >> 2) & 7) * 2 + (tl & 1);
                 const int py = ty * 4 + dy1 * 2 + (pos2 >> 1), px = tx * 4 + dx1 * 2 + (pos2 & 1);
                 const float mine = fg == 0 ? part[0] : fg == 1 ? part[1] : fg == 2 ? part[2] : part[3];
-                outs[(fg * 16 + py) * 64 + px] = mine;
+                outs[(fg * 8 + py) * 64 + px] = mine;
             }
         }
-    }
-    __syncthreads();
-    int ty0, tx0;
-    perm_coords(tile * 64, 2, &ty0, &tx0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = tid + 256 * j;            // 1024 float4: [k][row][col/4]
-        const int k = idx >> 8, row = (idx >> 4) & 15, c4 = idx & 15;
-        const float4 v = *reinterpret_cast<const float4*>(outs + (k * 16 + row) * 64 + c4 * 4);
-        *reinterpret_cast<float4*>(masks4 + (((int64_t)p * 4 + k) * 256 + (ty0 * 4 + row)) * 256 + tx0 * 4 + c4 * 4) = v;
+        __syncthreads();
+        {
+            const int k = tid >> 7, row = (tid >> 4) & 7, c4 = tid & 15;   // 512 float4: [k][row 0..7][col/4]
+            const float4 v = *reinterpret_cast<const float4*>(outs + (k * 8 + row) * 64 + c4 * 4);
+            *reinterpret_cast<float4*>(masks4 + (((int64_t)p * 4 + k) * 256 + (ty0 * 4 + row)) * 256 + tx0 * 4 + c4 * 4) = v;
+        }
     }
 }
 
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, const float* hyper, float* masks4, int P, hipStream_t s) {
     if (P <= 0) return nullptr;
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(P * 64), dim3(256), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, hyper, masks4, P);
+    const int groups = P >= 2 ? 2 : 1;   // 128 tiles x 2 groups = one resident block per CU
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, hyper, masks4, P, groups);
     return nullptr;
 }
 
