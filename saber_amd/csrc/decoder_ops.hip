@@ -368,71 +368,99 @@ const char* launch_mask_select(const float* masks4, const float* iou4, int P, in
 // thr / thr+-offset, count, track the bounding box, and bit-pack the >thr mask into full-image rows.
 // One block per (mask, band of 4 full-image rows); a wave covers 64 consecutive x of one row, so
 // __ballot gives two packed 32-bit words directly.  fp32 full-res logits never touch HBM.
+#define MP_ROWS 64   // output rows per block (16 per wave): one set of atomics per block, not per row
 __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ lowres, const int* __restrict__ idx, int crop_x0,
                                                         int crop_y0, int crop_w, int crop_h, int H, int W, float thr, float offset,
                                                         uint32_t* __restrict__ bits, MaskStats* __restrict__ stats) {
+    // per wave: the vertically blended source row (256 columns) lives in LDS, every output pixel is then two LDS reads
+    __shared__ float vrow[4][256];
+    __shared__ int red[4][8];
     const int mi = blockIdx.y;
     const float* src = lowres + (int64_t)(idx ? idx[mi] : mi) * 65536;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int y = blockIdx.x * 4 + wave;
-    if (y >= H) return;
     const int W32 = (W + 31) >> 5;
-    uint32_t* brow = bits + ((int64_t)mi * H + y) * W32;
-    const int cy = y - crop_y0;
-    const bool row_in = cy >= 0 && cy < crop_h;
     const float sy_scale = 256.0f / (float)crop_h, sx_scale = 256.0f / (float)crop_w;
-    int y0i = 0, y1i = 0;
-    float ly = 0.f;
-    if (row_in) {
+    int area = 0, inter = 0, uni = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+    for (int r = 0; r < MP_ROWS / 4; ++r) {
+        const int y = blockIdx.x * MP_ROWS + wave * (MP_ROWS / 4) + r;
+        if (y >= H) break;  // wave-uniform
+        uint32_t* brow = bits + ((int64_t)mi * H + y) * W32;
+        const int cy = y - crop_y0;
+        if (cy < 0 || cy >= crop_h) {  // wave-uniform: rows outside the crop are all zero
+            for (int wd = lane; wd < W32; wd += 64) brow[wd] = 0u;
+            continue;
+        }
         float sy = ((float)cy + 0.5f) * sy_scale - 0.5f;
         sy = fmaxf(sy, 0.f);
-        y0i = min((int)sy, 255);
-        y1i = min(y0i + 1, 255);
-        ly = sy - (float)y0i;
+        const int y0i = min((int)sy, 255), y1i = min(y0i + 1, 255);
+        const float ly = sy - (float)y0i;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const float4 a = *reinterpret_cast<const float4*>(src + y0i * 256 + lane * 4);
+            const float4 b = *reinterpret_cast<const float4*>(src + y1i * 256 + lane * 4);
+            float* vw = vrow[wave] + lane * 4;
+            vw[0] = (1.0f - ly) * a.x + ly * b.x; vw[1] = (1.0f - ly) * a.y + ly * b.y;
+            vw[2] = (1.0f - ly) * a.z + ly * b.z; vw[3] = (1.0f - ly) * a.w + ly * b.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* vr = vrow[wave];
+        unsigned long long mybits = 0ull;   // lane k keeps the 64-pixel chunk k (k + 64j for very wide images: flushed below)
+        int rowarea = 0;
+        for (int xb = 0; xb < W; xb += 64) {
+            const int x = xb + lane;
+            const int cx = x - crop_x0;
+            bool on = false, hi = false, lo = false;
+            if (x < W && cx >= 0 && cx < crop_w) {
+                float sx = ((float)cx + 0.5f) * sx_scale - 0.5f;
+                sx = fmaxf(sx, 0.f);
+                const int x0i = min((int)sx, 255);
+                const int x1i = min(x0i + 1, 255);
+                const float lx = sx - (float)x0i;
+                const float v = (1.0f - lx) * vr[x0i] + lx * vr[x1i];
+                on = v > thr;
+                hi = v > thr + offset;
+                lo = v > thr - offset;
+            }
+            const unsigned long long bm = __ballot(on);
+            rowarea += __popcll(bm);
+            inter += __popcll(__ballot(hi));
+            uni += __popcll(__ballot(lo));
+            if (bm) {
+                xmin = min(xmin, xb + (int)__ffsll((long long)bm) - 1);
+                xmax = max(xmax, xb + 63 - (int)__clzll((long long)bm));
+            }
+            const int chunk = xb >> 6;
+            if (lane == (chunk & 63)) mybits = bm;
+            if ((chunk & 63) == 63 || xb + 64 >= W) {   // flush: lanes 0..n-1 hold consecutive 8-byte pieces of the row
+                const int c0 = chunk & ~63;
+                const int wd = (c0 + lane) * 2;
+                if (c0 + lane <= chunk) {
+                    if (wd < W32) brow[wd] = (uint32_t)(mybits & 0xffffffffull);
+                    if (wd + 1 < W32) brow[wd + 1] = (uint32_t)(mybits >> 32);
+                }
+            }
+        }
+        if (rowarea) { area += rowarea; ymin = min(ymin, y); ymax = max(ymax, y); }
     }
-    int area = 0, inter = 0, uni = 0, xmin = 1 << 30, xmax = -1;
-    for (int xb = 0; xb < W; xb += 64) {
-        const int x = xb + lane;
-        const int cx = x - crop_x0;
-        bool on = false, hi = false, lo = false;
-        if (row_in && x < W && cx >= 0 && cx < crop_w) {
-            float sx = ((float)cx + 0.5f) * sx_scale - 0.5f;
-            sx = fmaxf(sx, 0.f);
-            const int x0i = min((int)sx, 255);
-            const int x1i = min(x0i + 1, 255);
-            const float lx = sx - (float)x0i;
-            const float v00 = src[y0i * 256 + x0i], v01 = src[y0i * 256 + x1i];
-            const float v10 = src[y1i * 256 + x0i], v11 = src[y1i * 256 + x1i];
-            const float v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
-            on = v > thr;
-            hi = v > thr + offset;
-            lo = v > thr - offset;
-        }
-        const unsigned long long bm = __ballot(on);
-        area += __popcll(bm);
-        inter += __popcll(__ballot(hi));
-        uni += __popcll(__ballot(lo));
-        if (bm) {
-            xmin = min(xmin, xb + (int)__ffsll((long long)bm) - 1);
-            xmax = max(xmax, xb + 63 - (int)__clzll((long long)bm));
-        }
-        if (lane == 0) {
-            const int wd = xb >> 5;
-            brow[wd] = (uint32_t)(bm & 0xffffffffull);
-            if (wd + 1 < W32) brow[wd + 1] = (uint32_t)(bm >> 32);
-        }
+    if (lane == 0) {
+        red[wave][0] = area; red[wave][1] = inter; red[wave][2] = uni; red[wave][3] = xmin;
+        red[wave][4] = xmax; red[wave][5] = ymin; red[wave][6] = ymax;
     }
-    if (lane == 0 && (uni | area | inter)) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, in_ = 0, u = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+        for (int w = 0; w < 4; ++w) {
+            a += red[w][0]; in_ += red[w][1]; u += red[w][2];
+            x0 = min(x0, red[w][3]); x1 = max(x1, red[w][4]); y0 = min(y0, red[w][5]); y1 = max(y1, red[w][6]);
+        }
         MaskStats* st = stats + mi;
-        if (area) {
-            atomicAdd(&st->area, area);
-            atomicMin(&st->x0, xmin);
-            atomicMax(&st->x1, xmax);
-            atomicMin(&st->y0, y);
-            atomicMax(&st->y1, y);
+        if (a) {
+            atomicAdd(&st->area, a);
+            atomicMin(&st->x0, x0); atomicMax(&st->x1, x1);
+            atomicMin(&st->y0, y0); atomicMax(&st->y1, y1);
         }
-        if (inter) atomicAdd(&st->inter, inter);
-        if (uni) atomicAdd(&st->uni, uni);
+        if (in_) atomicAdd(&st->inter, in_);
+        if (u) atomicAdd(&st->uni, u);
     }
 }
 
@@ -446,7 +474,7 @@ const char* launch_mask_post(const float* lowres, const int* idx, int n, int cro
     if (n <= 0) return nullptr;
     if (crop_w <= 0 || crop_h <= 0) return "mask_post: empty crop";
     hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, n);
-    hipLaunchKernelGGL(mask_post_kernel, dim3((H + 3) / 4, n), dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr,
+    hipLaunchKernelGGL(mask_post_kernel, dim3((H + MP_ROWS - 1) / MP_ROWS, n), dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr,
                        offset, bits, stats);
     return nullptr;
 }
