@@ -19,7 +19,8 @@
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fi, int fg, int64_t z) {
+template <int T>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[T][T], int m0, int n0, int wm, int wn, int fi, int fg, int64_t z) {
     // ---------------- epilogue: lane owns C[m][n..n+3]
     const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
     const float* res = p.res ? p.res + z * p.strideRes : nullptr;
@@ -39,11 +40,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fi;
+    for (int i = 0; i < T; ++i) {
+        const int m = m0 + wm * (16 * T) + i * 16 + fi;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+        for (int j = 0; j < T; ++j) {
+            const int n = n0 + wn * (16 * T) + j * 16 + fg * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             const bool nvec = vec_ok && (n + 3 < p.N);
             if (bias) {
@@ -103,25 +104,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
+// T = MFMA tiles per wave and dimension: T = 4 -> 128x128 block tile, T = 2 -> 64x64 (small problems: 4x the blocks)
+template <int T>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int TB = 32 * T;            // block tile edge
+    constexpr int TBYTES = TB * BK * 2;   // bytes per operand tile
+    constexpr int NL = T;                 // 16-B chunks per thread and operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_n = (p.N + TB - 1) / TB;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TB, n0 = tn * TB;
     const int64_t z = blockIdx.z;
     const bf16_t* __restrict__ A = p.A + z * p.strideA;
     const bf16_t* __restrict__ W = p.W + z * p.strideW;
 
     const int c = tid & 7, r0 = tid >> 3;
-    u32x4 ra[4], rw[4];
+    u32x4 ra[NL], rw[NL];
     // Loads are unconditional from clamped in-bounds addresses and zeroed by value selects afterwards: a
     // "load or zero" written as a branch makes hipcc wait vmcnt(0) per load and serialises the prefetch.
-    int64_t aoff[4], woff[4];
-    bool aok[4], wok[4];
+    int64_t aoff[NL], woff[NL];
+    bool aok[NL], wok[NL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
         const int row = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
         aok[i] = row < p.M;
         wok[i] = n < p.N;
@@ -134,16 +140,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         kok_cur = k < p.K;
         const int kc = kok_cur ? k : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NL; ++i) {
             ra[i] = *reinterpret_cast<const u32x4*>(A + aoff[i] + kc);
             rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + kc);
         }
     };
     auto lstore = [&](int buf) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sw = sa + TILE_BYTES;
+        char* sa = smem + buf * 2 * TBYTES;
+        char* sw = sa + TBYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NL; ++i) {
             const int row = r0 + 32 * i;
             const int off = swz(row, c);
             const u32x4 z4 = {0u, 0u, 0u, 0u};
@@ -152,11 +158,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[T][T];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
     gload(0);
@@ -165,27 +171,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int fi = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        const char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
-        const char* sw = sa + TILE_BYTES;
+        const char* sa = smem + (kt & 1) * 2 * TBYTES;
+        const char* sw = sa + TBYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
+            bf16x8 af[T], wf[T];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
-                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
+            for (int i = 0; i < T; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * (16 * T) + i * 16 + fi, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * (16 * T) + i * 16 + fi, ks * 4 + fg));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < T; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < T; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore((kt + 1) & 1);
         __syncthreads();
     }
 
-    gemm_epilogue(p, acc, m0, n0, wm, wn, fi, fg, z);
+    gemm_epilogue<T>(p, acc, m0, n0, wm, wn, fi, fg, z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -287,14 +293,14 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         __builtin_amdgcn_s_barrier();
         stage = stage == 2 ? 0 : stage + 1;
     }
-    gemm_epilogue(p, acc, m0, n0, wm, wn, fi, fg, z);
+    gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
 }
 #define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2))
 #define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2))
 
 const char* gemm_init_device() {
     hipError_t st = hipSuccess;
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_128);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_256);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
@@ -318,8 +324,12 @@ const char* launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (direct_ok && tiles256 >= 256 && !p.pool4) {
         // big problems: 256x128 tiles, 8 waves, operands straight into a 3-stage LDS ring
         hipLaunchKernelGGL(gemm_bf16_glds_kernel<4>, dim3(tiles256, 1, grid.z), dim3(512), GS_LDS_256, stream, p);
+    } else if (tiles >= 384) {
+        hipLaunchKernelGGL(gemm_bf16_kernel<4>, grid, dim3(256), 4 * TILE_BYTES, stream, p);
     } else {
-        hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+        // small problems (token-side GEMMs of the decoder): 64x64 tiles give 4x the blocks
+        const int tiles64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+        hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(tiles64, 1, grid.z), dim3(256), 2 * TILE_BYTES, stream, p);
     }
     return nullptr;
 }
