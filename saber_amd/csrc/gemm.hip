@@ -17,6 +17,16 @@
 #define BK 64
 #define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand per buffer
 
+// XCD-aware block -> tile map: blocks b and b+8 share an XCD (and its L2).  All N-tiles of one M-tile are given the same
+// b % 8 and consecutive dispatch slots, so the A panel is fetched from HBM once instead of once per XCD that touches it.
+// Grid must be ceil(tiles_m / 8) * 8 * tiles_n blocks; returns false for the padding blocks.
+__device__ __forceinline__ bool tile_map(int b, int tiles_m, int tiles_n, int* tm, int* tn) {
+    const int xcd = b & 7, q = b >> 3;
+    *tn = q % tiles_n;
+    *tm = (q / tiles_n) * 8 + xcd;
+    return *tm < tiles_m;
+}
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int T>
@@ -114,7 +124,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + TB - 1) / TB;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    int tm, tn;
+    if (!tile_map(blockIdx.x, (p.M + TB - 1) / TB, tiles_n, &tm, &tn)) return;
     const int m0 = tm * TB, n0 = tn * TB;
     const int64_t z = blockIdx.z;
     const bf16_t* __restrict__ A = p.A + z * p.strideA;
@@ -216,7 +227,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    int tm, tn;
+    if (!tile_map(blockIdx.x, (p.M + TBM - 1) / TBM, tiles_n, &tm, &tn)) return;
     const int m0 = tm * TBM, n0 = tn * BN;
     const int64_t z = blockIdx.z;
     const bf16_t* __restrict__ A = p.A + z * p.strideA;
@@ -293,6 +305,45 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         __builtin_amdgcn_s_barrier();
         stage = stage == 2 ? 0 : stage + 1;
     }
+    if (p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0) {
+        // bf16-only output (qkv, fc1: the widest matrices of the encoder): bias + activation in registers, then the wave's
+        // 64x64 tile is transposed through its private 8 KB of LDS so that every store instruction writes 8 full 128-B rows.
+        const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+        bf16_t* Cb = p.Cb + z * p.strideCb;
+        char* tb = smem + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (bias && n + 3 < p.N) {
+                    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+                }
+                const int row = i * 16 + fi, chunk = j * 2 + (fg >> 1);
+                *reinterpret_cast<uint2*>(tb + row * 128 + ((chunk ^ (row & 7)) << 4) + (fg & 1) * 8) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(tb + row * 128 + ((chunk ^ (row & 7)) << 4));
+            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = val;
+        }
+        return;
+    }
     gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
 }
 #define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2))
@@ -318,18 +369,19 @@ const char* launch_gemm(const GemmParams& p, hipStream_t stream) {
     }
     if (p.pool4 && (p.M & 3)) return "gemm: pool4 needs M % 4 == 0";
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
+    auto padded = [](int tiles_m, int tiles_n) { return ((tiles_m + 7) / 8) * 8 * tiles_n; };
+    dim3 grid(padded((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), 1, p.batch > 0 ? p.batch : 1);
     const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     if (direct_ok && tiles256 >= 256 && !p.pool4) {
         // big problems: 256x128 tiles, 8 waves, operands straight into a 3-stage LDS ring
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<4>, dim3(tiles256, 1, grid.z), dim3(512), GS_LDS_256, stream, p);
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<4>, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), GS_LDS_256, stream, p);
     } else if (tiles >= 384) {
         hipLaunchKernelGGL(gemm_bf16_kernel<4>, grid, dim3(256), 4 * TILE_BYTES, stream, p);
     } else {
         // small problems (token-side GEMMs of the decoder): 64x64 tiles give 4x the blocks
         const int tiles64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-        hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(tiles64, 1, grid.z), dim3(256), 2 * TILE_BYTES, stream, p);
+        hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3(padded((p.M + 63) / 64, (p.N + 63) / 64), 1, grid.z), dim3(256), 2 * TILE_BYTES, stream, p);
     }
     return nullptr;
 }
