@@ -118,13 +118,14 @@ def _match_masks(a, b):
     return out
 
 
-@pytest.mark.parametrize("layers", [0, 1])
-def test_amg_parity(engine, image, oracle_large, large_weights, layers):
+@pytest.mark.parametrize("layers,nms", [(0, 1.0), (1, 0.95)])
+def test_amg_parity(engine, image, oracle_large, large_weights, layers, nms):
     from oracle.sam2_ref import ImagePredictorRef
     from oracle.amg_ref import amg_from_saber_cfg
     from saber_amd.engine import make_amg_params, unpack_bits
     cfg, Wnp = large_weights
-    amg = dict(npoints=6, crop_n_layers=layers, box_nms_thresh=0.95, pred_iou_thresh=0.5, stability_score_thresh=0.8)
+    # nms 1.0 disables box suppression (IoU > 1 never holds): every mask that passes the score filters is compared
+    amg = dict(npoints=6, crop_n_layers=layers, box_nms_thresh=nms, pred_iou_thresh=0.5, stability_score_thresh=0.8)
     ref = amg_from_saber_cfg(ImagePredictorRef(Wnp, cfg), amg).generate(np.repeat(image[..., None], 3, 2))
     bits, meta = engine.amg_generate(torch.from_numpy(image).cuda(), make_amg_params(amg), max_masks=512)
     got = unpack_bits(bits, 1024)

@@ -1,0 +1,29 @@
+"""Per-kernel HBM traffic from the two rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KB units).
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of a wide coalesced read stream -> doubled."""
+import csv, json, sys, collections, os
+out, tag = sys.argv[1], sys.argv[2]
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            k = row["Kernel_Name"].split("(")[0]
+            acc[k][0] += 1
+            acc[k][1] += float(row["Counter_Value"])
+    return acc
+fe = load(os.path.join(out, "pmc_fetch", "bench_counter_collection.csv"), "FETCH_SIZE")
+wr = load(os.path.join(out, "pmc_write", "bench_counter_collection.csv"), "WRITE_SIZE")
+summary = {}
+for k in sorted(set(fe) | set(wr)):
+    n = max(fe.get(k, [0, 0])[0], wr.get(k, [0, 0])[0])
+    fetch_b = 2.0 * fe.get(k, [0, 0.0])[1] * 1024.0
+    write_b = wr.get(k, [0, 0.0])[1] * 1024.0
+    summary[k] = {"launches": n, "fetch_bytes_per_launch_corrected": fetch_b / max(1, n), "write_bytes_per_launch": write_b / max(1, n),
+                  "hbm_bytes_per_launch": (fetch_b + write_b) / max(1, n), "hbm_bytes_total": fetch_b + write_b}
+json.dump({"tag": tag, "note": "FETCH_SIZE doubled (gfx950 correction); per launch averages over one bench step", "kernels": summary},
+          open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+tot = sum(v["hbm_bytes_total"] for v in summary.values())
+print(f"total HBM bytes in the profiled step: {tot/1e9:.2f} GB")
+for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["hbm_bytes_total"])[:12]:
+    print(f"{k[:60]:60s} launches {v['launches']:5d}  {v['hbm_bytes_total']/1e9:8.2f} GB  {v['hbm_bytes_per_launch']/1e6:9.2f} MB/launch")
