@@ -341,7 +341,7 @@ const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows
     }
     if (nk % KB != 0) return "hiera_attention: nk must be 16, 64 or a multiple of 128";
     const int nq = q_pool ? nk / 4 : nk;
-    if (nq % 128 == 0) {
+    if (false && nq % 128 == 0) {
         const dim3 grid(n_windows * heads * (nq / 128));
         hipLaunchKernelGGL(hiera_attn_large_kernel<2>, grid, dim3(256), K_LDS_BYTES + V_LDS_BYTES, s, qkv, out, n_windows, nk, heads, q_pool);
     } else if (nq % 64 == 0) {
