@@ -216,52 +216,77 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // WM wave-rows x 2 wave-columns, each wave 64x64: WM = 2 -> 128x128 tile (4 waves), WM = 4 -> 256x128 tile (8 waves,
 // two per SIMD, so one wave's ds_read latency hides under the other's MFMAs).
+// PERSISTENT: the block walks over its tiles (XCD-aware order, stride = gridDim.x) with ONE continuous K-tile stream, so the
+// loads of the next tile's first K-tiles are in flight while the current tile's epilogue stores drain.
 template <int WM>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) {
     constexpr int TBM = WM * 64;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int NW = WM * 2;                 // waves
     constexpr int WI = 16 / NW;                // W wave-instructions per wave per K-tile (A: always 4)
+    constexpr int NLOADS = 4 + WI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* epi_lds = smem + 3 * STAGE;          // NW x 2 KB: per-wave transposition scratch of the bf16 epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    int tm, tn;
-    if (!tile_map(blockIdx.x, (p.M + TBM - 1) / TBM, tiles_n, &tm, &tn)) return;
-    const int m0 = tm * TBM, n0 = tn * BN;
+    const int tiles_m = (p.M + TBM - 1) / TBM, tiles_n = (p.N + BN - 1) / BN;
+    const int padded = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const int64_t z = blockIdx.z;
     const bf16_t* __restrict__ A = p.A + z * p.strideA;
     const bf16_t* __restrict__ W = p.W + z * p.strideW;
     const int fi = lane & 15, fg = lane >> 4;
+    const int nk = (p.K + BK - 1) / BK;
 
-    const bf16_t* asrc[4];
-    const bf16_t* wsrc[WI];
-    int achunk[4], wchunk[WI];
+    int achunk[4], wchunk[WI], arow[4], wrow[WI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        achunk[i] = (lane & 7) ^ ((row >> 1) & 7);      // logical 16-B chunk that lands at physical slot lane&7
-        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda;
+        arow[i] = (wave * 4 + i) * 8 + (lane >> 3);
+        achunk[i] = (lane & 7) ^ ((arow[i] >> 1) & 7);      // logical 16-B chunk that lands at physical slot lane&7
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int row = (wave * WI + i) * 8 + (lane >> 3);
-        wchunk[i] = (lane & 7) ^ ((row >> 1) & 7);
-        wsrc[i] = W + (int64_t)min(n0 + row, p.N - 1) * p.ldw;
+        wrow[i] = (wave * WI + i) * 8 + (lane >> 3);
+        wchunk[i] = (lane & 7) ^ ((wrow[i] >> 1) & 7);
     }
-    auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE;
+    auto next_tile = [&](int L, int* tm, int* tn) {   // first valid tile at or after linear slot L (stride gridDim.x)
+        while (L < padded && !tile_map(L, tiles_m, tiles_n, tm, tn)) L += gridDim.x;
+        return L;
+    };
+
+    // ---- issue cursor
+    int Li, tmi = 0, tni = 0, kti = 0, si = 0;
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[WI];
+    auto set_issue_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asrc[i] = A + (int64_t)min(tmi * TBM + arow[i], p.M - 1) * p.lda;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wsrc[i] = W + (int64_t)min(tni * BN + wrow[i], p.N - 1) * p.ldw;
+    };
+    auto issue = [&]() {   // one K-tile of the issue cursor into ring stage si, then advance the cursor
+        char* sa = smem + si * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = kt * BK + achunk[i] * 8;
+            const int k = kti * BK + achunk[i] * 8;
             const int ka = k < p.K ? k : 0;              // K tail of A: any finite data, W supplies the zeros
             __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + ka), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK + wchunk[i] * 8), (lptr_t)(sa + A_BYTES + (wave * WI + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kti * BK + wchunk[i] * 8), (lptr_t)(sa + A_BYTES + (wave * WI + i) * 1024), 16, 0, 0);
+        si = si == 2 ? 0 : si + 1;
+        if (++kti == nk) {
+            kti = 0;
+            Li = next_tile(Li + gridDim.x, &tmi, &tni);
+            if (Li < padded) set_issue_tile();
+        }
     };
+    Li = next_tile(blockIdx.x, &tmi, &tni);
+    if (Li >= padded) return;                      // block-uniform
+    set_issue_tile();
+    // ---- compute cursor
+    int Lc = Li, tmc = tmi, tnc = tni, ktc = 0, sc = 0;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -269,20 +294,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    issue(0, 0);
-    if (nk > 1) {
-        issue(1, 1);
-        if (WI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    int ahead = 0;                                  // K-tiles issued but not yet computed
+    issue(); ++ahead;
+    if (Li < padded) { issue(); ++ahead; }
+    if (ahead == 2) { if (NLOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 2 < nk;
-        if (more) issue(kt + 2, stage == 0 ? 2 : stage - 1);
-        const char* sa = smem + stage * STAGE;
+    while (Lc < padded) {
+        const bool more = Li < padded;              // a third K-tile can be put in flight
+        if (more) { issue(); ++ahead; }
+        const char* sa = smem + sc * STAGE;
         const char* sw = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -298,56 +319,69 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        // tile kt+1 must have landed (this wave's part) before the barrier; tile kt+2's loads may stay in flight
-        if (more) { if (WI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        --ahead;
+        // the K-tile computed next must have landed (this wave's part) before the barrier; the youngest one may stay in flight.
+        // This wait sits BEFORE the epilogue so that the epilogue's stores (younger in the vmcnt queue) are not waited for.
+        if (ahead == 2) { if (NLOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sc = sc == 2 ? 0 : sc + 1;
+        if (++ktc == nk) {
+            const int m0 = tmc * TBM, n0 = tnc * BN;
+            if (p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0) {
+                // bf16-only output (qkv, fc1: the widest matrices of the encoder): bias + activation in registers, then 16 rows at a
+                // time are transposed through the wave's 2 KB of LDS so that every store instruction writes 8 full 128-B rows.
+                const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+                bf16_t* Cb = p.Cb + z * p.strideCb;
+                char* tb = epi_lds + wave * 2048;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        if (bias && n + 3 < p.N) {
+                            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                        }
+                        if (p.act == ACT_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        } else if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+                        }
+                        const int chunk = j * 2 + (fg >> 1);
+                        *reinterpret_cast<uint2*>(tb + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(tb + row * 128 + ((chunk ^ (row & 7)) << 4));
+                        const int m = m0 + wm * 64 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
+                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = val;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ktc = 0;
+            Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        stage = stage == 2 ? 0 : stage + 1;
     }
-    if (p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0) {
-        // bf16-only output (qkv, fc1: the widest matrices of the encoder): bias + activation in registers, then the wave's
-        // 64x64 tile is transposed through its private 8 KB of LDS so that every store instruction writes 8 full 128-B rows.
-        const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
-        bf16_t* Cb = p.Cb + z * p.strideCb;
-        char* tb = smem + wave * 8192;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fg * 4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (bias && n + 3 < p.N) {
-                    const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (p.act == ACT_SIGMOID) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
-                }
-                const int row = i * 16 + fi, chunk = j * 2 + (fg >> 1);
-                *reinterpret_cast<uint2*>(tb + row * 128 + ((chunk ^ (row & 7)) << 4) + (fg & 1) * 8) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-            }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), chunk = lane & 7;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(tb + row * 128 + ((chunk ^ (row & 7)) << 4));
-            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
-            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = val;
-        }
-        return;
-    }
-    gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
 }
-#define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2))
-#define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2))
+#define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2) + 4 * 2048)
+#define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2) + 8 * 2048)
 
 const char* gemm_init_device() {
     hipError_t st = hipSuccess;
@@ -375,7 +409,10 @@ const char* launch_gemm(const GemmParams& p, hipStream_t stream) {
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     if (direct_ok && tiles256 >= 256 && !p.pool4) {
         // big problems: 256x128 tiles, 8 waves, operands straight into a 3-stage LDS ring
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<4>, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), GS_LDS_256, stream, p);
+        {
+            const int slots = padded((p.M + 255) / 256, (p.N + BN - 1) / BN);
+            hipLaunchKernelGGL(gemm_bf16_glds_kernel<4>, dim3(slots < 256 ? slots : 256, 1, grid.z), dim3(512), GS_LDS_256, stream, p);   // persistent: one block per CU
+        }
     } else if (tiles >= 384) {
         hipLaunchKernelGGL(gemm_bf16_kernel<4>, grid, dim3(256), 4 * TILE_BYTES, stream, p);
     } else {
