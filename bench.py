@@ -78,6 +78,22 @@ def cpu_baseline(cfg, weights, image01, crop_n_layers):
             "seconds_sampled": t_enc + t_first + t_m2m / 3.0}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel class from the latest committed rocprofv3 PMC summary
+    (profiles/*_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        tot = sum(v["hbm_bytes_total"] for n, v in k.items() if "gemm_bf16" in n)
+        cnt = sum(v["launches"] for n, v in k.items() if "gemm_bf16" in n)
+        return {"hbm_bytes_per_launch": tot / max(1, cnt), "source": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -161,8 +177,10 @@ def main():
         g = prof["gemm_bf16"]
         total_ms = sum(v["ms"] for v in prof.values())
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
-                           "kernel": "gemm_bf16_kernel", "launches_per_slice": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(),
+                           "kernel": "gemm_bf16 (gemm_bf16_glds_kernel<4> + gemm_bf16_kernel<T>)", "launches_per_slice": g["launches"],
+                           "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
+                           "algorithmic_gflop_per_launch": g["flops"] / max(1, g["launches"]) / 1e9,
                            "kernel_ms_per_slice": g["ms"], "share_of_kernel_time": g["ms"] / total_ms if total_ms else None}
         out["kernel_classes_ms_per_slice"] = {k: round(v["ms"], 3) for k, v in prof.items()}
         out["kernel_classes_launches"] = {k: v["launches"] for k, v in prof.items()}
