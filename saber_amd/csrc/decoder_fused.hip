@@ -83,26 +83,37 @@ const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, 
 }
 
 // ------------------------------------------------------------------------------------------------ tokens -> image
-#define T2I_KB 64
-#define T2I_LDS (T2I_KB * ROW_B + T2I_KB * VT_STRIDE)
-
-// grid = P * split.  Each block: 64 folded query rows (4 waves x 16) over 4096/split keys of prompt p.
+// grid = P * split, 512 threads.  Each block: 64 folded query rows over 4096/split keys of prompt p, in 64-key blocks.
+//  * score = Qt.(x + pe) is evaluated as [Qt | Qt].[x ; pe] (contraction 512): the positional encoding enters through the
+//    MFMA instead of a VALU add, so BOTH operand tiles are plain copies and go global -> LDS directly
+//    (global_load_lds_dwordx4, 2-stage ring, no staging registers, no ds_write).
+//  * one LDS image of the X tile (XOR-swizzled 512-B rows, source-side swizzle) serves the K operand (ds_read_b128 rows)
+//    and the V operand (ds_read_b64_tr_b16 with the same XOR).
+//  * 8 waves: wave = (key half kh) * 4 + (q tile); each wave keeps its own online-softmax partial over its 32 keys of
+//    every block; the two halves are merged through LDS at the end.  Two waves per SIMD hide each other's LDS latency.
 // Writes un-normalised partial O [P][split][64][256] and (m, l) [P][split][64][2] (log2 domain).
-__global__ __launch_bounds__(256) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
+#define T2I_KB 64
+#define T2I_STAGE (2 * T2I_KB * ROW_B)        // X tile + PE tile
+#define T2I_LDS (2 * T2I_STAGE)
+typedef __attribute__((address_space(1))) const void* gptr_d;
+typedef __attribute__((address_space(3))) void* lptr_d;
+
+__global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
                                                       const bf16_t* __restrict__ Qt, float* __restrict__ Opart, float* __restrict__ ML,
                                                       int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ks_ = smem;
-    char* vs = smem + T2I_KB * ROW_B;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qt = wave & 3, kh = wave >> 2;
     const int fi = lane & 15, fg = lane >> 4;
     const int p = blockIdx.x / split, sp = blockIdx.x - p * split;
     const int nkeys = 4096 / split, key0 = sp * nkeys, nkb = nkeys / T2I_KB;
-    const bf16_t* Xp = X + (int64_t)p * x_bs;
+    const bf16_t* Xp = X + (int64_t)p * x_bs + (int64_t)key0 * DC;
+    const bf16_t* Pp = pe + (int64_t)key0 * DC;
 
     bf16x8 qf[8];
     {
-        const bf16_t* qrow = Qt + ((int64_t)p * 64 + wave * 16 + fi) * DC;
+        const bf16_t* qrow = Qt + ((int64_t)p * 64 + qt * 16 + fi) * DC;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
     }
@@ -111,90 +122,110 @@ __global__ __launch_bounds__(256) void dec_t2i_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int dt = 0; dt < 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    u32x4 rx[8], rp[8];
-    auto gload = [&](int kb) {
+    // this wave's 4 + 4 direct-to-LDS instructions per stage: instruction i covers rows 2i, 2i+1 (1 KB) of a 64-row tile
+    int srow[4], schunk[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            const int64_t off = (int64_t)(key0 + kb * T2I_KB + row) * DC + ch * 8;
-            rx[j] = *reinterpret_cast<const u32x4*>(Xp + off);
-            rp[j] = *reinterpret_cast<const u32x4*>(pe + off);
+    for (int i = 0; i < 4; ++i) {
+        srow[i] = 2 * (wave * 4 + i) + (lane >> 5);
+        schunk[i] = (lane & 31) ^ (srow[i] & 15);          // logical chunk that must land at physical slot lane & 31
+    }
+    auto issue = [&](int kb, int stage) {
+        char* sx = smem + stage * T2I_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t off = (int64_t)(kb * T2I_KB + srow[i]) * DC + schunk[i] * 8;
+            __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_d)(Pp + off), (lptr_d)(sx + T2I_KB * ROW_B + (wave * 4 + i) * 1024), 16, 0, 0);
         }
     };
-    auto lstore = [&]() {
+    // per-lane LDS offsets that do not depend on the block
+    int koff[8];                                        // K-operand fragment of key row (16kt + fi), k-step ks
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            *reinterpret_cast<u32x4*>(ks_ + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
-            *reinterpret_cast<u32x4*>(vs + row * VT_STRIDE + ch * 16) = rx[j];
-        }
-    };
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = fi * ROW_B + (((4 * ks + fg) ^ fi) << 4);
+    const int vrow = 4 * fg + (fi >> 2);                // tr-read row within the 32-key half (+16 for the second read)
+    const int vsel = (fi & 3) >> 1, vlow = (fi & 1) * 8;
 
-    gload(0);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (kb + 1 < nkb) gload(kb + 1);
-        f32x4 s[4];
+        const int stage = kb & 1;
+        if (kb + 1 < nkb) issue(kb + 1, stage ^ 1);
+        const char* xs = smem + stage * T2I_STAGE + kh * 32 * ROW_B;     // this wave's 32 keys
+        const char* ps = xs + T2I_KB * ROW_B;
+        f32x4 s[2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < 2; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int row = 16 * kt + fi;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + kswz(row, 4 * ks + fg));
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                const bf16x8 kx = *reinterpret_cast<const bf16x8*>(xs + kt * 16 * ROW_B + koff[ks]);
+                const bf16x8 kp = *reinterpret_cast<const bf16x8*>(ps + kt * 16 * ROW_B + koff[ks]);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kx, qf[ks], s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kp, qf[ks], s[kt], 0, 0, 0);
             }
         }
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
-        m = mn;
+        if (__any(mx > m)) {        // rescale only when some row's running maximum grows (wave-uniform branch)
+            const float mn = fmaxf(m, mx);
+            const float alpha = exp2f(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[kt][r] - mn);
+                const float e = exp2f(s[kt][r] - m);
                 s[kt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        l = l * alpha + sum;
+        l += sum;
+        const bf16x8 pf = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-        bf16x8 pf[2];
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-            pf[k2] = pack8_d(s[2 * k2][0], s[2 * k2][1], s[2 * k2][2], s[2 * k2][3], s[2 * k2 + 1][0], s[2 * k2 + 1][1], s[2 * k2 + 1][2],
-                             s[2 * k2 + 1][3]);
-#pragma unroll
-        for (int dt = 0; dt < 16; ++dt)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const char* base = vs + (32 * k2 + 4 * fg + (fi >> 2)) * VT_STRIDE + (16 * dt + 4 * (fi & 3)) * 2;
-                const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * VT_STRIDE));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[k2], o[dt], 0, 0, 0);
-            }
+        for (int dt = 0; dt < 16; ++dt) {
+            const int sw = ((2 * dt + vsel) ^ (vrow & 15)) << 4;       // rows vrow and vrow+16 share (row & 15)
+            const char* base = xs + vrow * ROW_B + sw + vlow;
+            const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * ROW_B));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next block landed (this wave's part)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-    const int q = wave * 16 + fi;
-    float* op = Opart + (((int64_t)p * split + sp) * 64 + q) * DC;
+    // merge the two key halves of each q tile: waves 4..7 park (m, l, O) in LDS, waves 0..3 combine and store
+    float* mo = reinterpret_cast<float*>(smem) + (size_t)qt * 16 * 260;      // [16 q][256 + 4] floats per q tile
+    if (kh == 1) {
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) *reinterpret_cast<float4*>(op + 16 * dt + 4 * fg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
-    if (fg == 0) {
-        float* mlp = ML + (((int64_t)p * split + sp) * 64 + q) * 2;
-        mlp[0] = m;
-        mlp[1] = l;
+        for (int dt = 0; dt < 16; ++dt) *reinterpret_cast<float4*>(mo + fi * 260 + 16 * dt + 4 * fg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        if (fg == 0) { mo[fi * 260 + 256] = m; mo[fi * 260 + 257] = l; }
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const float m2 = mo[fi * 260 + 256], l2 = mo[fi * 260 + 257];
+        const float mn = fmaxf(m, m2);
+        const float a1 = exp2f(m - mn), a2 = exp2f(m2 - mn);
+        const int q = qt * 16 + fi;
+        float* op = Opart + (((int64_t)p * split + sp) * 64 + q) * DC;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            const float4 t = *reinterpret_cast<const float4*>(mo + fi * 260 + 16 * dt + 4 * fg);
+            *reinterpret_cast<float4*>(op + 16 * dt + 4 * fg) = make_float4(o[dt][0] * a1 + t.x * a2, o[dt][1] * a1 + t.y * a2, o[dt][2] * a1 + t.z * a2, o[dt][3] * a1 + t.w * a2);
+        }
+        if (fg == 0) {
+            float* mlp = ML + (((int64_t)p * split + sp) * 64 + q) * 2;
+            mlp[0] = mn;
+            mlp[1] = l * a1 + l2 * a2;
+        }
     }
 }
 
@@ -240,7 +271,7 @@ const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
                            const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
     if (P <= 0) return nullptr;
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
-    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(256), T2I_LDS, s, X, x_bs, pe, Qt, Opart, ML, split);
+    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, x_bs, pe, Qt, Opart, ML, split);
     hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
