@@ -44,6 +44,21 @@ int saber_k_mask_post(const float* lowres, int n, int crop_x0, int crop_y0, int 
                       float offset, uint32_t* bits, int32_t* stats, void* stream);
 
 /* engine token order helpers (DESIGN.md "token order") */
+/* Folded image->token attention of the two-way transformer (reference: sam2 TwoWayAttentionBlock.cross_attn_image_to_token +
+ * norm4, called from sam2/modeling/sam/transformer.py via saber/adapters/sam2/automask.py's predictor):
+ * Xout[p][n] = LN(x_n + softmax_heads((x_n + pe_n) Kt_p^T + cb_p) VtT_p^T + bo).  X [P or 1][4096][256] bf16 (x_batch_stride 0 = shared),
+ * pe [4096][256] bf16, Kt [P][64][256] bf16 (8 heads x 8 tokens, log2e/sqrt(d) folded in), cb [P][64], VtT [P][256][64] bf16. */
+int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Kt, const float* cb, const uint16_t* VtT,
+                    const float* bo, const float* gamma, const float* beta, float eps, uint16_t* Xout, int P, void* stream);
+
+/* Folded token->image attention (cross_attn_token_to_image / final_attn_token_to_image): out[p][t] = Wv (sum_n softmax_n(Qt_p[h,t].(x_n+pe_n)) x_n) + bv.
+ * Qt [P][64][256] bf16 (folded queries), part_ws [P*split*64*256] f32, ml_ws [P*split*64*2] f32, out [P][8][256] bf16. */
+int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Qt, float* part_ws, float* ml_ws, int P,
+                    int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream);
+
+/* development hook: bit flags read by experimental kernel variants (0 in production) */
+void saber_k_set_debug(int flags);
+
 int saber_k_perm_index(int y, int x, int stage);
 
 #ifdef __cplusplus

@@ -21,6 +21,7 @@ extern "C" int saber_k_init(int device_id) {
     const char* m = gemm_init_device();
     if (!m) m = hiera_attention_init_device();
     if (!m) m = image_ops_init_device();
+    if (!m) m = decoder_fused_init_device();
     (void)hipGetLastError();
     if (m) return kfail(m);
     return 0;
@@ -66,3 +67,17 @@ extern "C" int saber_k_mask_post(const float* lowres, int n, int crop_x0, int cr
 }
 
 extern "C" int saber_k_perm_index(int y, int x, int stage) { return perm_index(y, x, stage); }
+
+extern "C" int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Kt, const float* cb,
+                               const uint16_t* VtT, const float* bo, const float* gamma, const float* beta, float eps, uint16_t* Xout, int P,
+                               void* stream) {
+    return kcheck(launch_dec_i2t(X, x_batch_stride, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, P, (hipStream_t)stream));
+}
+
+extern "C" int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Qt, float* part_ws, float* ml_ws,
+                               int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream) {
+    return kcheck(launch_dec_t2i(X, x_batch_stride, pe, Qt, part_ws, ml_ws, P, split, Wv, bv, out, (hipStream_t)stream));
+}
+
+int g_saber_debug_flags = 0;
+extern "C" void saber_k_set_debug(int flags) { g_saber_debug_flags = flags; }

@@ -48,7 +48,7 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * ROW_B + (
 
 // ------------------------------------------------------------------------------------------------ fold
 // out[p][8h+t][d] = scale * sum_j a[p][t][16h+j] * W(16h+j, d);  W row-major [128][256] (mode 0: k_proj / q_proj
-// weight) or [256][128] indexed W[d][16h+j] (mode 1: out_proj weight).  cb[p][8h+t] = scale * sum_j a . bias[16h+j].
+// weight, out [p][64][256]) or [256][128] indexed W[d][16h+j] (mode 1: out_proj weight, out TRANSPOSED [p][256][64]).  cb[p][8h+t] = scale * sum_j a . bias[16h+j].
 __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__ a, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                        int mode, float scale, bf16_t* __restrict__ out, float* __restrict__ cb) {
     __shared__ float as[8 * 128];
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc += as[t * 128 + 16 * h + j] * w[j];
-            out[((int64_t)p * 64 + 8 * h + t) * 256 + d] = f2bf(acc * scale);
+            if (mode == 0) out[((int64_t)p * 64 + 8 * h + t) * 256 + d] = f2bf(acc * scale);
+            else out[((int64_t)p * 256 + d) * 64 + 8 * h + t] = f2bf(acc * scale);   // Vt^T: rows = channel d, 64 folded columns
         }
     }
     if (cb && d < 64) {
@@ -97,6 +98,10 @@ const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, 
 #define T2I_LDS (2 * T2I_STAGE)
 typedef __attribute__((address_space(1))) const void* gptr_d;
 typedef __attribute__((address_space(3))) void* lptr_d;
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 
 __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
                                                       const bf16_t* __restrict__ Qt, float* __restrict__ Opart, float* __restrict__ ML,
@@ -277,158 +282,202 @@ const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
 }
 
 // ------------------------------------------------------------------------------------------------ image -> tokens
-#define I2T_ROWS 64
-#define I2T_TILES 8   // row tiles per block (512 rows), folded operands stay in LDS across them
-#define I2T_LDS (64 * ROW_B + 64 * VT_STRIDE + I2T_ROWS * ROW_B + I2T_ROWS * VT_STRIDE)
+// X_out[p][n] = LN(x_n + softmax_heads((x_n + pe_n).Kt + cb).Vt + b_o), one block per prompt, 32-row tiles.
+// Pure streaming kernel: the folded operands of the prompt live in REGISTERS (each wave owns one 16-column slice of Kt
+// for GEMM1 and a 64-channel slice of Vt^T for GEMM2), the X and PE tiles go global -> LDS directly through a 4-stage
+// ring (3 tiles in flight), and (x + pe).Kt is evaluated as x.Kt + pe.Kt inside the MFMA chain (no VALU add).
+// 8 waves: wave = (row tile rt) * 4 + (quarter qr).  Per tile: GEMM1 -> softmax -> P via LDS -> GEMM2 -> residual +
+// LayerNorm (row statistics exchanged through LDS) -> bf16 rows.  Normalisation of tile t is deferred until after the
+// barrier of tile t+1, so each tile costs ONE workgroup barrier.
+#define I2T_ROWS 32
+#define I2T_STAGE (2 * I2T_ROWS * ROW_B)          // X tile + PE tile (16 KB each)
+#define I2T_NSTAGE 4
+#define I2T_PSTRIDE 144                           // bytes per P row (64 bf16 + pad)
+#define I2T_PBUF_B (2 * 16 * I2T_PSTRIDE)           // one P buffer: [2 row tiles][16 rows][144 B]
+#define I2T_STAT_B (2 * 16 * 4 * 2 * 4)             // one statistics buffer: [2 row tiles][16 rows][4 quarters][sum, sumsq]
+#define I2T_LDS (I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B)
 
-// grid = P * (4096 / (I2T_ROWS * I2T_TILES)).  X_out[p][n] = LN(x_n + softmax_heads((x_n + pe_n).Kt + cb).Vt + b_o)
-__global__ __launch_bounds__(256) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
+__global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
                                                       const bf16_t* __restrict__ Kt, const float* __restrict__ cb,
-                                                      const bf16_t* __restrict__ Vt, const float* __restrict__ bo,
+                                                      const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                      bf16_t* __restrict__ Xout) {
+                                                      bf16_t* __restrict__ Xout, int nsplit, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kt_s = smem;                                  // [64 c][256] swizzled   (A operand of GEMM1)
-    char* vt_s = kt_s + 64 * ROW_B;                     // [64 c][256] stride 544 (tr-read source of GEMM2)
-    char* xp_s = vt_s + 64 * VT_STRIDE;                 // [64 rows][256] swizzled: bf16(x + pe)  (B operand of GEMM1)
-    char* x_s = xp_s + I2T_ROWS * ROW_B;                // [64 rows][256] x (residual), padded rows: the 16 rows a wave reads hit different banks
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* pbuf = smem + I2T_NSTAGE * I2T_STAGE;                         // [2 rt][16 rows][144 B]
+    float* stat = reinterpret_cast<float*>(pbuf + 2 * I2T_PBUF_B);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave >> 2, qr = wave & 3;
     const int fi = lane & 15, fg = lane >> 4;
-    const int blocks_per_p = 4096 / (I2T_ROWS * I2T_TILES);
-    const int p = blockIdx.x / blocks_per_p, seg = blockIdx.x - p * blocks_per_p;
-    const bf16_t* Xp = X + (int64_t)p * x_bs;
-    bf16_t* Xo = Xout + (int64_t)p * 4096 * DC;
+    const int p = blockIdx.x / nsplit;
+    const int NT = (4096 / I2T_ROWS) / nsplit;                  // tiles of this block
+    const int64_t row0 = (int64_t)(blockIdx.x % nsplit) * NT * I2T_ROWS;
+    const bf16_t* Xp = X + (int64_t)p * x_bs + row0 * DC;
+    const bf16_t* pep = pe + row0 * DC;
+    bf16_t* Xo = Xout + ((int64_t)p * 4096 + row0) * DC;
 
-    // folded operands of this prompt
+    // folded operands of this prompt, straight into registers
+    bf16x8 kf[8], vf[4][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-        *reinterpret_cast<uint4*>(kt_s + kswz(row, ch)) = *reinterpret_cast<const uint4*>(Kt + ((int64_t)p * 64 + row) * DC + ch * 8);
-        *reinterpret_cast<uint4*>(vt_s + row * VT_STRIDE + ch * 16) = *reinterpret_cast<const uint4*>(Vt + ((int64_t)p * 64 + row) * DC + ch * 8);
+    for (int ks = 0; ks < 8; ++ks)
+        kf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Kt + ((int64_t)p * 64 + 16 * qr + fi) * DC + 32 * ks + 8 * fg));
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            vf[t][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(VtT + ((int64_t)p * 256 + 64 * qr + 16 * t + fi) * 64 + 32 * ks + 8 * fg));
+    const float4 cb4 = *reinterpret_cast<const float4*>(cb + (int64_t)p * 64 + 16 * qr + 4 * fg);
+    float4 bo4[4], g4[4], be4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        bo4[t] = *reinterpret_cast<const float4*>(bo + 64 * qr + 16 * t + 4 * fg);
+        g4[t] = *reinterpret_cast<const float4*>(gamma + 64 * qr + 16 * t + 4 * fg);
+        be4[t] = *reinterpret_cast<const float4*>(beta + 64 * qr + 16 * t + 4 * fg);
     }
-    // per-lane constants: cb for c = 16ct + 4g + r ; bo/gamma/beta for d = 16dt + 4g + r are re-read per tile from L1
-    float cbv[4][4];
+    // direct-to-LDS: per stage 16 X + 16 PE wave-instructions (1 KB = 2 rows each); wave w issues instructions 2w, 2w+1
+    int srow[2], schunk[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const float4 v = *reinterpret_cast<const float4*>(cb + (int64_t)p * 64 + 16 * ct + 4 * fg);
-        cbv[ct][0] = v.x; cbv[ct][1] = v.y; cbv[ct][2] = v.z; cbv[ct][3] = v.w;
+    for (int i = 0; i < 2; ++i) {
+        srow[i] = 2 * (wave * 2 + i) + (lane >> 5);
+        schunk[i] = (lane & 31) ^ (srow[i] & 15);
     }
-
-    u32x4 rx[8];
-    auto gload = [&](int t) {
-        const int row0 = (seg * I2T_TILES + t) * I2T_ROWS;
+    auto issue = [&](int t) {
+        char* sx = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            rx[j] = *reinterpret_cast<const u32x4*>(Xp + (int64_t)(row0 + row) * DC + ch * 8);
+        for (int i = 0; i < 2; ++i) {
+            const int64_t off = (int64_t)(t * I2T_ROWS + srow[i]) * DC + schunk[i] * 8;
+            __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_d)(pep + off), (lptr_d)(sx + I2T_ROWS * ROW_B + (wave * 2 + i) * 1024), 16, 0, 0);
         }
     };
-    gload(0);
-#pragma unroll 1
-    for (int t = 0; t < I2T_TILES; ++t) {
-        u32x4 rp[8];   // positional encoding of this tile: shared by every prompt, L2-resident
+    int xoff[8];      // B-operand fragment of row (16 rt + fi), k-step ks, in the swizzled tile
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            rp[j] = *reinterpret_cast<const u32x4*>(pe + (int64_t)((seg * I2T_TILES + t) * I2T_ROWS + row) * DC + ch * 8);
-        }
-        __syncthreads();  // previous tile consumed (first time: folded operands visible after the 2nd barrier)
+    for (int ks = 0; ks < 8; ++ks) xoff[ks] = (16 * rt + fi) * ROW_B + (((4 * ks + fg) ^ fi) << 4);
+    int roff[4];      // residual: x[m][64 qr + 16 t + 4 fg .. +3]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, ch = idx & 31;
-            *reinterpret_cast<u32x4*>(xp_s + kswz(row, ch)) = add_bf16x8(rx[j], rp[j]);
-            *reinterpret_cast<u32x4*>(x_s + row * VT_STRIDE + ch * 16) = rx[j];
+    for (int t = 0; t < 4; ++t) roff[t] = (16 * rt + fi) * ROW_B + (((8 * qr + 2 * t + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8;
+    // P and the row statistics are double-buffered by tile parity so that one barrier per tile suffices
+    const uint32_t prow_a = (uint32_t)(uintptr_t)(lptr_d)(pbuf + (rt * 16 + fi) * I2T_PSTRIDE);
+    const uint32_t stat_a = (uint32_t)(uintptr_t)(lptr_d)(stat + ((rt * 16 + fi) * 4) * 2);
+    const uint32_t smem_a = (uint32_t)(uintptr_t)(lptr_d)smem;
+    f32x2 g2[8], be2[8], bo2[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        g2[2 * t] = (f32x2){g4[t].x, g4[t].y}; g2[2 * t + 1] = (f32x2){g4[t].z, g4[t].w};
+        be2[2 * t] = (f32x2){be4[t].x, be4[t].y}; be2[2 * t + 1] = (f32x2){be4[t].z, be4[t].w};
+        bo2[2 * t] = (f32x2){bo4[t].x, bo4[t].y}; bo2[2 * t + 1] = (f32x2){bo4[t].z, bo4[t].w};
+    }
+    f32x2 y2[8];                      // y of the previous tile (bias + residual added), normalised one barrier later
+    // normalise + store tile tp from y2 and the exchanged statistics
+    auto finish_tile = [&](int tp) {
+        f32x4 a, b;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(stat_a + (tp & 1) * I2T_STAT_B) : "memory");
+        const float tot = (a.x + a.z) + (b.x + b.z), tsq = (a.y + a.w) + (b.y + b.w);
+        const float mean = tot * (1.0f / DC);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(tsq * (1.0f / DC) - mean * mean, 0.f) + eps);
+        const f32x2 mean2 = (f32x2){mean, mean}, rstd2 = (f32x2){rstd, rstd};
+        bf16_t* orow = Xo + (int64_t)(tp * I2T_ROWS + 16 * rt + fi) * DC + 64 * qr + 4 * fg;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const f32x2 v0 = ((y2[2 * tt] - mean2) * rstd2) * g2[2 * tt] + be2[2 * tt];
+            const f32x2 v1 = ((y2[2 * tt + 1] - mean2) * rstd2) * g2[2 * tt + 1] + be2[2 * tt + 1];
+            *reinterpret_cast<uint2*>(orow + 16 * tt) = make_uint2(pack_bf16(v0.x, v0.y), pack_bf16(v1.x, v1.y));
         }
-        __syncthreads();
-        if (t + 1 < I2T_TILES) gload(t + 1);
-        const int mrow = wave * 16 + fi;  // row of this lane within the tile
+    };
 
-        // GEMM1 (swapped): S^T[c][m] = Kt[c] . xpos[m]
-        f32x4 s[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) s[ct] = (f32x4){cbv[ct][0], cbv[ct][1], cbv[ct][2], cbv[ct][3]};
+    issue(0); issue(1); issue(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < NT; ++t) {
+        const char* xs = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+        const char* ps = xs + I2T_ROWS * ROW_B;
+        // GEMM1 (swapped): S^T[c][m] = Kt[c].x[m] + Kt[c].pe[m] + cb[c] for this wave's 16 columns c
+        f32x4 s = (f32x4){cb4.x, cb4.y, cb4.z, cb4.w}, s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp_s + kswz(mrow, 4 * ks + fg));
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt_s + kswz(16 * ct + fi, 4 * ks + fg));
-                s[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, xf, s[ct], 0, 0, 0);
-            }
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + xoff[ks]);
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(ps + xoff[ks]);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], xf, s, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], pf, s1, 0, 0, 0);
         }
-        // softmax over the 8 tokens of a head: c = 16ct + 4g + r -> head = 2ct + (g >> 1); members: r = 0..3 and lane ^ 16
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            float mx = fmaxf(fmaxf(s[ct][0], s[ct][1]), fmaxf(s[ct][2], s[ct][3]));
+        s += s1;
+        // softmax over the 8 tokens of a head: this lane's 4 values + lane ^ 16
+        {
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[ct][r] = exp2f(s[ct][r] - mx); sum += s[ct][r]; }
+            for (int r = 0; r < 4; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mx); sum += s[r]; }
             sum += __shfl_xor(sum, 16, 64);
             const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[ct][r] *= inv;
+            // LDS stores go through inline asm: a compiler-visible ds_write makes it wait vmcnt(0) for the direct-to-LDS loads in flight
+            lds_write_b64(prow_a + (t & 1) * I2T_PBUF_B + (16 * qr + 4 * fg) * 2, pack_bf16(s[0] * inv, s[1] * inv), pack_bf16(s[2] * inv, s[3] * inv));
         }
-        bf16x8 pf[2];
+        // tile t+1 (issued two iterations ago) must have landed before the barrier makes it visible to everyone; the younger
+        // loads and the bf16 stores stay in flight.  Queue behind L(t+1): [S(t-3)] L(t+2) [S(t-2)], 4 ops per group.
+        if (t + 3 >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (t < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (t == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // the ONE barrier per tile: P(t) and stat(t-1) complete, tile t+1 visible, slot of tile t-1 free
+        if (t + 3 < NT) issue(t + 3);
+        if (t > 0) finish_tile(t - 1);
+        // GEMM2: Y^T[d][m] for this wave's 64 channels
+        f32x4 y[4];
+        {
+            bf16x8 p0, p1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(p0), "=&v"(p1) : "v"(prow_a + (t & 1) * I2T_PBUF_B + 16 * fg) : "memory");
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-            pf[k2] = pack8_d(s[2 * k2][0], s[2 * k2][1], s[2 * k2][2], s[2 * k2][3], s[2 * k2 + 1][0], s[2 * k2 + 1][1], s[2 * k2 + 1][2],
-                             s[2 * k2 + 1][3]);
-        // GEMM2: Y^T[d][m] = Vt^T[d][c] . P^T[c][m]
-        f32x4 y[16];
-#pragma unroll
-        for (int dt = 0; dt < 16; ++dt) {
-            y[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const char* base = vt_s + (32 * k2 + 4 * fg + (fi >> 2)) * VT_STRIDE + (16 * dt + 4 * (fi & 3)) * 2;
-                const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * VT_STRIDE));
-                y[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[k2], y[dt], 0, 0, 0);
+            for (int tt = 0; tt < 4; ++tt) {
+                y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                y[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt][0], p0, y[tt], 0, 0, 0);
+                y[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt][1], p1, y[tt], 0, 0, 0);
             }
         }
-        // residual + LayerNorm over the 256 channels of row m (lane holds d = 16dt + 4g + r; partners: lane ^ 16, ^ 32)
-        float sum = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 16; ++dt) {
-            const uint2 xr = *reinterpret_cast<const uint2*>(x_s + mrow * VT_STRIDE + (16 * dt + 4 * fg) * 2);
-            const float4 b4 = *reinterpret_cast<const float4*>(bo + 16 * dt + 4 * fg);
-            y[dt][0] += __uint_as_float(xr.x << 16) + b4.x;
-            y[dt][1] += __uint_as_float(xr.x & 0xffff0000u) + b4.y;
-            y[dt][2] += __uint_as_float(xr.y << 16) + b4.z;
-            y[dt][3] += __uint_as_float(xr.y & 0xffff0000u) + b4.w;
-            sum += (y[dt][0] + y[dt][1]) + (y[dt][2] + y[dt][3]);
+        // residual + bias, partial LayerNorm statistics over this wave's 64 channels of row m.  The residual reads of the
+        // DMA-written tile also go through inline asm (a visible ds_read of that region again forces vmcnt(0)).
+        uint64_t xr0, xr1, xr2, xr3;
+        {
+            const uint32_t xa = smem_a + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(xr0), "=&v"(xr1), "=&v"(xr2), "=&v"(xr3)
+                         : "v"(xa + roff[0]), "v"(xa + roff[1]), "v"(xa + roff[2]), "v"(xa + roff[3])
+                         : "memory");
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.0f / DC);
-        float var = 0.f;
+        const uint64_t xrs[4] = {xr0, xr1, xr2, xr3};
+        f32x2 sum2 = (f32x2){0.f, 0.f}, sq2 = (f32x2){0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float dlt = y[dt][r] - mean; var += dlt * dlt; }
-        var += __shfl_xor(var, 16, 64);
-        var += __shfl_xor(var, 32, 64);
-        const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / DC) + eps);
-        bf16_t* orow = Xo + (int64_t)((seg * I2T_TILES + t) * I2T_ROWS + mrow) * DC;
-#pragma unroll
-        for (int dt = 0; dt < 16; ++dt) {
-            const float4 g4 = *reinterpret_cast<const float4*>(gamma + 16 * dt + 4 * fg);
-            const float4 e4 = *reinterpret_cast<const float4*>(beta + 16 * dt + 4 * fg);
-            const float v0 = (y[dt][0] - mean) * rstd * g4.x + e4.x, v1 = (y[dt][1] - mean) * rstd * g4.y + e4.y;
-            const float v2 = (y[dt][2] - mean) * rstd * g4.z + e4.z, v3 = (y[dt][3] - mean) * rstd * g4.w + e4.w;
-            *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * fg) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+        for (int tt = 0; tt < 4; ++tt) {
+            const uint32_t xlo = (uint32_t)xrs[tt], xhi = (uint32_t)(xrs[tt] >> 32);
+            const f32x2 r0 = (f32x2){__uint_as_float(xlo << 16), __uint_as_float(xlo & 0xffff0000u)};
+            const f32x2 r1 = (f32x2){__uint_as_float(xhi << 16), __uint_as_float(xhi & 0xffff0000u)};
+            y2[2 * tt] = ((f32x2){y[tt][0], y[tt][1]} + bo2[2 * tt]) + r0;
+            y2[2 * tt + 1] = ((f32x2){y[tt][2], y[tt][3]} + bo2[2 * tt + 1]) + r1;
+            sum2 += y2[2 * tt]; sum2 += y2[2 * tt + 1];
+            sq2 = __builtin_elementwise_fma(y2[2 * tt], y2[2 * tt], sq2);
+            sq2 = __builtin_elementwise_fma(y2[2 * tt + 1], y2[2 * tt + 1], sq2);
         }
+        float sum = sum2.x + sum2.y, sq = sq2.x + sq2.y;
+        sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
+        sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        if (fg == 0) lds_write_b64(stat_a + (t & 1) * I2T_STAT_B + qr * 8, __float_as_uint(sum), __float_as_uint(sq));
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    finish_tile(NT - 1);
 }
 
-const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt,
+const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* VtT,
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s) {
     if (P <= 0) return nullptr;
-    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * (4096 / (I2T_ROWS * I2T_TILES))), dim3(256), I2T_LDS, s, X, x_bs, pe, Kt, cb, Vt, bo, gamma,
-                       beta, eps, Xout);
+    int nsplit = 1;
+    while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's 128 tiles over several blocks
+    extern int g_saber_debug_flags;
+    if (g_saber_debug_flags >> 8) nsplit = g_saber_debug_flags >> 8;
+    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * nsplit), dim3(512), I2T_LDS, s, X, x_bs, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, g_saber_debug_flags & 255);
     return nullptr;
 }
-
 
 // ------------------------------------------------------------------------------------------------ upscaling head
 // Fused output_upscaling + hypernetwork product:

@@ -294,6 +294,18 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias of the bf16 fast path is fetched when a tile STARTS: a global load inside the epilogue would have to wait (vmcnt is
+    // in-order) for the K-tile prefetch and for the stores of the previous rows.
+    const bool fast_bf16 = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0;
+    float4 bias4[4];
+    auto load_bias = [&](int tn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tn * BN + wn * 64 + j * 16 + fg * 4;
+            bias4[j] = (fast_bf16 && p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_bias(tnc);
     int ahead = 0;                                  // K-tiles issued but not yet computed
     issue(); ++ahead;
     if (Li < padded) { issue(); ++ahead; }
@@ -327,22 +339,19 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         sc = sc == 2 ? 0 : sc + 1;
         if (++ktc == nk) {
             const int m0 = tmc * TBM, n0 = tnc * BN;
-            if (p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0) {
+            if (fast_bf16) {
                 // bf16-only output (qkv, fc1: the widest matrices of the encoder): bias + activation in registers, then 16 rows at a
                 // time are transposed through the wave's 2 KB of LDS so that every store instruction writes 8 full 128-B rows.
-                const float* bias = p.bias ? p.bias + z * p.strideBias : nullptr;
                 bf16_t* Cb = p.Cb + z * p.strideCb;
-                char* tb = epi_lds + wave * 2048;
+                const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(epi_lds + wave * 2048);
+                const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // rows 0-7; rows 8-15 are +1024 (same swizzle)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int n = n0 + wn * 64 + j * 16 + fg * 4;
                         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        if (bias && n + 3 < p.N) {
-                            const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                        }
+                        v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
                         if (p.act == ACT_GELU) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -354,17 +363,20 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                             for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
                         }
                         const int chunk = j * 2 + (fg >> 1);
-                        *reinterpret_cast<uint2*>(tb + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                        // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS
+                        // loads in flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous 16 rows.
+                        const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    u32x4 val0, val1;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(val0), "=&v"(val1) : "v"(tb_r0), "v"(tb_r0 + 1024) : "memory");
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         const int row = it * 8 + (lane >> 3), chunk = lane & 7;
-                        const u32x4 val = *reinterpret_cast<const u32x4*>(tb + row * 128 + ((chunk ^ (row & 7)) << 4));
                         const int m = m0 + wm * 64 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
-                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = val;
+                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
             } else {
                 gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             ktc = 0;
             Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
+            if (Lc < padded) load_bias(tnc);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
