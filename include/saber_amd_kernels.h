@@ -23,6 +23,11 @@ int saber_k_init(int device_id);
 int saber_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, const float* res, float* out_f32, uint16_t* out_bf16,
                  int M, int N, int K, int act, int act_last, int pool4, int res_shift, int res_mod, void* stream);
 
+/* Same GEMM with explicit leading dimensions; w_kpad = 1 declares W rows zero-padded to a multiple of 64 in K (ldw >= padded K),
+ * the layout the engine uploads weights in (enables the direct-to-LDS kernel for K = 144, 288). */
+int saber_k_gemm_ld(const uint16_t* A, int lda, const uint16_t* W, int ldw, int w_kpad, const float* bias, const float* res, float* out_f32,
+                    uint16_t* out_bf16, int M, int N, int K, int act, void* stream);
+
 /* nn.LayerNorm over the last dim; fp32 in, fp32 and/or bf16 out. */
 int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,
                       int rows, int C, int act, void* stream);

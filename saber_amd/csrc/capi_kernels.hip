@@ -36,6 +36,14 @@ extern "C" int saber_k_gemm(const uint16_t* A, const uint16_t* W, const float* b
     return kcheck(launch_gemm(p, (hipStream_t)stream));
 }
 
+extern "C" int saber_k_gemm_ld(const uint16_t* A, int lda, const uint16_t* W, int ldw, int w_kpad, const float* bias, const float* res,
+                               float* out_f32, uint16_t* out_bf16, int M, int N, int K, int act, void* stream) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.w_kpad = w_kpad;
+    return kcheck(launch_gemm(p, (hipStream_t)stream));
+}
+
 extern "C" int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,
                                  int rows, int C, int act, void* stream) {
     LayerNormParams p;

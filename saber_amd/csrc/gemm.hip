@@ -339,7 +339,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         sc = sc == 2 ? 0 : sc + 1;
         if (++ktc == nk) {
             const int m0 = tmc * TBM, n0 = tnc * BN;
-            if (fast_bf16) {
+            if (p.dbg & 2) {
+            } else if (fast_bf16) {
                 // bf16-only output (qkv, fc1: the widest matrices of the encoder): bias + activation in registers, then 16 rows at a
                 // time are transposed through the wave's 2 KB of LDS so that every store instruction writes 8 full 128-B rows.
                 bf16_t* Cb = p.Cb + z * p.strideCb;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                     for (int it = 0; it < 2; ++it) {
                         const int row = it * 8 + (lane >> 3), chunk = lane & 7;
                         const int m = m0 + wm * 64 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
-                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
+                        if (m < p.M && n < p.N && !(p.dbg & 1)) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
                     }
                 }
             } else {
@@ -404,7 +405,10 @@ const char* gemm_init_device() {
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
-const char* launch_gemm(const GemmParams& p, hipStream_t stream) {
+extern int g_saber_debug_flags;
+const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.dbg = g_saber_debug_flags;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
     if ((p.K & 7) || (p.lda & 7) || (p.ldw & 7)) return "gemm: K, lda, ldw must be multiples of 8";
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return "gemm: A/W must be 16-byte aligned";

@@ -94,7 +94,8 @@ def test_layernorm(gpu_lib, rows, C, act):
     ob = torch.zeros(rows, C, dtype=torch.int16, device="cuda")
     xd, gd, bd = x.cuda(), gam.cuda(), bet.cuda()
     kcall(gpu_lib, gpu_lib.saber_k_layernorm(ptr(xd), ptr(gd), ptr(bd), 1e-6, ptr(of), ptr(ob), rows, C, act, None))
-    assert (of.cpu().double() - ref).abs().max().item() < 2e-5
+    # act=1: the kernels' GELU is the 9-op fit of the exact erf form (common.h gelu_erf, |error| <= 2.6e-5 absolute)
+    assert (of.cpu().double() - ref).abs().max().item() < (5e-5 if act else 2e-5)
     assert (from_bf(ob).double() - ref).abs().max().item() < 0.03 * ref.abs().max().item()
 
 

@@ -75,3 +75,18 @@ def test_amg_utilities():
     assert near.tolist() == [False, False]
     near = amg_ref.is_box_near_crop_edge(torch.tensor([[100.0, 2, 300, 400]]), [0, 338, 687, 1024], [0, 0, 1024, 1024])
     assert near.tolist() == [True]
+
+
+def test_gelu_fit_matches_exact_erf_gelu():
+    """The kernels' GELU (saber_amd/csrc/common.h gelu_erf, fitted by tools/fit_gelu.py) restated in float32 numpy against
+    the exact erf GELU of the reference (torch.nn.GELU() in sam2 hieradet MLP / mask decoder upscaling)."""
+    import numpy as np
+    from scipy.special import erfc
+    x = np.linspace(-30, 30, 600001).astype(np.float32)
+    x2 = np.minimum(x * x, np.float32(50.0))
+    q = x2 * np.float32(1.01426305e-3) + np.float32(-1.06775724e-1)
+    q = q * x2 + np.float32(-2.30112134)
+    with np.errstate(over="ignore"):
+        got = x / (np.float32(1.0) + np.exp2(x * q))
+    ref = x.astype(np.float64) * 0.5 * erfc(-x.astype(np.float64) / np.sqrt(2.0))
+    assert np.max(np.abs(got - ref)) < 4e-5
