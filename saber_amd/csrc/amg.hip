@@ -108,7 +108,15 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         grids[l].resize(n);
         for (int i = 0; i < n; ++i) grids[l][i] = n == 1 ? off : off + (1.0 - 2.0 * off) * (double)i / (double)(n - 1);
     }
-    const size_t max_pts = (size_t)grid_n[0] * grid_n[0];
+    // crops of one layer that were encoded together are decoded as ONE batch (per-slot feature lookup inside the kernels), so
+    // the work buffers hold the largest such group
+    size_t max_pts = 0;
+    {
+        std::vector<int> per_layer(prm->crop_n_layers + 1, 0);
+        for (int l : layers) per_layer[l]++;
+        for (int l = 0; l <= prm->crop_n_layers; ++l)
+            max_pts = std::max(max_pts, (size_t)std::min(per_layer[l], e->max_images) * grid_n[l] * grid_n[l]);
+    }
     const size_t max_prompts = max_pts * M;
     if (e->amg_prompts_cap < max_prompts) {
         TRY(eng_alloc(e, &e->amg_pts, max_pts * 2));
@@ -158,43 +166,52 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         std::vector<int> cb(4 * ncb);
         for (int i = 0; i < ncb; ++i) for (int k = 0; k < 4; ++k) cb[4 * i + k] = crops[c0 + i][k];
         TRY(eng_encode(e, img_dev, H, W, channels, cb.data(), ncb, 0, s));
-        for (int ci = 0; ci < ncb; ++ci) {
-            const auto& box = crops[c0 + ci];
+        for (int ci = 0, G = 1; ci < ncb; ci += G) {
             const int layer = layers[c0 + ci];
-            const int cw = box[2] - box[0], chh = box[3] - box[1];
+            for (G = 1; ci + G < ncb && layers[c0 + ci + G] == layer; ++G) {}
             const int gn = grid_n[layer];
-            const int np = gn * gn;
-            h_pts.resize((size_t)np * 2);
-            std::vector<float> crop_pts((size_t)np * 2);
-            for (int iy = 0; iy < gn; ++iy)
-                for (int ix = 0; ix < gn; ++ix) {
-                    const float px = (float)(grids[layer][ix] * (double)cw), py = (float)(grids[layer][iy] * (double)chh);
-                    const size_t k = (size_t)iy * gn + ix;
-                    crop_pts[2 * k] = px; crop_pts[2 * k + 1] = py;
-                    h_pts[2 * k] = (px / (float)cw) * 1024.0f;
-                    h_pts[2 * k + 1] = (py / (float)chh) * 1024.0f;
-                }
-            ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * np, hipMemcpyHostToDevice, s));
-            TRY(eng_decode(e, ci, e->amg_pts, nullptr, np, prm->multimask_output, nullptr, e->amg_low1, e->amg_iou1, nullptr, s));
-            const int nm = np * M;
+            const int np = gn * gn;                 // points per crop
+            const int nm = np * M;                  // masks per crop
+            h_pts.resize((size_t)G * np * 2);
+            std::vector<float> crop_pts_all((size_t)G * np * 2);
+            for (int g = 0; g < G; ++g) {
+                const auto& box = crops[c0 + ci + g];
+                const int cw = box[2] - box[0], chh = box[3] - box[1];
+                for (int iy = 0; iy < gn; ++iy)
+                    for (int ix = 0; ix < gn; ++ix) {
+                        const float px = (float)(grids[layer][ix] * (double)cw), py = (float)(grids[layer][iy] * (double)chh);
+                        const size_t k = (size_t)g * np + (size_t)iy * gn + ix;
+                        crop_pts_all[2 * k] = px; crop_pts_all[2 * k + 1] = py;
+                        h_pts[2 * k] = (px / (float)cw) * 1024.0f;
+                        h_pts[2 * k + 1] = (py / (float)chh) * 1024.0f;
+                    }
+            }
+            ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * G * np, hipMemcpyHostToDevice, s));
+            TRY(eng_decode(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, e->amg_low1, e->amg_iou1, nullptr, s));
             const float* masks = e->amg_low1;
             const float* ious = e->amg_iou1;
             if (prm->use_m2m) {
-                hipLaunchKernelGGL(clamp_kernel, dim3(2048), dim3(256), 0, s, e->amg_low1, (int64_t)nm * 65536, -32.0f, 32.0f);
-                h_pts2.resize((size_t)nm * 2);
-                for (int k = 0; k < np; ++k)
-                    for (int m = 0; m < M; ++m) { h_pts2[2 * ((size_t)k * M + m)] = h_pts[2 * k]; h_pts2[2 * ((size_t)k * M + m) + 1] = h_pts[2 * k + 1]; }
-                ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * nm, hipMemcpyHostToDevice, s));
-                TRY(eng_decode(e, ci, e->amg_pts2, nullptr, nm, 0, e->amg_low1, e->amg_low2, e->amg_iou2, nullptr, s));
+                hipLaunchKernelGGL(clamp_kernel, dim3(2048), dim3(256), 0, s, e->amg_low1, (int64_t)G * nm * 65536, -32.0f, 32.0f);
+                h_pts2.resize((size_t)G * nm * 2);
+                for (size_t k = 0; k < (size_t)G * np; ++k)
+                    for (int m = 0; m < M; ++m) { h_pts2[2 * (k * M + m)] = h_pts[2 * k]; h_pts2[2 * (k * M + m) + 1] = h_pts[2 * k + 1]; }
+                ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * G * nm, hipMemcpyHostToDevice, s));
+                TRY(eng_decode(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, e->amg_low2, e->amg_iou2, nullptr, s));
                 masks = e->amg_low2;
                 ious = e->amg_iou2;
             }
-            h_iou.resize(nm);
-            ENG_HIP(e, hipMemcpyAsync(h_iou.data(), ious, sizeof(float) * nm, hipMemcpyDeviceToHost, s));
+            std::vector<float> h_iou_all((size_t)G * nm);
+            ENG_HIP(e, hipMemcpyAsync(h_iou_all.data(), ious, sizeof(float) * G * nm, hipMemcpyDeviceToHost, s));
             ENG_HIP(e, hipStreamSynchronize(s));
+          for (int g = 0; g < G; ++g) {            // per-crop filtering and NMS, exactly as for unbatched crops
+            const auto& box = crops[c0 + ci + g];
+            const int cw = box[2] - box[0], chh = box[3] - box[1];
+            const float* crop_pts = crop_pts_all.data() + (size_t)g * np * 2;
+            const int kbase = g * nm;              // first mask of this crop in the group buffers
+            h_iou.assign(h_iou_all.begin() + kbase, h_iou_all.begin() + kbase + nm);
             h_idx.clear();
             for (int k = 0; k < nm; ++k)
-                if (!(prm->pred_iou_thresh > 0.0f) || h_iou[k] > prm->pred_iou_thresh) h_idx.push_back(k);
+                if (!(prm->pred_iou_thresh > 0.0f) || h_iou[k] > prm->pred_iou_thresh) h_idx.push_back(kbase + k);
             const int ns = (int)h_idx.size();
             if (ns == 0) continue;
             TRY(crop_reserve((size_t)ns));
@@ -223,7 +240,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                     near = near || (nc_ && !ni);
                 }
                 if (near) continue;
-                const int src = h_idx[k];
+                const int src = h_idx[k] - kbase;
                 cd.iou = h_iou[src];
                 cd.stab = stab;
                 const int pk = src / M;
@@ -247,6 +264,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                 cd.bits_slot = acc_used++;
                 all.push_back(cd);
             }
+          }
         }
     }
     std::vector<int> final_order(all.size());

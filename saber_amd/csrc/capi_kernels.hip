@@ -79,12 +79,12 @@ extern "C" int saber_k_perm_index(int y, int x, int stage) { return perm_index(y
 extern "C" int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Kt, const float* cb,
                                const uint16_t* VtT, const float* bo, const float* gamma, const float* beta, float eps, uint16_t* Xout, int P,
                                void* stream) {
-    return kcheck(launch_dec_i2t(X, x_batch_stride, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, P, (hipStream_t)stream));
+    return kcheck(launch_dec_i2t(X, XMap{x_batch_stride, 1, 0}, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, P, (hipStream_t)stream));
 }
 
 extern "C" int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Qt, float* part_ws, float* ml_ws,
                                int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream) {
-    return kcheck(launch_dec_t2i(X, x_batch_stride, pe, Qt, part_ws, ml_ws, P, split, Wv, bv, out, (hipStream_t)stream));
+    return kcheck(launch_dec_t2i(X, XMap{x_batch_stride, 1, 0}, pe, Qt, part_ws, ml_ws, P, split, Wv, bv, out, (hipStream_t)stream));
 }
 
 int g_saber_debug_flags = 0;

@@ -103,9 +103,9 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-__global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
-                                                      const bf16_t* __restrict__ Qt, float* __restrict__ Opart, float* __restrict__ ML,
-                                                      int split) {
+__global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
+                                                      const bf16_t* __restrict__ pe, const bf16_t* __restrict__ Qt,
+                                                      float* __restrict__ Opart, float* __restrict__ ML, int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
     const int fi = lane & 15, fg = lane >> 4;
     const int p = blockIdx.x / split, sp = blockIdx.x - p * split;
     const int nkeys = 4096 / split, key0 = sp * nkeys, nkb = nkeys / T2I_KB;
-    const bf16_t* Xp = X + (int64_t)p * x_bs + (int64_t)key0 * DC;
+    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs + (int64_t)key0 * DC;   // image tokens of prompt p (see kernels.h XMap)
     const bf16_t* Pp = pe + (int64_t)key0 * DC;
 
     bf16x8 qf[8];
@@ -272,11 +272,12 @@ __global__ __launch_bounds__(256) void dec_t2i_finish_kernel(const float* __rest
     }
 }
 
-const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
+const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
                            const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
     if (P <= 0) return nullptr;
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
-    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, x_bs, pe, Qt, Opart, ML, split);
+    if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
+    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, xm.stride, xm.div, xm.off, pe, Qt, Opart, ML, split);
     hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
@@ -297,7 +298,7 @@ const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, cons
 #define I2T_STAT_B (2 * 16 * 4 * 2 * 4)             // one statistics buffer: [2 row tiles][16 rows][4 quarters][sum, sumsq]
 #define I2T_LDS (I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B)
 
-__global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, const bf16_t* __restrict__ pe,
+__global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ pe,
                                                       const bf16_t* __restrict__ Kt, const float* __restrict__ cb,
                                                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
     const int p = blockIdx.x / nsplit;
     const int NT = (4096 / I2T_ROWS) / nsplit;                  // tiles of this block
     const int64_t row0 = (int64_t)(blockIdx.x % nsplit) * NT * I2T_ROWS;
-    const bf16_t* Xp = X + (int64_t)p * x_bs + row0 * DC;
+    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs + row0 * DC;
     const bf16_t* pep = pe + row0 * DC;
     bf16_t* Xo = Xout + ((int64_t)p * 4096 + row0) * DC;
 
@@ -468,14 +469,15 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
     finish_tile(NT - 1);
 }
 
-const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* VtT,
+const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* VtT,
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s) {
     if (P <= 0) return nullptr;
     int nsplit = 1;
     while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's 128 tiles over several blocks
     extern int g_saber_debug_flags;
     if (g_saber_debug_flags >> 8) nsplit = g_saber_debug_flags >> 8;
-    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * nsplit), dim3(512), I2T_LDS, s, X, x_bs, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, g_saber_debug_flags & 255);
+    if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
+    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * nsplit), dim3(512), I2T_LDS, s, X, xm.stride, xm.div, xm.off, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, g_saber_debug_flags & 255);
     return nullptr;
 }
 
@@ -500,7 +502,7 @@ __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + (
 __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
-                                                          const float* __restrict__ fs1, const float* __restrict__ fs0,
+                                                          const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
                                                           const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
@@ -532,18 +534,28 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
     for (int ni = 0; ni < 4; ++ni) {
         gg[ni] = *reinterpret_cast<const float4*>(ln_g + ni * 16 + 4 * fg);
         be[ni] = *reinterpret_cast<const float4*>(ln_b + ni * 16 + 4 * fg);
-        const float4 r = *reinterpret_cast<const float4*>(fs1 + ((int64_t)tok * 4 + pos) * 64 + ni * 16 + 4 * fg);
-        const float4 b = *reinterpret_cast<const float4*>(b1 + pos * 64 + ni * 16 + 4 * fg);
-        f1[ni] = make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
     }
+    // the high-resolution features belong to the crop (slot) of the prompt: prompts of one slot are contiguous, so a block
+    // re-reads them only when its prompt sequence crosses into the next slot
+    int cur_slot = -1;
+    auto load_feats = [&](int slot) {
+        const float* s1 = fs1 + (int64_t)slot * 16384 * 64;
+        const float* s0 = fs0 + (int64_t)slot * 65536 * 32;
 #pragma unroll
-    for (int pos2 = 0; pos2 < 4; ++pos2)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const float4 r = *reinterpret_cast<const float4*>(fs0 + (((int64_t)tok * 4 + pos) * 4 + pos2) * 32 + hh * 16 + 4 * fg);
-            const float4 b = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
-            f0[pos2][hh] = make_uint2(pack_bf16(r.x + b.x, r.y + b.y), pack_bf16(r.z + b.z, r.w + b.w));
+        for (int ni = 0; ni < 4; ++ni) {
+            const float4 r = *reinterpret_cast<const float4*>(s1 + ((int64_t)tok * 4 + pos) * 64 + ni * 16 + 4 * fg);
+            const float4 b = *reinterpret_cast<const float4*>(b1 + pos * 64 + ni * 16 + 4 * fg);
+            f1[ni] = make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
         }
+#pragma unroll
+        for (int pos2 = 0; pos2 < 4; ++pos2)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float4 r = *reinterpret_cast<const float4*>(s0 + (((int64_t)tok * 4 + pos) * 4 + pos2) * 32 + hh * 16 + 4 * fg);
+                const float4 b = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
+                f0[pos2][hh] = make_uint2(pack_bf16(r.x + b.x, r.y + b.y), pack_bf16(r.z + b.z, r.w + b.w));
+            }
+    };
     const int dy1 = pos >> 1, dx1 = pos & 1;
     const int ty = (tl >> 1) & 1, tx = ((tl >> 2) & 7) * 2 + (tl & 1);
     int ty0, tx0;
@@ -568,6 +580,10 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         }
         __syncthreads();
         if (p + groups < P) xload(p + groups);
+        {
+            const int slot = (p + s_off) / s_div;     // block-uniform
+            if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
+        }
         float4 hy[2][4];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
@@ -666,10 +682,12 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
 }
 
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
-                               const float* b2, const float* fs1, const float* fs0, const float* hyper, float* masks4, int P, hipStream_t s) {
+                               const float* b2, const float* fs1, const float* fs0, XMap sm, const float* hyper, float* masks4, int P,
+                               hipStream_t s) {
     if (P <= 0) return nullptr;
+    if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
     const int groups = P >= 2 ? 2 : 1;   // 128 tiles x 2 groups = one resident block per CU
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, hyper, masks4, P, groups);
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups);
     return nullptr;
 }
 

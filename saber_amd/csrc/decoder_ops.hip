@@ -43,12 +43,13 @@ const char* launch_prompt_tokens(const float* pts, const int* labels, int P, Pro
 // token computes the 16-channel hidden vector from its 4x4 logit patch; phase 2, thread d produces channel d
 // of every token (coalesced 512-B rows).
 __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
-                                                             const float* __restrict__ image_embed, const float* __restrict__ pos,
+                                                             const float* __restrict__ image_embed_base, XMap em, const float* __restrict__ pos,
                                                              MaskEmbedWeights w, float* __restrict__ src_f,
                                                              bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf) {
     __shared__ float h2s[64][17];
     const int tid = threadIdx.x;
     const int p = blockIdx.x >> 6, tok0 = (blockIdx.x & 63) * 64;
+    const float* image_embed = image_embed_base + (int64_t)((p + em.off) / em.div) * em.stride;
     if (tid < 64) {
         const int tok = tok0 + tid;
         int ty, tx;
@@ -123,10 +124,11 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
     }
 }
 
-const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, const float* pos, MaskEmbedWeights w,
+const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap em, const float* pos, MaskEmbedWeights w,
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s) {
     if (P <= 0) return nullptr;
-    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(P * 64), dim3(256), 0, s, mask_in, P, image_embed, pos, w, src_f, src_bf, srcpos_bf);
+    if (em.div <= 0) return "mask_embed_src: XMap.div must be positive";
+    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(P * 64), dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf);
     return nullptr;
 }
 

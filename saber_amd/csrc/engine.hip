@@ -663,23 +663,30 @@ static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
     return SABER_OK;
 }
 
-static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* labels, int P, int multimask, const float* mask_in,
-                        float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+// One chunk of P prompts.  The prompts may span several consecutive slots (crops of one AMG layer batched together): prompt p of
+// the chunk reads the features of slot slot0 + (p_base + p) / per_slot.
+static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, int multimask,
+                        const float* mask_in, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
     const int T = 8;
     const int PT = P * T;
-    const size_t o256 = (size_t)slot * 4096 * 256;
+    const size_t o256 = (size_t)slot0 * 4096 * 256;
     const bool shared = (mask_in == nullptr);
+    const int slot_last = slot0 + (p_base + P - 1) / per_slot;
+    const XMap slots{(int64_t)4096 * 256, per_slot, p_base};          // per-slot tensors of 4096 x 256 elements
+    const XMap per_prompt{(int64_t)4096 * 256, 1, 0};
     const float kScale = 0.25f * 1.4426950408889634f;  // head_dim 16 ^ -0.5 * log2(e): scores live in the exp2 domain
     int split = 1;
     while (split < 8 && P * split < 512) split *= 2;
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
     ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
     const bf16_t* X;      // image tokens of each prompt, bf16 [4096][256], engine order
-    int64_t x_bs;
-    if (shared) { TRY(ensure_shared(e, slot, s)); X = e->src0_bf + o256; x_bs = 0; }
-    else {
-        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, s));
-        X = e->keys_bf; x_bs = (int64_t)4096 * 256;
+    XMap xm;
+    if (shared) {
+        for (int sl = slot0 + p_base / per_slot; sl <= slot_last; ++sl) TRY(ensure_shared(e, sl, s));
+        X = e->src0_bf + o256; xm = slots;
+    } else {
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, slots, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, s));
+        X = e->keys_bf; xm = per_prompt;
     }
 
     // tokens -> image: fold q into 64 rows of dimension 256, stream X once (dec_t2i), un-fold with v_proj
@@ -689,7 +696,7 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
         g.Cf = e->tq; g.ldcf = 128;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tq, a.k.w, nullptr, 0, kScale, e->fold_q, nullptr, P, s));
-        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, x_bs, e->dense_pe_bf, e->fold_q, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
+        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, e->dense_pe_bf, e->fold_q, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
         g = mk_gemm(e->t_att, 128, PT, a.o);
         g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
@@ -726,8 +733,8 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
         g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tk, w.i2t.q.w, w.i2t.q.b, 0, kScale, e->fold_k, e->fold_cb, P, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tv, w.i2t.o.w, nullptr, 1, 1.0f, e->fold_v, nullptr, P, s));
-        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, x_bs, e->dense_pe_bf, e->fold_k, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
-        X = e->keys_bf; x_bs = (int64_t)4096 * 256;
+        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, e->dense_pe_bf, e->fold_k, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
+        X = e->keys_bf; xm = per_prompt;
     }
     TRY(t2i(e->final_attn, e->final_ln));
 
@@ -757,23 +764,26 @@ static int decode_chunk(saber_engine* e, int slot, const float* pts, const int* 
     }
     // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
-           launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot * 16384 * 64,
-                              e->fs0 + (size_t)slot * 65536 * 32, e->hyper_out, e->masks4, P, s));
+           launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot0 * 16384 * 64,
+                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, e->masks4, P, s));
     float* om = out_lowres ? out_lowres : e->dec_out_masks;
     float* oi = out_iou ? out_iou : e->dec_out_iou;
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
     return SABER_OK;
 }
 
-int eng_decode(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask, const float* mask_in_dev,
-               float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
+               const float* mask_in_dev, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
-    if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot]) return eng_fail(e, SABER_ERR_STATE, "decode: slot holds no encoded image; call saber_encode first");
-    if (!pts_dev || n < 0) return eng_fail(e, SABER_ERR_INVALID, "decode: bad argument");
+    if (!pts_dev || n < 0 || per_slot < 0) return eng_fail(e, SABER_ERR_INVALID, "decode: bad argument");
+    if (per_slot == 0 || per_slot > n) per_slot = n > 0 ? n : 1;      // every prompt reads slot `slot`
+    const int nslots = n > 0 ? (n + per_slot - 1) / per_slot : 1;
+    for (int sl = slot; sl < slot + nslots; ++sl)
+        if (sl < 0 || sl >= e->max_images || !e->slot_valid[sl]) return eng_fail(e, SABER_ERR_STATE, "decode: slot holds no encoded image; call saber_encode first");
     const int M = multimask ? 3 : 1;
     for (int p0 = 0; p0 < n; p0 += e->max_prompts) {
         const int P = std::min(e->max_prompts, n - p0);
-        TRY(decode_chunk(e, slot, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
+        TRY(decode_chunk(e, slot, per_slot, p0, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
                          mask_in_dev ? mask_in_dev + (size_t)p0 * 65536 : nullptr,
                          out_lowres ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
                          out_obj ? out_obj + p0 : nullptr, s));
@@ -786,7 +796,7 @@ extern "C" int saber_decode_points(saber_engine* e, int slot, const float* pts_d
                                    const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream) {
     if (!e) return SABER_ERR_INVALID;
     ENG_HIP(e, hipSetDevice(e->device));
-    return eng_decode(e, slot, pts_dev, labels_dev, n, multimask, mask_in_dev, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
+    return eng_decode(e, slot, 0, pts_dev, labels_dev, n, multimask, mask_in_dev, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ label plane

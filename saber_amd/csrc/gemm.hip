@@ -270,11 +270,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         for (int i = 0; i < 4; ++i) {
             const int k = kti * BK + achunk[i] * 8;
             const int ka = k < p.K ? k : 0;              // K tail of A: any finite data, W supplies the zeros
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + ka), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+            if (!(p.dbg & 4)) __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + ka), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kti * BK + wchunk[i] * 8), (lptr_t)(sa + A_BYTES + (wave * WI + i) * 1024), 16, 0, 0);
+            if (!(p.dbg & 8)) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kti * BK + wchunk[i] * 8), (lptr_t)(sa + A_BYTES + (wave * WI + i) * 1024), 16, 0, 0);
         si = si == 2 ? 0 : si + 1;
         if (++kti == nk) {
             kti = 0;

@@ -71,7 +71,11 @@ struct MaskEmbedWeights {
     const float *w3, *b3;              // conv 16->256 1x1 [256][16]
 };
 // src[p][tok] = image_embed[tok] + mask_downscaling(mask_in[p]) (token order = engine order on the 64x64 grid)
-const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, const float* pos, MaskEmbedWeights w,
+// Which image a prompt reads: prompt p of a launch uses the tensor at base + ((p + off) / div) * stride.
+// One tensor per prompt: {stride, 1, 0}; one tensor shared by every prompt: {0, 1, 0}; several crops batched into one
+// launch, `div` consecutive prompts per crop (slot): {slot stride, div, index of the launch's first prompt within the batch}.
+struct XMap { int64_t stride; int div; int off; };
+const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap emb_map, const float* pos, MaskEmbedWeights w,
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s);
 
 // fp32 multi-head attention for the two-way transformer.  q [B][nq][heads*hd], k/v [B or 1][nk][heads*hd].
@@ -87,12 +91,13 @@ const char* launch_mask_select(const float* masks4, const float* iou4, int P, in
 
 // ------------------------------------------------------------------ decoder_fused.hip
 const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, int mode, float scale, bf16_t* out, float* cb, int P, hipStream_t s);
-const char* launch_dec_t2i(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
+const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
                            const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
-const char* launch_dec_i2t(const bf16_t* X, int64_t x_bs, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt, const float* bo,
+const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt, const float* bo,
                            const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s);
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
-                               const float* b2, const float* fs1, const float* fs0, const float* hyper, float* masks4, int P, hipStream_t s);
+                               const float* b2, const float* fs1, const float* fs0, XMap slot_map, const float* hyper, float* masks4, int P,
+                               hipStream_t s);
 const char* decoder_fused_init_device();
 
 // K8: bilinear upsample of 256x256 logits to the crop, threshold / stability counts / bbox / bit-packing.
