@@ -297,15 +297,33 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
     // bias of the bf16 fast path is fetched when a tile STARTS: a global load inside the epilogue would have to wait (vmcnt is
     // in-order) for the K-tile prefetch and for the stores of the previous rows.
     const bool fast_bf16 = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0;
+    // fp32 output (+ fp32 residual): proj / fc2 of every block.  The residual tile is fetched into registers right before the
+    // LAST K-tile of the output tile is computed (older in the vmcnt queue than that iteration's prefetch, so the counted wait
+    // that precedes the epilogue covers it) instead of 16 dependent load -> wait -> add -> store round trips.
+    const bool fast_f32 = p.Cf && !p.Cb && !p.pool4 && p.act == ACT_NONE && (p.N & 3) == 0 && (p.ldcf & 3) == 0 &&
+                          (!p.res || (p.res_shift == 0 && p.res_mod == 0 && (p.ldres & 3) == 0));
     float4 bias4[4];
     auto load_bias = [&](int tn) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = tn * BN + wn * 64 + j * 16 + fg * 4;
-            bias4[j] = (fast_bf16 && p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bias4[j] = ((fast_bf16 || fast_f32) && p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     load_bias(tnc);
+    float4 rres[4][4];
+    auto load_res = [&](int tm, int tn) {
+        const float* res = p.res + z * p.strideRes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(tm * TBM + wm * 64 + i * 16 + fi, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = min(tn * BN + wn * 64 + j * 16 + fg * 4, p.N - 4);     // clamped lanes are never stored
+                rres[i][j] = *reinterpret_cast<const float4*>(res + (int64_t)m * p.ldres + n);
+            }
+        }
+    };
     int ahead = 0;                                  // K-tiles issued but not yet computed
     issue(); ++ahead;
     if (Li < padded) { issue(); ++ahead; }
@@ -314,6 +332,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
     __builtin_amdgcn_s_barrier();
     while (Lc < padded) {
         const bool more = Li < padded;              // a third K-tile can be put in flight
+        if (fast_f32 && p.res && ktc == nk - 1) load_res(tmc, tnc);
         if (more) { issue(); ++ahead; }
         const char* sa = smem + sc * STAGE;
         const char* sw = sa + A_BYTES;
@@ -377,6 +396,19 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                         const int row = it * 8 + (lane >> 3), chunk = lane & 7;
                         const int m = m0 + wm * 64 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
                         if (m < p.M && n < p.N && !(p.dbg & 1)) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
+                    }
+                }
+            } else if (fast_f32) {
+                float* Cf = p.Cf + z * p.strideCf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + wm * 64 + i * 16 + fi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                        float4 v = make_float4(acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w);
+                        if (p.res) { v.x += rres[i][j].x; v.y += rres[i][j].y; v.z += rres[i][j].z; v.w += rres[i][j].w; }
+                        if (m < p.M && n + 3 < p.N) *reinterpret_cast<float4*>(Cf + (int64_t)m * p.ldcf + n) = v;
                     }
                 }
             } else {

@@ -6,6 +6,7 @@ from saber_amd import _lib
 lib = _lib.load(); assert lib.saber_k_init(0) == 0
 def ptr(t): return C.c_void_p(t.data_ptr())
 ACT = int(os.environ.get('ACT', '0'))
+RES = int(os.environ.get('RES', '0'))   # 1: fp32 output with fp32 residual (proj / fc2 of a Hiera block)
 if os.environ.get('DBG'): lib.saber_k_set_debug(int(os.environ['DBG'], 0))
 shapes = [(32768, 1728, 576), (32768, 576, 576), (32768, 2304, 576), (32768, 576, 2304), (131072, 864, 288), (131072, 1152, 288), (131072, 288, 1152),
           (524288, 432, 144), (524288, 576, 144), (524288, 144, 576), (8192, 3456, 1152), (8192, 4608, 1152), (8192, 1152, 4608), (8192, 256, 256), (4096, 4096, 4096), (8192, 8192, 8192)]
@@ -14,11 +15,12 @@ for M, N, K in shapes:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); W = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
     W[:, :K] = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for _ in range(3): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), None, None, ptr(out), M, N, K, ACT, None)
+    outf = torch.empty(M, N, device="cuda") if RES else None; res = torch.randn(M, N, device="cuda") if RES else None
+    for _ in range(3): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, None)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), None, None, ptr(out), M, N, K, ACT, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for _ in range(10): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f"M={M:7d} N={N:5d} K={K:5d}  {ms*1e3:9.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s", flush=True)
