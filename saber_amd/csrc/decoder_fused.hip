@@ -51,22 +51,37 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * ROW_B + (
 // weight, out [p][64][256]) or [256][128] indexed W[d][16h+j] (mode 1: out_proj weight, out TRANSPOSED [p][256][64]).  cb[p][8h+t] = scale * sum_j a . bias[16h+j].
 __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__ a, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                        int mode, float scale, bf16_t* __restrict__ out, float* __restrict__ cb) {
-    __shared__ float as[8 * 128];
+    __shared__ __attribute__((aligned(16))) float as[8 * 128];
     const int p = blockIdx.x, d = threadIdx.x;
-    for (int i = d; i < 8 * 128; i += 256) as[i] = a[(int64_t)p * 1024 + i];
+    reinterpret_cast<float4*>(as)[d] = reinterpret_cast<const float4*>(a + (int64_t)p * 1024)[d];
     __syncthreads();
     for (int h = 0; h < 8; ++h) {
         float w[16];
+        if (mode == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = mode == 0 ? bf2f(W[(16 * h + j) * 256 + d]) : bf2f(W[d * 128 + 16 * h + j]);
+            for (int j = 0; j < 16; ++j) w[j] = bf2f(W[(16 * h + j) * 256 + d]);
+        } else {        // thread d owns row d of W: 32 contiguous bytes per head
+            const uint4 w0 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h), w1 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h + 8);
+            const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { w[2 * j] = __uint_as_float(ww[j] << 16); w[2 * j + 1] = __uint_as_float(ww[j] & 0xffff0000u); }
+        }
+        float r[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc += as[t * 128 + 16 * h + j] * w[j];
-            if (mode == 0) out[((int64_t)p * 64 + 8 * h + t) * 256 + d] = f2bf(acc * scale);
-            else out[((int64_t)p * 256 + d) * 64 + 8 * h + t] = f2bf(acc * scale);   // Vt^T: rows = channel d, 64 folded columns
+            for (int j4 = 0; j4 < 4; ++j4) {       // broadcast reads, 16 bytes at a time
+                const float4 av = *reinterpret_cast<const float4*>(as + t * 128 + 16 * h + 4 * j4);
+                acc += av.x * w[4 * j4] + av.y * w[4 * j4 + 1] + av.z * w[4 * j4 + 2] + av.w * w[4 * j4 + 3];
+            }
+            r[t] = acc * scale;
+            if (mode == 0) out[((int64_t)p * 64 + 8 * h + t) * 256 + d] = f2bf(r[t]);
         }
+        // Vt^T: rows = channel d, 64 folded columns -> the 8 tokens of head h are 16 contiguous bytes of row d
+        if (mode != 0)
+            *reinterpret_cast<uint4*>(out + ((int64_t)p * 256 + d) * 64 + 8 * h) =
+                make_uint4(pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]), pack_bf16(r[4], r[5]), pack_bf16(r[6], r[7]));
     }
     if (cb && d < 64) {
         const int h = d >> 3, t = d & 7;
