@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--crop-n-layers", type=int, default=2, help="cfgAMG.crop_n_layers (SABER default 2)")
     ap.add_argument("--npoints", type=int, default=32)
-    ap.add_argument("--max-images", type=int, default=8, help="crops encoded per batched pass")
+    ap.add_argument("--max-images", type=int, default=21, help="crops encoded per batched pass (21 = every crop of the default 1+4+16 AMG pyramid)")
     ap.add_argument("--max-prompts", type=int, default=1024, help="prompts decoded per batched pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")

@@ -15,7 +15,7 @@ from saber_amd.adapters.sam2 import amg as fmask
 _ENGINES: Dict[Any, Any] = {}
 
 
-def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 8, max_prompts: int = 128):
+def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 21, max_prompts: int = 1024):
     """One engine per (device, trunk, weights): the reference builds a second SAM2 copy for AMG (SURVEY 3.4);
     here adapter and generator share one handle."""
     from saber_amd.engine import Engine
