@@ -42,85 +42,118 @@ const char* launch_prompt_tokens(const float* pts, const int* labels, int P, Pro
 // with "src = image_embed + dense".  One block = 64 consecutive tokens of one prompt: phase 1, one thread per
 // token computes the 16-channel hidden vector from its 4x4 logit patch; phase 2, thread d produces channel d
 // of every token (coalesced 512-B rows).
+#define ME_NP 8
 __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
                                                              const float* __restrict__ image_embed_base, XMap em, const float* __restrict__ pos,
                                                              MaskEmbedWeights w, float* __restrict__ src_f,
                                                              bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf) {
-    __shared__ float h2s[64][17];
+    // one block = 64 tokens x ME_NP consecutive prompts: the image-embedding rows (fp32, shared by every prompt of the crop) are
+    // read once per block instead of once per prompt
+    __shared__ __attribute__((aligned(16))) float h2s[ME_NP][64][20];
     const int tid = threadIdx.x;
-    const int p = blockIdx.x >> 6, tok0 = (blockIdx.x & 63) * 64;
-    const float* image_embed = image_embed_base + (int64_t)((p + em.off) / em.div) * em.stride;
-    if (tid < 64) {
-        const int tok = tok0 + tid;
+    const int pg = blockIdx.x >> 6, tok0 = (blockIdx.x & 63) * 64;
+    const int p0 = pg * ME_NP, np = min(ME_NP, P - p0);
+    for (int pi = 0; pi < np; ++pi) {
+        const int p = p0 + pi;
+        // phase 1: four adjacent lanes share a token; lane q computes position q of the first conv (2x2 patch -> 4 channels,
+        // LN2d, GELU), the four h1 vectors are exchanged by shuffles, then lane q computes channels 4q..4q+3 of the second conv.
+        const int tl = tid >> 2, q = tid & 3;
+        const int py = q >> 1, px = q & 1;
         int ty, tx;
-        perm_coords(tok, 2, &ty, &tx);
-        const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4) * 256 + tx * 4;
-        float in[4][4];
+        perm_coords(tok0 + tl, 2, &ty, &tx);
+        const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4 + py * 2) * 256 + tx * 4 + px * 2;
+        const float2 r0 = *reinterpret_cast<const float2*>(mp), r1 = *reinterpret_cast<const float2*>(mp + 256);
+        const float in[4] = {r0.x, r0.y, r1.x, r1.y};
+        float v[4], mu = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4 v = *reinterpret_cast<const float4*>(mp + r * 256);
-            in[r][0] = v.x; in[r][1] = v.y; in[r][2] = v.z; in[r][3] = v.w;
+        for (int c = 0; c < 4; ++c) {
+            float a = w.b1[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a += w.w1[c * 4 + k] * in[k];
+            v[c] = a;
+            mu += a;
         }
-        float h1[2][2][4];
+        mu *= 0.25f;
+        float var = 0.f;
 #pragma unroll
-        for (int py = 0; py < 2; ++py)
+        for (int c = 0; c < 4; ++c) var += (v[c] - mu) * (v[c] - mu);
+        float rstd = __builtin_amdgcn_rsqf(var * 0.25f + 1e-6f);
+        float h1[4][4];     // [position ky*2+kx][channel]
+        float mine[4];
 #pragma unroll
-            for (int px = 0; px < 2; ++px) {
-                float v[4], mu = 0.f;
+        for (int c = 0; c < 4; ++c) mine[c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float a = w.b1[c];
+        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                    for (int ky = 0; ky < 2; ++ky)
+            for (int c = 0; c < 4; ++c) h1[qq][c] = __shfl(mine[c], (tid & ~3) | qq, 64);
+        float h2[4];
+        mu = 0.f;
 #pragma unroll
-                        for (int kx = 0; kx < 2; ++kx) a += w.w1[c * 4 + ky * 2 + kx] * in[py * 2 + ky][px * 2 + kx];
-                    v[c] = a;
-                    mu += a;
-                }
-                mu *= 0.25f;
-                float var = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) var += (v[c] - mu) * (v[c] - mu);
-                const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) h1[py][px][c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
-            }
-        float h2[16], mu = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = 4 * q + cc;
             float a = w.b2[c];
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                for (int ky = 0; ky < 2; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 2; ++kx) a += w.w2[((c * 4 + ci) * 2 + ky) * 2 + kx] * h1[ky][kx][ci];
-            h2[c] = a;
+                for (int k = 0; k < 4; ++k) a += w.w2[(c * 4 + ci) * 4 + k] * h1[k][ci];
+            h2[cc] = a;
             mu += a;
         }
+        mu += __shfl_xor(mu, 1, 64); mu += __shfl_xor(mu, 2, 64);
         mu *= (1.0f / 16.0f);
-        float var = 0.f;
+        var = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) var += (h2[c] - mu) * (h2[c] - mu);
-        const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) h2s[tid][c] = gelu_erf((h2[c] - mu) * rstd * w.g2[c] + w.be2[c]);
+        for (int cc = 0; cc < 4; ++cc) var += (h2[cc] - mu) * (h2[cc] - mu);
+        var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64);
+        rstd = __builtin_amdgcn_rsqf(var * (1.0f / 16.0f) + 1e-6f);
+        float4 o;
+        o.x = gelu_erf((h2[0] - mu) * rstd * w.g2[4 * q + 0] + w.be2[4 * q + 0]);
+        o.y = gelu_erf((h2[1] - mu) * rstd * w.g2[4 * q + 1] + w.be2[4 * q + 1]);
+        o.z = gelu_erf((h2[2] - mu) * rstd * w.g2[4 * q + 2] + w.be2[4 * q + 2]);
+        o.w = gelu_erf((h2[3] - mu) * rstd * w.g2[4 * q + 3] + w.be2[4 * q + 3]);
+        *reinterpret_cast<float4*>(&h2s[pi][tl][4 * q]) = o;
     }
     __syncthreads();
-    float w3[16];
+    // phase 2: thread = (4 consecutive channels, one of 4 token rows): one wave writes one whole 512-B token row per store
+    const int c0 = (tid & 63) * 4, tr = tid >> 6;
+    float w3[4][16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) w3[k] = w.w3[tid * 16 + k];
-    const float b3 = w.b3[tid];
-    for (int t = 0; t < 64; ++t) {
-        const int tok = tok0 + t;
-        float a = b3;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a += w3[k] * h2s[t][k];
-        a += image_embed[(int64_t)tok * DEC_C + tid];
-        const int64_t off = ((int64_t)p * 4096 + tok) * DEC_C + tid;
-        if (src_f) src_f[off] = a;
-        src_bf[off] = f2bf(a);
-        if (srcpos_bf) srcpos_bf[off] = f2bf(a + pos[(int64_t)tok * DEC_C + tid]);
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 t = *reinterpret_cast<const float4*>(w.w3 + (c0 + c) * 16 + 4 * k4);
+            w3[c][4 * k4] = t.x; w3[c][4 * k4 + 1] = t.y; w3[c][4 * k4 + 2] = t.z; w3[c][4 * k4 + 3] = t.w;
+        }
+    const float4 b3 = *reinterpret_cast<const float4*>(w.b3 + c0);
+    // prompts of one block may straddle two crops (slots) only if ME_NP does not divide the prompts per crop: handled per prompt
+    for (int t0 = tr; t0 < 64; t0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 4 * u, tok = tok0 + t;
+            int cur_slot = -1;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (srcpos_bf) pp = *reinterpret_cast<const float4*>(pos + (int64_t)tok * DEC_C + c0);
+            for (int pi = 0; pi < np; ++pi) {
+                const int p = p0 + pi;
+                const int slot = (p + em.off) / em.div;
+                if (slot != cur_slot) {
+                    e = *reinterpret_cast<const float4*>(image_embed_base + (int64_t)slot * em.stride + (int64_t)tok * DEC_C + c0);
+                    cur_slot = slot;
+                }
+                float a[4] = {b3.x + e.x, b3.y + e.y, b3.z + e.z, b3.w + e.w};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 h = *reinterpret_cast<const float4*>(&h2s[pi][t][4 * k4]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] += w3[c][4 * k4] * h.x + w3[c][4 * k4 + 1] * h.y + w3[c][4 * k4 + 2] * h.z + w3[c][4 * k4 + 3] * h.w;
+                }
+                const int64_t off = ((int64_t)p * 4096 + tok) * DEC_C + c0;
+                if (src_f) *reinterpret_cast<float4*>(src_f + off) = make_float4(a[0], a[1], a[2], a[3]);
+                *reinterpret_cast<uint2*>(src_bf + off) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+                if (srcpos_bf) *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_bf16(a[0] + pp.x, a[1] + pp.y), pack_bf16(a[2] + pp.z, a[3] + pp.w));
+            }
+        }
     }
 }
 
@@ -128,7 +161,7 @@ const char* launch_mask_embed_src(const float* mask_in, int P, const float* imag
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s) {
     if (P <= 0) return nullptr;
     if (em.div <= 0) return "mask_embed_src: XMap.div must be positive";
-    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(P * 64), dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf);
+    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(((P + ME_NP - 1) / ME_NP) * 64), dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf);
     return nullptr;
 }
 

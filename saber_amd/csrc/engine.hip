@@ -76,8 +76,8 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     if (t != "large")
         return eng_fail(nullptr, SABER_ERR_INVALID,
                         "HIP engine: trunk '" + t + "' is not built yet (its 14x14 / 7x7 windows do not tile the engine's token order); use 'large'");
-    if (max_images < 1 || max_images > 64 || max_prompts < 1 || max_prompts > 1024)
-        return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: max_images must be 1..64 and max_prompts 1..1024");
+    if (max_images < 1 || max_images > 64 || max_prompts < 1 || max_prompts > 4096)
+        return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: max_images must be 1..64 and max_prompts 1..4096");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return eng_fail(nullptr, SABER_ERR_HIP, "no HIP device visible: the MI355X engine cannot run");
     if (device_id < 0 || device_id >= ndev) return eng_fail(nullptr, SABER_ERR_INVALID, "device_id out of range");
