@@ -501,8 +501,10 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf1
 //   u1 = GELU(LN64(ConvT1(x) + feat_s1));  u2 = GELU(ConvT2(u1) + feat_s0);  masks[k] = hyper[k] . u2
 // Persistent blocks: one block owns a tile of 32 consecutive tokens (2x16 tokens = 8x64 output pixels) and walks over
 // the prompts.  Both ConvTranspose weights stay resident in LDS (128 KB + 16 KB), the tile's feat_s1 / feat_s0 rows and
-// the LayerNorm parameters stay in registers, and the next prompt's 16-KB X tile is prefetched while the current one is
-// computed - per prompt the block touches HBM only for X (read) and the 8-KB logit tile (write).
+// the LayerNorm parameters stay in registers.  The X rows of a wave's 16 tokens are loaded straight into MFMA operand registers
+// (next prompt prefetched while the current one is computed) and every lane stores its own 2x2 output pixels, so the prompt
+// loop contains NO workgroup barrier: the two waves of a SIMD drift apart and one's MFMA phases overlap the other's
+// LayerNorm / GELU / hyper-product VALU phases (in lock-step the VALU work was 60 % of the time with the matrix cores idle).
 // Phase A: [32 tok] x [256 = pos*64+ch] over K=256; wave w owns pos = w, so its LayerNorm groups are wave-local and its
 // GELU outputs feed phase B straight from registers (k-slot permutation, W2 pre-permuted on the host).
 // Phase B: [(pos w, 32 tok)] x [128 = pos2*32+ch2] over K=64, epilogue = +feat_s0, GELU, 4 dot products with hyper.
@@ -510,8 +512,7 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf1
 #define UP_TOK 32
 #define UP_W1S (256 * ROW_B)          // W1 [256 n][256 k] bf16, kswz
 #define UP_W2S (128 * 128)            // W2p [128 n2][64] bf16 (k-slots pre-permuted), swz128
-#define UP_XS (UP_TOK * ROW_B)        // X tile [32][256] bf16, kswz; reused as the output tile [4][8][64] fp32
-#define UP_LDS (UP_W1S + UP_W2S + UP_XS)
+#define UP_LDS (UP_W1S + UP_W2S)
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
@@ -522,8 +523,6 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
     char* w2s = w1s + UP_W1S;
-    char* xs = w2s + UP_W2S;
-    float* outs = reinterpret_cast<float*>(xs);
     // 8 waves (two per SIMD: the epilogues are VALU-bound, a lone wave would issue at half rate):
     // wave = (token half mw) * 4 + (pos = ConvT1 output position)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -576,25 +575,24 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
     int ty0, tx0;
     perm_coords(tile * UP_TOK, 2, &ty0, &tx0);
 
-    u32x4 rx[2];
-    auto xload = [&](int p) {
-        const bf16_t* Xt = X + ((int64_t)p * 4096 + tile * UP_TOK) * DC;
+    // B-operand fragments of the wave's 16 tokens: lane (fi, fg) holds X[tok][32 ks + 8 fg .. +7], ks = 0..7
+    const int64_t xrow = ((int64_t)tile * UP_TOK + tl) * DC + 8 * fg;
+    bf16x8 xf[8];
+    auto xload = [&](int p, bf16x8 (&dst)[8]) {
+        const bf16_t* Xt = X + (int64_t)p * 4096 * DC + xrow;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 512 * j;
-            rx[j] = *reinterpret_cast<const u32x4*>(Xt + (int64_t)(idx >> 5) * DC + (idx & 31) * 8);
-        }
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Xt + 32 * ks));
     };
-    if (grp < P) xload(grp);
+    // output pixels of this lane: token (gy, gx) on the 64x64 grid, ConvT1 position (dy1, dx1); mask k = fg
+    const int gy = ty0 + ty, gx = tx0 + tx;
+    const int64_t obase = ((int64_t)fg * 256 + gy * 4 + dy1 * 2) * 256 + gx * 4 + dx1 * 2;
+    const bool fb0 = fg & 1, fb1 = fg >> 1;
+    __syncthreads();   // resident weights visible; the only workgroup barrier of the kernel
+    if (grp < P) xload(grp, xf);
     for (int p = grp; p < P; p += groups) {
-        __syncthreads();  // weights visible (first pass) / previous output tile fully stored
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 512 * j;
-            *reinterpret_cast<u32x4*>(xs + kswz(idx >> 5, idx & 31)) = rx[j];
-        }
-        __syncthreads();
-        if (p + groups < P) xload(p + groups);
+        // compiler fence: without it the loop-invariant weight fragments (32 + 16 ds_read_b128 per wave) are hoisted out of the
+        // prompt loop and spill
+        asm volatile("" ::: "memory");
         {
             const int slot = (p + s_off) / s_div;     // block-uniform
             if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
@@ -610,13 +608,14 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + kswz(tl, ks * 4 + fg));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1s + kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg));
-                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[ks], acc[ni], 0, 0, 0);
             }
         }
+        // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
+        if (p + groups < P) xload(p + groups, xf);
         // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
         bf16x8 uf[2];
         {
@@ -650,8 +649,8 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 uf[ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
                                  v[2 * ks + 1][3]);
         }
-        __syncthreads();  // every wave is done reading the X tile: its LDS now holds the output tile
         // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
+        float* orow = masks4 + (int64_t)p * 4 * 65536 + obase;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             f32x4 c2[4];
@@ -664,6 +663,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                     const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
                     c2[nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, uf[ks], c2[nl], 0, 0, 0);
                 }
+            float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
                 const int pos2 = 2 * hb + pp;
@@ -675,23 +675,18 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                     const float u0 = gelu_erf(c2[nl][0] + __uint_as_float(fb.x << 16)), u1 = gelu_erf(c2[nl][1] + __uint_as_float(fb.x & 0xffff0000u));
                     const float u2 = gelu_erf(c2[nl][2] + __uint_as_float(fb.y << 16)), u3 = gelu_erf(c2[nl][3] + __uint_as_float(fb.y & 0xffff0000u));
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) part[k] += (u0 * hy[hh][k].x + u1 * hy[hh][k].y) + (u2 * hy[hh][k].z + u3 * hy[hh][k].w);
+                    for (int k = 0; k < 4; ++k) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    part[k] += __shfl_xor(part[k], 16, 64);
-                    part[k] += __shfl_xor(part[k], 32, 64);
-                }
-                const int py = ty * 4 + dy1 * 2 + (pos2 >> 1), px = tx * 4 + dx1 * 2 + (pos2 & 1);
-                const float mine = fg == 0 ? part[0] : fg == 1 ? part[1] : fg == 2 ? part[2] : part[3];
-                outs[(fg * 8 + py) * 64 + px] = mine;
+                // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
+                // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
+                float k0 = fb0 ? part[1] : part[0], k1 = fb0 ? part[3] : part[2];
+                k0 += __shfl_xor(fb0 ? part[0] : part[1], 16, 64);
+                k1 += __shfl_xor(fb0 ? part[2] : part[3], 16, 64);
+                float mine = fb1 ? k1 : k0;
+                mine += __shfl_xor(fb1 ? k0 : k1, 32, 64);
+                if (pp == 0) px2.x = mine; else px2.y = mine;
             }
-        }
-        __syncthreads();
-        {
-            const int k = tid >> 7, row = (tid >> 4) & 7, c4 = tid & 15;   // 512 float4: [k][row 0..7][col/4]
-            const float4 v = *reinterpret_cast<const float4*>(outs + (k * 8 + row) * 64 + c4 * 4);
-            *reinterpret_cast<float4*>(masks4 + (((int64_t)p * 4 + k) * 256 + (ty0 * 4 + row)) * 256 + tx0 * 4 + c4 * 4) = v;
+            *reinterpret_cast<float2*>(orow + hb * 256) = px2;
         }
     }
 }
