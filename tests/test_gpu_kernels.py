@@ -210,3 +210,87 @@ def test_perm_index_is_window_contiguous(lib):
             for x in range(0, g, 2):
                 q = idx[y:y + 2, x:x + 2].ravel()
                 assert q.tolist() == list(range(q[0], q[0] + 4)) and q[0] % 4 == 0
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res", [
+    (32768, 576, 576, 0, True),      # stage-2 proj: fp32 + residual fast epilogue of the persistent direct-to-LDS kernel
+    (32768, 2304, 576, 1, False),    # stage-2 fc1: bf16 + GELU epilogue through the LDS transposition
+    (65536, 432, 144, 0, False),     # stage-0 qkv: K = 144 on zero-padded weight rows (engine upload layout)
+    (70000, 288, 1152, 0, True),     # ragged M, N not a multiple of the 128 tile
+])
+def test_gemm_direct_to_lds(gpu_lib, M, N, K, act, use_res):
+    """Shapes large enough for gemm_bf16_glds_kernel<4> (the kernel every Hiera block runs); torch fp64 on the GPU is the reference."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    Kp = (K + 63) // 64 * 64
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
+    W[:, :K] = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g) if use_res else None
+    ref = A.double() @ W[:, :K].double().T + bias.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + res.double()
+    if use_res:
+        out = torch.zeros(M, N, device="cuda")
+        kcall(gpu_lib, gpu_lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res), ptr(out), None, M, N, K, act, None))
+        err = (out.double() - ref).abs().max().item()
+        assert err < 2e-4, err
+    else:
+        out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        kcall(gpu_lib, gpu_lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), None, None, ptr(out), M, N, K, act, None))
+        err = ((out.double() - ref).abs() / (ref.abs() + 1.0)).max().item()
+        assert err < 2.0 ** -8, err      # one bf16 rounding of the output (+ the 2.6e-5 GELU fit)
+
+
+def _dec_inputs(P, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s, scale=1.0: (torch.randn(*s, device="cuda", generator=g) * scale)
+    X = r(P, 4096, 256).to(torch.bfloat16)
+    pe = r(4096, 256).to(torch.bfloat16)
+    return g, r, X, pe
+
+
+@pytest.mark.parametrize("P,shared", [(3, False), (2, True), (70, False)])
+def test_dec_i2t(gpu_lib, P, shared):
+    """Folded image->token attention + residual + LayerNorm (dec_i2t_kernel) against the plain formula in fp64:
+    out = LN(x + softmax_per_head((x + pe) Kt^T + cb) Vt + bo).  Scores live in the exp2 domain (log2e folded into Kt, cb)."""
+    g, r, X, pe = _dec_inputs(1 if shared else P, 11 + P)
+    Kt = r(P, 64, 256, scale=0.08).to(torch.bfloat16)
+    cb = r(P, 64)
+    VtT = r(P, 256, 64, scale=0.5).to(torch.bfloat16)
+    bo, gamma, beta = r(256), 1.0 + 0.1 * r(256), 0.1 * r(256)
+    out = torch.zeros(P, 4096, 256, device="cuda", dtype=torch.bfloat16)
+    kcall(gpu_lib, gpu_lib.saber_k_dec_i2t(ptr(X), 0 if shared else 4096 * 256, ptr(pe), ptr(Kt), ptr(cb), ptr(VtT), ptr(bo), ptr(gamma), ptr(beta),
+                                          1e-5, ptr(out), P, None))
+    Xd = X.double().expand(P, -1, -1)
+    S = (Xd + pe.double()) @ Kt.double().transpose(1, 2) + cb.double()[:, None, :]
+    Pm = torch.softmax(S.view(P, 4096, 8, 8) * np.log(2.0), dim=-1).view(P, 4096, 64)
+    Y = Pm.to(torch.bfloat16).double() @ VtT.double().transpose(1, 2)        # the kernel rounds P to bf16 for the second MFMA
+    ref = F.layer_norm(Xd + Y + bo.double(), (256,), gamma.double(), beta.double(), 1e-5)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 0.04, err          # bf16 output of O(1..4) LayerNorm values: one ulp is 2^-7 at magnitude 2..4
+    assert (out.double() - ref).pow(2).mean().sqrt().item() < 4e-3
+
+
+@pytest.mark.parametrize("P,split,shared", [(3, 1, False), (2, 4, True), (5, 8, False)])
+def test_dec_t2i(gpu_lib, P, split, shared):
+    """Folded token->image attention (dec_t2i_kernel + finish): out[p][t][16h+i] = Wv[16h+i] . (sum_n softmax_n(Qt[8h+t] . (x_n + pe_n)) x_n) + bv."""
+    g, r, X, pe = _dec_inputs(1 if shared else P, 5 + P)
+    Qt = r(P, 64, 256, scale=0.05).to(torch.bfloat16)
+    Wv = (r(128, 256) / 16).to(torch.bfloat16)
+    bv = r(128)
+    part = torch.zeros(P * split * 64 * 256, device="cuda")
+    ml = torch.zeros(P * split * 64 * 2, device="cuda")
+    out = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
+    kcall(gpu_lib, gpu_lib.saber_k_dec_t2i(ptr(X), 0 if shared else 4096 * 256, ptr(pe), ptr(Qt), ptr(part), ptr(ml), P, split, ptr(Wv), ptr(bv), ptr(out), None))
+    Xd = X.double().expand(P, -1, -1)
+    S = Qt.double() @ (Xd + pe.double()).transpose(1, 2)                     # [P, 64, 4096], exp2 domain
+    Pm = torch.softmax(S * np.log(2.0), dim=-1)
+    Z = Pm @ Xd                                                              # [P, 64 = 8h + t, 256]
+    Z = Z.view(P, 8, 8, 256)                                                 # [p][h][t][256]
+    ref = torch.einsum("phtd,hid->pthi", Z, Wv.double().view(8, 16, 256)).reshape(P, 8, 128) + bv.double()
+    err = (out.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err < 0.02 * scale, (err, scale)      # P is rounded to bf16 before the PV MFMA, output stored as bf16
