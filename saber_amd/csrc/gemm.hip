@@ -426,6 +426,157 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         __builtin_amdgcn_s_barrier();
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Two workgroups per CU: 256x128 tile, K-tiles of 32, 3-stage direct-to-LDS ring (72 KB), 8 waves of 64x64, <= 128 VGPRs.
+// While one workgroup runs its epilogue (bias / activation / residual, LDS transposition, stores) the other one keeps the
+// matrix cores busy; with one workgroup per CU the epilogue is serial time (25-60 % of the shapes of a Hiera block).
+// LDS rows are 64 B (4 chunks of 16 B); physical chunk = logical chunk ^ G[(row >> 2) & 3], G = {0, 2, 3, 1}, which makes the
+// four 16-lane service groups of ds_read_b128 hit 16 distinct (row mod 4, chunk) pairs = all 64 banks.
+#define BK2 32
+#define G2_STAGE ((256 + BN) * BK2 * 2)
+#define G2_LDS (3 * G2_STAGE)
+__device__ __forceinline__ int g2perm(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0, 2, 3, 1}
+__device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ g2perm(row)) << 4); }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_bf16_glds2_kernel(GemmParams p) {
+    constexpr int A_BYTES = 256 * BK2 * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    if (!tile_map(blockIdx.x, tiles_m, tiles_n, &tm, &tn)) return;
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int64_t z = blockIdx.z;
+    const bf16_t* __restrict__ A = p.A + z * p.strideA;
+    const bf16_t* __restrict__ W = p.W + z * p.strideW;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int nk = (p.K + BK2 - 1) / BK2;
+
+    // one wave-instruction = 16 rows x 64 B; per K-tile: A 16 instructions (2 per wave), W 8 (1 per wave)
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const bf16_t* asrc[2];
+    int achunk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + lrow;
+        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda;
+        achunk[i] = lslot ^ g2perm(row);
+    }
+    const int wrow_l = wave * 16 + lrow;
+    const bf16_t* wsrc = W + (int64_t)min(n0 + wrow_l, p.N - 1) * p.ldw;
+    const int wchunk = lslot ^ g2perm(wrow_l);
+    auto issue = [&](int kt) {
+        char* sa = smem + (kt % 3) * G2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = kt * BK2 + achunk[i] * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (k < p.K ? k : 0)), (lptr_t)(sa + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + kt * BK2 + wchunk * 8), (lptr_t)(sa + A_BYTES + wave * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) issue(kt + 2);
+        const char* sa = smem + (kt % 3) * G2_STAGE;
+        const char* sw = sa + A_BYTES;
+        bf16x8 af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 64 + i * 16 + fi, fg));
+            wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + i * 16 + fi, fg));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        // K-tile kt+1 must have landed (this wave's pieces); the youngest one may stay in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const bool fast_bf16 = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0;
+    const bool fast_f32 = p.Cf && !p.Cb && !p.pool4 && p.act == ACT_NONE && (p.N & 3) == 0 && (p.ldcf & 3) == 0 &&
+                          (!p.res || (p.res_shift == 0 && p.res_mod == 0 && (p.ldres & 3) == 0));
+    if (fast_bf16) {
+        // bias + activation in registers, 16 rows at a time transposed through 2 KB of the (now idle) ring so that every store
+        // instruction writes 8 full 128-B rows; LDS traffic in inline asm (see gemm_bf16_glds_kernel)
+        bf16_t* Cb = p.Cb + z * p.strideCb;
+        const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(smem + wave * 2048);
+        const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (p.bias && n + 3 < p.N) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+                }
+                const int chunk = j * 2 + (fg >> 1);
+                const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
+            }
+            u32x4 val0, val1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(val0), "=&v"(val1) : "v"(tb_r0), "v"(tb_r0 + 1024) : "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+                const int m = m0 + wm * 64 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
+                if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
+            }
+        }
+    } else if (fast_f32) {
+        float* Cf = p.Cf + z * p.strideCf;
+        const float* res = p.res ? p.res + z * p.strideRes : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fi;
+            float4 rr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4);
+                rr[j] = res ? *reinterpret_cast<const float4*>(res + (int64_t)min(m, p.M - 1) * p.ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias && n + 3 < p.N) b = *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n);
+                const float4 v = make_float4(acc[i][j][0] + b.x + rr[j].x, acc[i][j][1] + b.y + rr[j].y, acc[i][j][2] + b.z + rr[j].z, acc[i][j][3] + b.w + rr[j].w);
+                if (m < p.M && n + 3 < p.N) *reinterpret_cast<float4*>(Cf + (int64_t)m * p.ldcf + n) = v;
+            }
+        }
+    } else {
+        gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
+    }
+}
+
 #define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2) + 4 * 2048)
 #define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2) + 8 * 2048)
 
@@ -434,6 +585,7 @@ const char* gemm_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_128);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_256);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
@@ -456,7 +608,10 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     dim3 grid(padded((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), 1, p.batch > 0 ? p.batch : 1);
     const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-    if (direct_ok && tiles256 >= 256 && !p.pool4) {
+    if (direct_ok && tiles256 >= 512 && !p.pool4 && !(p.dbg & 16)) {
+        // two co-resident workgroups per CU: one's epilogue overlaps the other's main loop
+        hipLaunchKernelGGL(gemm_bf16_glds2_kernel, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), G2_LDS, stream, p);
+    } else if (direct_ok && tiles256 >= 256 && !p.pool4) {
         // big problems: 256x128 tiles, 8 waves, operands straight into a 3-stage LDS ring
         {
             const int slots = padded((p.M + 255) / 256, (p.N + BN - 1) / BN);
