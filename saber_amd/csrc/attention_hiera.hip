@@ -182,8 +182,14 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     const int fi = lane & 15, fg = lane >> 4;
     const int nq = q_pool ? nk / 4 : nk;
     const int qblocks = nq / (64 * QT);
-    const int task = blockIdx.x / qblocks, qb = blockIdx.x - task * qblocks;
-    const int w = task / heads, h = task - w * heads;
+    // XCD-aware block -> (window, head, q-block) map: blocks b and b + 8 share an XCD (and its L2).  Every block of a window
+    // runs on XCD (w % 8), heads and q-blocks in consecutive dispatch slots, so a window's K/V rows (whose 128-B lines are
+    // shared by the 8 heads) are fetched from HBM once instead of once per XCD that touches them.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_w = heads * qblocks;
+    const int w = (slot / per_w) * 8 + xcd;
+    if (w >= n_windows) return;                      // padding blocks (block-uniform)
+    const int h = (slot % per_w) / qblocks, qb = slot % qblocks;
     const int64_t rs = 3 * (int64_t)heads * HD;
     const int64_t os = (int64_t)heads * HD;
     const int64_t tok0 = (int64_t)w * nk;
@@ -342,10 +348,10 @@ const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows
     if (nk % KB != 0) return "hiera_attention: nk must be 16, 64 or a multiple of 128";
     const int nq = q_pool ? nk / 4 : nk;
     if (false && nq % 128 == 0) {
-        const dim3 grid(n_windows * heads * (nq / 128));
+        const dim3 grid(((n_windows + 7) / 8) * 8 * heads * (nq / 128));
         hipLaunchKernelGGL(hiera_attn_large_kernel<2>, grid, dim3(256), K_LDS_BYTES + V_LDS_BYTES, s, qkv, out, n_windows, nk, heads, q_pool);
     } else if (nq % 64 == 0) {
-        const dim3 grid(n_windows * heads * (nq / 64));
+        const dim3 grid(((n_windows + 7) / 8) * 8 * heads * (nq / 64));
         hipLaunchKernelGGL(hiera_attn_large_kernel<1>, grid, dim3(256), K_LDS_BYTES + V_LDS_BYTES, s, qkv, out, n_windows, nk, heads, q_pool);
     } else return "hiera_attention: nq must be a multiple of 64 for large windows";
     return nullptr;
