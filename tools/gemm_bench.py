@@ -8,8 +8,9 @@ def ptr(t): return C.c_void_p(t.data_ptr())
 ACT = int(os.environ.get('ACT', '0'))
 RES = int(os.environ.get('RES', '0'))   # 1: fp32 output with fp32 residual (proj / fc2 of a Hiera block)
 if os.environ.get('DBG'): lib.saber_k_set_debug(int(os.environ['DBG'], 0))
-shapes = [(32768, 1728, 576), (32768, 576, 576), (32768, 2304, 576), (32768, 576, 2304), (131072, 864, 288), (131072, 1152, 288), (131072, 288, 1152),
-          (524288, 432, 144), (524288, 576, 144), (524288, 144, 576), (8192, 3456, 1152), (8192, 4608, 1152), (8192, 1152, 4608), (8192, 256, 256), (4096, 4096, 4096), (8192, 8192, 8192)]
+M0 = int(os.environ.get("M0", "8"))
+shapes = [(4096 * M0, 1728, 576), (4096 * M0, 576, 576), (4096 * M0, 2304, 576), (4096 * M0, 576, 2304), (16384 * M0, 864, 288), (16384 * M0, 1152, 288), (16384 * M0, 288, 1152),
+          (65536 * M0, 432, 144), (65536 * M0, 576, 144), (65536 * M0, 144, 576), (1024 * M0, 3456, 1152), (1024 * M0, 4608, 1152), (1024 * M0, 1152, 4608), (8192, 256, 256), (4096, 4096, 4096), (8192, 8192, 8192)]
 for M, N, K in shapes:
     Kp = (K + 63) // 64 * 64   # weights as the engine uploads them: rows zero-padded to a multiple of 64
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); W = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
