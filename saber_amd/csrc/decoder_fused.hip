@@ -120,7 +120,8 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32
 
 __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
                                                       const bf16_t* __restrict__ pe, const bf16_t* __restrict__ Qt,
-                                                      float* __restrict__ Opart, float* __restrict__ ML, int split) {
+                                                      float* __restrict__ Opart, float* __restrict__ ML, int split,
+                                                      const bf16_t* __restrict__ Wv, const float* __restrict__ bv, bf16_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,16 +236,46 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
         const float mn = fmaxf(m, m2);
         const float a1 = exp2f(m - mn), a2 = exp2f(m2 - mn);
         const int q = qt * 16 + fi;
-        float* op = Opart + (((int64_t)p * split + sp) * 64 + q) * DC;
+        if (split > 1) {
+            float* op = Opart + (((int64_t)p * split + sp) * 64 + q) * DC;
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt) {
-            const float4 t = *reinterpret_cast<const float4*>(mo + fi * 260 + 16 * dt + 4 * fg);
-            *reinterpret_cast<float4*>(op + 16 * dt + 4 * fg) = make_float4(o[dt][0] * a1 + t.x * a2, o[dt][1] * a1 + t.y * a2, o[dt][2] * a1 + t.z * a2, o[dt][3] * a1 + t.w * a2);
-        }
-        if (fg == 0) {
-            float* mlp = ML + (((int64_t)p * split + sp) * 64 + q) * 2;
-            mlp[0] = mn;
-            mlp[1] = l * a1 + l2 * a2;
+            for (int dt = 0; dt < 16; ++dt) {
+                const float4 t = *reinterpret_cast<const float4*>(mo + fi * 260 + 16 * dt + 4 * fg);
+                *reinterpret_cast<float4*>(op + 16 * dt + 4 * fg) = make_float4(o[dt][0] * a1 + t.x * a2, o[dt][1] * a1 + t.y * a2, o[dt][2] * a1 + t.z * a2, o[dt][3] * a1 + t.w * a2);
+            }
+            if (fg == 0) {
+                float* mlp = ML + (((int64_t)p * split + sp) * 64 + q) * 2;
+                mlp[0] = mn;
+                mlp[1] = l * a1 + l2 * a2;
+            }
+        } else {
+            // whole key range in this block: normalise and apply v_proj here (out[p][t][16h+i] = Wv[16h+i] . Z[8h+t] + bv[16h+i])
+            // instead of a round trip of the partials through HBM and a second kernel.  The wave's 16 query rows are the 8 tokens
+            // of heads 2qt and 2qt+1: Z goes back to LDS in fp32, is re-read as the bf16 B operand (k = channel d, n = row q),
+            // and both heads' 16x256 slices of Wv multiply all 16 rows; each row keeps the tile of its own head.
+            const float inv = __builtin_amdgcn_rcpf(l * a1 + l2 * a2);
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt) {
+                const float4 t = *reinterpret_cast<const float4*>(mo + fi * 260 + 16 * dt + 4 * fg);
+                *reinterpret_cast<float4*>(mo + fi * 260 + 16 * dt + 4 * fg) =
+                    make_float4((o[dt][0] * a1 + t.x * a2) * inv, (o[dt][1] * a1 + t.y * a2) * inv, (o[dt][2] * a1 + t.z * a2) * inv, (o[dt][3] * a1 + t.w * a2) * inv);
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float4 z0 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg), z1 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg + 4);
+                const bf16x8 zf = pack8_d(z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w);
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + fi) * DC + 32 * ks + 8 * fg));
+                const bf16x8 w1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + 16 + fi) * DC + 32 * ks + 8 * fg));
+                r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, zf, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, zf, r1, 0, 0, 0);
+            }
+            const int hsel = fi >> 3, hh = 2 * qt + hsel, t = fi & 7;      // lane: row q = fi -> head hh, token t; outputs 16 hh + 4 fg + r
+            const float4 b4 = *reinterpret_cast<const float4*>(bv + 16 * hh + 4 * fg);
+            const f32x4 r = hsel ? r1 : r0;
+            *reinterpret_cast<uint2*>(out + (int64_t)p * 1024 + t * 128 + 16 * hh + 4 * fg) =
+                make_uint2(pack_bf16(r[0] + b4.x, r[1] + b4.y), pack_bf16(r[2] + b4.z, r[3] + b4.w));
         }
     }
 }
@@ -292,8 +323,8 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pe, const bf1
     if (P <= 0) return nullptr;
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
     if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
-    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, xm.stride, xm.div, xm.off, pe, Qt, Opart, ML, split);
-    hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
+    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, xm.stride, xm.div, xm.off, pe, Qt, Opart, ML, split, Wv, bv, out);
+    if (split > 1) hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
 
