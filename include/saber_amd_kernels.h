@@ -35,6 +35,11 @@ int saber_k_layernorm(const float* x, const float* gamma, const float* beta, flo
 /* Hiera MultiScaleAttention core on contiguous windows (head_dim 72): qkv bf16 [tokens][3*heads*72]
  * -> out bf16 [tokens_q][heads*72]; nk keys per window, q_pool: queries max-pooled over 4 consecutive rows. */
 int saber_k_hiera_attention(const uint16_t* qkv, uint16_t* out, int n_windows, int nk, int heads, int q_pool, void* stream);
+/* Same for every trunk: head_dim 72 (large) | 96 (tiny, small) | 56 (base+); any nk (the 14x14 / 7x7 windows of the smaller
+ * trunks are 196 / 49 keys); key_mask (optional, device): one byte per key of a window, zero-padded to a multiple of 128 bytes,
+ * 0 = the key takes no part (window-padding rows in the global-attention blocks of those trunks). */
+int saber_k_hiera_attention_ex(const uint16_t* qkv, uint16_t* out, int n_windows, int nk, int heads, int head_dim, int q_pool,
+                               const uint8_t* key_mask, void* stream);
 
 /* two-way-transformer attention (fp32 in, bf16 out), contiguous [B][n][heads*hd]. */
 int saber_k_dec_attention(const float* q, const float* k, const float* v, uint16_t* out, int B, int nq, int nk, int heads, int hd,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "saber_k_gemm_ld": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "saber_k_layernorm": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
     "saber_k_hiera_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "saber_k_hiera_attention_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "saber_k_dec_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "saber_k_prepare": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_mask_post": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),

@@ -11,12 +11,26 @@
 //   O^T = V^T . P^T A-operand = V^T fragment read with ds_read_b64_tr_b16 from row-major V in LDS,
 //                   B-operand = P straight from the S accumulators (no lane movement)
 //                   -> lane holds O[q=i][d = 16*dt + 4g + r]: 4 consecutive d = one 8-byte store.
-// head_dim 72 is zero-padded to 96 for the QK^T contraction and to 80 for the PV output.
+// head_dim (72 for Hiera-L, 96 for tiny/small, 56 for base+) is zero-padded to a multiple of 32 for the QK^T contraction
+// and to a multiple of 16 for the PV output.
+//
+// Windows whose key count is not a multiple of the key tile (the 14x14 = 196-key and 7x7 = 49-key padded windows of the
+// tiny/small/base+ trunks) and the global blocks of those trunks (whose token matrix carries the window padding rows, which
+// must not act as keys) are handled by masking: scores of keys >= nk, or of keys whose kmask byte is 0, are set to -3e38.
 #include "common.h"
 #include "kernels.h"
 
-#define HD 72
-#define VSTRIDE 160  // bytes per V row in LDS (80 bf16): 8 rows x 32 B land on disjoint banks for the tr read
+template <int HD_> struct HdTraits {
+    static constexpr int HD = HD_;
+    static constexpr int NCH = HD_ / 8;              // 16-B chunks per row
+    static constexpr int CK = (HD_ + 31) / 32;       // k-steps of the QK^T contraction
+    static constexpr int DT = (HD_ + 15) / 16;       // 16-wide tiles of the PV output
+    // bytes per V row in LDS: >= 32 * DT, and 8 consecutive rows x 32 B land on disjoint banks for the tr read
+    static constexpr int VSTRIDE = HD_ > 80 ? 224 : 160;
+    static constexpr int VCH = VSTRIDE / 16;
+    // HD^-0.5 * log2(e): scores live in the exp2 domain
+    static constexpr float SCALE = (HD_ == 72 ? 0.11785113019775793f : HD_ == 96 ? 0.10206207261596575f : 0.1336306209562122f) * 1.4426950408889634f;
+};
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
@@ -47,6 +61,7 @@ __device__ __forceinline__ uint4 bf16max4(uint4 a, uint4 b) {
 }
 
 // q fragment for 16 rows starting at pooled/unpooled row index `row` (already validated by caller)
+template <int HD>
 __device__ __forceinline__ bf16x8 load_q_frag(const bf16_t* qkv, int64_t rs, int64_t tok0, int row, bool valid, int hdoff,
                                               int hoff, int q_pool) {
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -65,11 +80,13 @@ __device__ __forceinline__ bf16x8 load_q_frag(const bf16_t* qkv, int64_t rs, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// small windows (NK = 16 or 64 keys): one wave per (window, head); K fragments live in registers,
+// small windows (nk <= NK = 16 or 64 keys): one wave per (window, head); K fragments live in registers,
 // V is staged into a wave-private LDS region (no workgroup barrier anywhere).
-template <int NK>
+template <int NK, int HD>
 __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                               int n_windows, int heads, int q_pool) {
+                                                               int n_windows, int nk, int heads, int q_pool) {
+    using TR = HdTraits<HD>;
+    constexpr int VSTRIDE = TR::VSTRIDE, VCH = TR::VCH, NCH = TR::NCH, CK = TR::CK, DT = TR::DT;
     constexpr int NKP = NK < 32 ? 32 : NK;
     constexpr int KT = NKP / 16;
     constexpr int KS = NKP / 32;
@@ -80,52 +97,52 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
     const int w = task / heads, h = task - w * heads;
     const int64_t rs = 3 * (int64_t)heads * HD;
     const int64_t os = (int64_t)heads * HD;
-    const int64_t tok0 = (int64_t)w * NK;
+    const int64_t tok0 = (int64_t)w * nk;
     const int fi = lane & 15, fg = lane >> 4;
     char* vs = vlds + wave * NKP * VSTRIDE;
 
-    // stage V (rows >= NK and cols 72..79 are zero)
-    for (int idx = lane; idx < NKP * 10; idx += 64) {
-        const int row = idx / 10, ch = idx - row * 10;
+    // stage V (rows >= nk and the pad columns are zero)
+    for (int idx = lane; idx < NKP * VCH; idx += 64) {
+        const int row = idx / VCH, ch = idx - row * VCH;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (row < NK && ch < 9) val = *reinterpret_cast<const uint4*>(qkv + (tok0 + row) * rs + 2 * os + h * HD + ch * 8);
+        if (row < nk && ch < NCH) val = *reinterpret_cast<const uint4*>(qkv + (tok0 + row) * rs + 2 * os + h * HD + ch * 8);
         *reinterpret_cast<uint4*>(vs + row * VSTRIDE + ch * 16) = val;
     }
     // K fragments straight from global
-    bf16x8 kf[KT][3];
+    bf16x8 kf[KT][CK];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < CK; ++c) {
             const int key = kt * 16 + fi, hdoff = 32 * c + 8 * fg;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < NK && hdoff < HD) v = *reinterpret_cast<const uint4*>(qkv + (tok0 + key) * rs + os + h * HD + hdoff);
+            if (key < nk && hdoff < HD) v = *reinterpret_cast<const uint4*>(qkv + (tok0 + key) * rs + os + h * HD + hdoff);
             kf[kt][c] = __builtin_bit_cast(bf16x8, v);
         }
     __builtin_amdgcn_wave_barrier();
 
-    const int nq = q_pool ? NK / 4 : NK;
+    const int nq = q_pool ? nk / 4 : nk;
     const int64_t orow0 = (int64_t)w * nq;
-    const float sc = 0.11785113019775793f * 1.4426950408889634f;  // 72^-0.5 * log2(e)
+    const float sc = TR::SCALE;
     for (int qt = 0; qt * 16 < nq; ++qt) {
         const int row = qt * 16 + fi;
         const bool rvalid = row < nq;
-        bf16x8 qf[3];
+        bf16x8 qf[CK];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qf[c] = load_q_frag(qkv, rs, tok0, row, rvalid, 32 * c + 8 * fg, h * HD, q_pool);
+        for (int c = 0; c < CK; ++c) qf[c] = load_q_frag<HD>(qkv, rs, tok0, row, rvalid, 32 * c + 8 * fg, h * HD, q_pool);
         f32x4 s[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kt], 0, 0, 0);
+            for (int c = 0; c < CK; ++c) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kt], 0, 0, 0);
         }
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool kvalid = (kt * 16 + fg * 4 + r) < NK;
+                const bool kvalid = (kt * 16 + fg * 4 + r) < nk;
                 s[kt][r] = kvalid ? s[kt][r] * sc : -3.0e38f;
                 mx = fmaxf(mx, s[kt][r]);
             }
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
             pf[ks] = pack8(s[2 * ks][0], s[2 * ks][1], s[2 * ks][2], s[2 * ks][3], s[2 * ks + 1][0], s[2 * ks + 1][1],
                            s[2 * ks + 1][2], s[2 * ks + 1][3]);
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -166,25 +183,29 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// large windows (nk % 128 == 0, incl. global attention): 4 waves share 128-key K/V blocks in LDS,
-// online softmax across blocks, QT query tiles (16 rows each) per wave.
+// large windows (incl. global attention): 4 waves share 128-key K/V blocks in LDS, online softmax across blocks,
+// QT query tiles (16 rows each) per wave.  MASKED = the key count is not a multiple of 128 and/or a key mask is given.
 #define KB 128
 #define K_LDS_BYTES (KB * 256)
-#define V_LDS_BYTES (KB * VSTRIDE)
 
-template <int QT>
+template <int QT, int HD, bool MASKED>
 __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                               int n_windows, int nk, int heads, int q_pool) {
+                                                               int n_windows, int nk, int heads, int q_pool,
+                                                               const uint8_t* __restrict__ kmask) {
+    using TR = HdTraits<HD>;
+    constexpr int VSTRIDE = TR::VSTRIDE, NCH = TR::NCH, CK = TR::CK, DT = TR::DT;
+    constexpr int V_LDS_BYTES = KB * VSTRIDE;
+    constexpr int NJ = (KB * NCH + 255) / 256;     // staging chunks per thread and operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks_ = smem;
     char* vs = smem + K_LDS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     const int nq = q_pool ? nk / 4 : nk;
-    const int qblocks = nq / (64 * QT);
+    const int qblocks = (nq + 64 * QT - 1) / (64 * QT);
     // XCD-aware block -> (window, head, q-block) map: blocks b and b + 8 share an XCD (and its L2).  Every block of a window
     // runs on XCD (w % 8), heads and q-blocks in consecutive dispatch slots, so a window's K/V rows (whose 128-B lines are
-    // shared by the 8 heads) are fetched from HBM once instead of once per XCD that touches them.
+    // shared by the heads) are fetched from HBM once instead of once per XCD that touches them.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int per_w = heads * qblocks;
     const int w = (slot / per_w) * 8 + xcd;
@@ -199,48 +220,51 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     // zero the whole K/V region once: pad chunks are never overwritten afterwards
     for (int i = tid; i < (K_LDS_BYTES + V_LDS_BYTES) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    bf16x8 qf[QT][3];
+    bf16x8 qf[QT][CK];
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qf[t][c] = load_q_frag(qkv, rs, tok0, q0 + 16 * t + fi, true, 32 * c + 8 * fg, h * HD, q_pool);
+        for (int c = 0; c < CK; ++c)
+            qf[t][c] = load_q_frag<HD>(qkv, rs, tok0, q0 + 16 * t + fi, !MASKED || (q0 + 16 * t + fi) < nq, 32 * c + 8 * fg, h * HD, q_pool);
 
     float m[QT], l[QT];
-    f32x4 o[QT][5];
+    f32x4 o[QT][DT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         m[t] = -3.0e38f;
         l[t] = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const float sc = 0.11785113019775793f * 1.4426950408889634f;
+    const float sc = TR::SCALE;
 
-    // staging: 128 rows x 9 chunks = 1152 16-B chunks per operand, 4.5 per thread
-    u32x4 rk[5], rv[5];
+    // staging: 128 rows x NCH 16-B chunks per operand
+    u32x4 rk[NJ], rv[NJ];
     auto gload = [&](int kb) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int idx = min(tid + 256 * j, KB * 9 - 1);  // unconditional (clamped) loads keep rk/rv in registers
-            const int row = idx / 9, ch = idx - row * 9;
-            const bf16_t* p = qkv + (tok0 + (int64_t)kb * KB + row) * rs + h * HD + ch * 8;
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = min(tid + 256 * j, KB * NCH - 1);  // unconditional (clamped) loads keep rk/rv in registers
+            const int row = idx / NCH, ch = idx - row * NCH;
+            int key = kb * KB + row;
+            if (MASKED) key = min(key, nk - 1);                // rows past the window: any finite data, their scores are masked
+            const bf16_t* p = qkv + (tok0 + key) * rs + h * HD + ch * 8;
             rk[j] = *reinterpret_cast<const u32x4*>(p + os);
             rv[j] = *reinterpret_cast<const u32x4*>(p + 2 * os);
         }
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int idx = tid + 256 * j;
-            if (idx < KB * 9) {
-                const int row = idx / 9, ch = idx - row * 9;
+            if (idx < KB * NCH) {
+                const int row = idx / NCH, ch = idx - row * NCH;
                 *reinterpret_cast<u32x4*>(ks_ + row * 256 + ((ch ^ (row & 15)) << 4)) = rk[j];
                 *reinterpret_cast<u32x4*>(vs + row * VSTRIDE + ch * 16) = rv[j];
             }
         }
     };
 
-    const int nkb = nk / KB;
+    const int nkb = (nk + KB - 1) / KB;
     gload(0);
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();  // previous block fully consumed (and, first time, zero-fill done)
@@ -251,9 +275,9 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
         f32x4 s[QT][8];
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            bf16x8 kf[3];
+            bf16x8 kf[CK];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < CK; ++c) {
                 const int row = 16 * kt + fi;
                 kf[c] = *reinterpret_cast<const bf16x8*>(ks_ + row * 256 + (((4 * c + fg) ^ (row & 15)) << 4));
             }
@@ -261,7 +285,20 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
             for (int t = 0; t < QT; ++t) {
                 s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qf[t][c], s[t][kt], 0, 0, 0);
+                for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qf[t][c], s[t][kt], 0, 0, 0);
+            }
+        }
+        uint32_t mbits = 0xffffffffu;                      // bit 4*kt + r: key kb*128 + 16*kt + 4*fg + r takes part
+        if (MASKED) {
+            mbits = 0u;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                const int key = kb * KB + 16 * kt + 4 * fg;
+                uint32_t mv = 0x01010101u;
+                if (kmask) mv = *reinterpret_cast<const uint32_t*>(kmask + key);   // kmask is zero-padded to a multiple of 128
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key + r < nk && ((mv >> (8 * r)) & 0xffu)) mbits |= 1u << (4 * kt + r);
             }
         }
         bf16x8 pf[QT][4];
@@ -273,6 +310,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s[t][kt][r] *= sc;
+                    if (MASKED && !((mbits >> (4 * kt + r)) & 1u)) s[t][kt][r] = -3.0e38f;
                     mx = fmaxf(mx, s[t][kt][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -285,7 +323,8 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
             for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[t][kt][r] - mn);
+                    float e = exp2f(s[t][kt][r] - mn);
+                    if (MASKED && !((mbits >> (4 * kt + r)) & 1u)) e = 0.f;   // also covers a block with no valid key at all
                     s[t][kt][r] = e;
                     sum += e;
                 }
@@ -293,7 +332,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
             sum += __shfl_xor(sum, 32, 64);
             l[t] = l[t] * alpha + sum;
 #pragma unroll
-            for (int dt = 0; dt < 5; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
 #pragma unroll
@@ -302,7 +341,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
                                   s[t][2 * ks + 1][1], s[t][2 * ks + 1][2], s[t][2 * ks + 1][3]);
         }
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const char* base = vs + (32 * ks + 4 * fg + (fi >> 2)) * VSTRIDE + (16 * dt + 4 * (fi & 3)) * 2;
@@ -313,10 +352,11 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const float inv = 1.0f / l[t];
+        const float inv = l[t] > 0.f ? 1.0f / l[t] : 0.f;
         const int row = q0 + 16 * t + fi;
+        if (MASKED && row >= nq) continue;
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const int d = 16 * dt + 4 * fg;
             if (d < HD)
                 *reinterpret_cast<uint2*>(out + (orow0 + row) * os + h * HD + d) =
@@ -325,34 +365,49 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     }
 }
 
+template <int HD> static hipError_t attn_attrs() {
+    constexpr int lds = K_LDS_BYTES + KB * HdTraits<HD>::VSTRIDE;
+    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return st;
+}
+
 const char* hiera_attention_init_device() {
-    hipError_t st = hipSuccess;
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        K_LDS_BYTES + V_LDS_BYTES);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        K_LDS_BYTES + V_LDS_BYTES);
+    hipError_t st = attn_attrs<72>();
+    if (st == hipSuccess) st = attn_attrs<96>();
+    if (st == hipSuccess) st = attn_attrs<56>();
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
-const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int q_pool,
-                                   hipStream_t s) {
-    if (n_windows <= 0) return nullptr;
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return "hiera_attention: pointer alignment";
-    if (nk == 16 || nk == 64) {
+template <int HD>
+static const char* launch_hd(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int q_pool, const uint8_t* kmask, hipStream_t s) {
+    if (nk <= 64 && !kmask) {
+        if (q_pool && (nk & 3)) return "hiera_attention: q_pool needs nk % 4 == 0";
         const int tasks = n_windows * heads;
         const dim3 grid((tasks + 3) / 4);
-        if (nk == 16) hipLaunchKernelGGL(hiera_attn_small_kernel<16>, grid, dim3(256), 0, s, qkv, out, n_windows, heads, q_pool);
-        else hipLaunchKernelGGL(hiera_attn_small_kernel<64>, grid, dim3(256), 0, s, qkv, out, n_windows, heads, q_pool);
+        if (nk <= 16) hipLaunchKernelGGL((hiera_attn_small_kernel<16, HD>), grid, dim3(256), 0, s, qkv, out, n_windows, nk, heads, q_pool);
+        else hipLaunchKernelGGL((hiera_attn_small_kernel<64, HD>), grid, dim3(256), 0, s, qkv, out, n_windows, nk, heads, q_pool);
         return nullptr;
     }
-    if (nk % KB != 0) return "hiera_attention: nk must be 16, 64 or a multiple of 128";
+    if (q_pool && (nk & 3)) return "hiera_attention: q_pool needs nk % 4 == 0";
     const int nq = q_pool ? nk / 4 : nk;
-    if (false && nq % 128 == 0) {
-        const dim3 grid(((n_windows + 7) / 8) * 8 * heads * (nq / 128));
-        hipLaunchKernelGGL(hiera_attn_large_kernel<2>, grid, dim3(256), K_LDS_BYTES + V_LDS_BYTES, s, qkv, out, n_windows, nk, heads, q_pool);
-    } else if (nq % 64 == 0) {
-        const dim3 grid(((n_windows + 7) / 8) * 8 * heads * (nq / 64));
-        hipLaunchKernelGGL(hiera_attn_large_kernel<1>, grid, dim3(256), K_LDS_BYTES + V_LDS_BYTES, s, qkv, out, n_windows, nk, heads, q_pool);
-    } else return "hiera_attention: nq must be a multiple of 64 for large windows";
+    constexpr int lds = K_LDS_BYTES + KB * HdTraits<HD>::VSTRIDE;
+    const dim3 grid(((n_windows + 7) / 8) * 8 * heads * ((nq + 63) / 64));
+    if (kmask || (nk % KB) != 0 || (nq % 64) != 0)
+        hipLaunchKernelGGL((hiera_attn_large_kernel<1, HD, true>), grid, dim3(256), lds, s, qkv, out, n_windows, nk, heads, q_pool, kmask);
+    else
+        hipLaunchKernelGGL((hiera_attn_large_kernel<1, HD, false>), grid, dim3(256), lds, s, qkv, out, n_windows, nk, heads, q_pool, kmask);
     return nullptr;
+}
+
+const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int hd, int q_pool,
+                                   const uint8_t* kmask, hipStream_t s) {
+    if (n_windows <= 0) return nullptr;
+    if (nk <= 0 || heads <= 0) return "hiera_attention: bad shape";
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return "hiera_attention: pointer alignment";
+    if (kmask && ((uintptr_t)kmask & 3)) return "hiera_attention: key mask must be 4-byte aligned";
+    if (hd == 72) return launch_hd<72>(qkv, out, n_windows, nk, heads, q_pool, kmask, s);
+    if (hd == 96) return launch_hd<96>(qkv, out, n_windows, nk, heads, q_pool, kmask, s);
+    if (hd == 56) return launch_hd<56>(qkv, out, n_windows, nk, heads, q_pool, kmask, s);
+    return "hiera_attention: head_dim must be 72 (large), 96 (tiny/small) or 56 (base+)";
 }

@@ -52,7 +52,12 @@ extern "C" int saber_k_layernorm(const float* x, const float* gamma, const float
 }
 
 extern "C" int saber_k_hiera_attention(const uint16_t* qkv, uint16_t* out, int n_windows, int nk, int heads, int q_pool, void* stream) {
-    return kcheck(launch_hiera_attention(qkv, out, n_windows, nk, heads, q_pool, (hipStream_t)stream));
+    return kcheck(launch_hiera_attention(qkv, out, n_windows, nk, heads, 72, q_pool, nullptr, (hipStream_t)stream));
+}
+
+extern "C" int saber_k_hiera_attention_ex(const uint16_t* qkv, uint16_t* out, int n_windows, int nk, int heads, int head_dim, int q_pool,
+                                          const uint8_t* key_mask, void* stream) {
+    return kcheck(launch_hiera_attention(qkv, out, n_windows, nk, heads, head_dim, q_pool, key_mask, (hipStream_t)stream));
 }
 
 extern "C" int saber_k_dec_attention(const float* q, const float* k, const float* v, uint16_t* out, int B, int nq, int nk, int heads,

@@ -30,8 +30,20 @@ struct saber_engine {
     std::string err;
     bool finalized = false;
 
-    // model description (Hiera-L only in this build)
+    // model description (tiny / small / base+ / large)
     int embed_dim = 0;
+    int head_dim = 0;                 // embed_dim / heads of stage 0: 96 (tiny, small), 56 (base+), 72 (large)
+    int pe_bkg = 7;                   // side of the background pos_embed that is bicubically resized to the 256^2 grid
+    // Token layout per stage.  large: the bit-interleaved order of common.h in every stage.  tiny/small/base+ (14x14 and 7x7
+    // windows on the 64^2 / 32^2 grids): stages 2 and 3 are stored window-major WITH the reference's window padding rows
+    // (70^2 = 25 windows x 196 rows, 35^2 = 25 x 49), rows of a 14x14 window ordered by 2x2 pooling group, so windows stay
+    // contiguous runs of rows, a pooling group stays 4 consecutive rows and row r of stage 3 is rows 4r..4r+3 of stage 2.
+    bool padded = false;
+    int tok_rows[4] = {65536, 16384, 4096, 1024};
+    const uint8_t* valid[4] = {nullptr, nullptr, nullptr, nullptr};   // per stage: 1 = real token, 0 = window padding row
+    const uint8_t* kmask2 = nullptr;  // valid[2] zero-padded to a multiple of 128 (key mask of the global-attention blocks)
+    const int* pack_idx = nullptr;    // [tok_rows[2]]: engine-order row of the 64^2 grid, or -1 for a padding row
+    const int* unpack_idx = nullptr;  // [4096]: padded-layout row of each engine-order row
     std::vector<BlockSpec> blocks;
     std::vector<int> stage_ends;
     std::vector<int> stage_dims;

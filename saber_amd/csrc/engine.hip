@@ -40,29 +40,49 @@ template int eng_alloc<MaskStats>(saber_engine*, MaskStats**, size_t);
 #define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
 
 // ------------------------------------------------------------------------------------------------ model description
-static void hiera_large_spec(saber_engine* e) {
-    const int stages[4] = {2, 6, 36, 4};
-    const int window_spec[4] = {8, 4, 16, 8};
-    const int global_blocks[3] = {23, 33, 43};
-    e->embed_dim = 144;
+struct TrunkSpec { const char* name; int embed_dim, heads0; int stages[4]; int globals[3]; int window_spec[4]; int pe_bkg; };
+// configs/sam2.1/sam2.1_hiera_{t,s,b+,l}.yaml of the third-party sam2 package (selected by saber/pretrained_weights.py:183-188)
+static const TrunkSpec kTrunks[4] = {
+    {"tiny", 96, 1, {1, 2, 7, 2}, {5, 7, 9}, {8, 4, 14, 7}, 7},
+    {"small", 96, 1, {1, 2, 11, 2}, {7, 10, 13}, {8, 4, 14, 7}, 7},
+    {"base", 112, 2, {2, 3, 16, 3}, {12, 16, 20}, {8, 4, 14, 7}, 14},
+    {"large", 144, 2, {2, 6, 36, 4}, {23, 33, 43}, {8, 4, 16, 8}, 7},
+};
+
+static const char* hiera_spec(saber_engine* e, const TrunkSpec& t) {
+    e->embed_dim = t.embed_dim;
+    e->head_dim = t.embed_dim / t.heads0;
+    e->pe_bkg = t.pe_bkg;
+    e->padded = t.window_spec[2] == 14;
+    if (e->padded) {
+        if (t.window_spec[3] != 7 || t.stages[2] < 2) return "trunk spec: padded layout needs 14/7 windows and >= 2 blocks in stage 2";
+        e->tok_rows[2] = 25 * 196;
+        e->tok_rows[3] = 25 * 49;
+    } else if (t.window_spec[2] != 16 || t.window_spec[3] != 8) return "trunk spec: unsupported window sizes";
+    if (t.window_spec[0] != 8 || t.window_spec[1] != 4) return "trunk spec: unsupported window sizes";
     e->blocks.clear(); e->stage_ends.clear(); e->stage_dims.clear();
     int idx = 0;
     for (int s = 0; s < 4; ++s) {
-        const int dim = 144 << s, heads = 2 << s;
+        const int dim = t.embed_dim << s, heads = t.heads0 << s;
         e->stage_dims.push_back(dim);
-        for (int b = 0; b < stages[s]; ++b, ++idx) {
+        for (int b = 0; b < t.stages[s]; ++b, ++idx) {
             BlockSpec bs;
             const bool first = s > 0 && b == 0;
             bs.dout = dim;
             bs.din = first ? dim / 2 : dim;
             bs.heads = heads;
-            bs.window = first ? window_spec[s - 1] : window_spec[s];
-            for (int g : global_blocks) if (g == idx) bs.window = 0;
+            bs.window = first ? t.window_spec[s - 1] : t.window_spec[s];
+            for (int g : t.globals)
+                if (g == idx) {
+                    if (s != 2 || first) return "trunk spec: global attention blocks must lie inside stage 2";
+                    bs.window = 0;
+                }
             bs.q_stride = first ? 2 : 1;
             e->blocks.push_back(bs);
         }
         e->stage_ends.push_back(idx - 1);
     }
+    return nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI: lifecycle
@@ -73,9 +93,8 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     const std::string t(trunk);
     if (t != "tiny" && t != "small" && t != "base" && t != "large")
         return eng_fail(nullptr, SABER_ERR_INVALID, "cfg must be one of tiny/small/base/large, got '" + t + "'");
-    if (t != "large")
-        return eng_fail(nullptr, SABER_ERR_INVALID,
-                        "HIP engine: trunk '" + t + "' is not built yet (its 14x14 / 7x7 windows do not tile the engine's token order); use 'large'");
+    const TrunkSpec* spec = nullptr;
+    for (const TrunkSpec& k : kTrunks) if (t == k.name) spec = &k;
     if (max_images < 1 || max_images > 64 || max_prompts < 1 || max_prompts > 4096)
         return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: max_images must be 1..64 and max_prompts 1..4096");
     int ndev = 0;
@@ -87,7 +106,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     e->trunk = t;
     e->max_images = max_images;
     e->max_prompts = max_prompts;
-    hiera_large_spec(e);
+    if (const char* m = hiera_spec(e, *spec)) { delete e; return eng_fail(nullptr, SABER_ERR_INVALID, m); }
     {
         const char* m = gemm_init_device();
         if (!m) m = hiera_attention_init_device();
@@ -244,7 +263,8 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     {
         const HostTensor* w = F.get(t + "patch_embed.proj.weight", {C0, 3, 7, 7});
         const HostTensor* b = F.get(t + "patch_embed.proj.bias", {C0});
-        const HostTensor* pe = F.get(t + "pos_embed", {1, C0, 7, 7});
+        const int bkg = e->pe_bkg;
+        const HostTensor* pe = F.get(t + "pos_embed", {1, C0, bkg, bkg});
         const HostTensor* pw = F.get(t + "pos_embed_window", {1, C0, 8, 8});
         if (F.status != SABER_OK) return F.status;
         std::vector<float> wt((size_t)147 * C0);
@@ -257,7 +277,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
             for (int x = 0; x < 256; ++x) {
                 const size_t row = (size_t)perm_index256(y, x);
                 for (int c = 0; c < C0; ++c)
-                    pos[row * C0 + c] = (float)bicubic_sample(pe->data.data() + (size_t)c * 49, 7, 7, y, x, 256, 256) +
+                    pos[row * C0 + c] = (float)bicubic_sample(pe->data.data() + (size_t)c * bkg * bkg, bkg, bkg, y, x, 256, 256) +
                                         pw->data[(size_t)c * 64 + (y & 7) * 8 + (x & 7)];
             }
         e->pos_table = F.up_f32(pos);
@@ -435,17 +455,48 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     }
     if (F.status != SABER_OK) return F.status;
 
+    // ---- token-layout tables of the padded-window trunks (engine.h)
+    if (e->padded) {
+        const int R2 = e->tok_rows[2], R3 = e->tok_rows[3];
+        std::vector<int> pack(R2), unpack(4096, -1);
+        std::vector<uint8_t> v2(((size_t)R2 + 127) / 128 * 128, 0), v3(R3, 0);
+        for (int r = 0; r < R2; ++r) {
+            const int w = r / 196, i = r % 196, g = i >> 2, j = i & 3;
+            const int y = (w / 5) * 14 + (g / 7) * 2 + (j >> 1), x = (w % 5) * 14 + (g % 7) * 2 + (j & 1);
+            pack[r] = (y < 64 && x < 64) ? perm_index(y, x, 2) : -1;
+            if (pack[r] >= 0) { v2[r] = 1; unpack[pack[r]] = r; }
+        }
+        for (int r = 0; r < R3; ++r) {
+            const int w = r / 49, g = r % 49;
+            v3[r] = ((w / 5) * 7 + g / 7 < 32 && (w % 5) * 7 + g % 7 < 32) ? 1 : 0;
+        }
+        for (int i = 0; i < 4096; ++i) if (unpack[i] < 0) return eng_fail(e, SABER_ERR_INVALID, "internal: token layout table is not a bijection");
+        auto up_bytes = [&](const void* src, size_t bytes, const void** dst) -> int {
+            void* d = nullptr;
+            TRY(eng_alloc_bytes(e, &d, bytes));
+            ENG_HIP(e, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+            *dst = d;
+            return SABER_OK;
+        };
+        const void* d = nullptr;
+        TRY(up_bytes(pack.data(), pack.size() * 4, &d)); e->pack_idx = (const int*)d;
+        TRY(up_bytes(unpack.data(), unpack.size() * 4, &d)); e->unpack_idx = (const int*)d;
+        TRY(up_bytes(v2.data(), v2.size(), &d)); e->kmask2 = (const uint8_t*)d; e->valid[2] = e->kmask2;
+        TRY(up_bytes(v3.data(), v3.size(), &d)); e->valid[3] = (const uint8_t*)d;
+    }
+
     // ---- workspaces
     const size_t B = e->max_images, P = e->max_prompts;
+    const size_t C0s = (size_t)C0;
     TRY(eng_alloc(e, &e->pix, B * 3 * 1024 * 1024));
-    TRY(eng_alloc(e, &e->xa, B * 65536 * 144));
-    TRY(eng_alloc(e, &e->xb, B * 65536 * 144));
-    TRY(eng_alloc(e, &e->xn, B * 65536 * 144));
-    TRY(eng_alloc(e, &e->qkv, B * 65536 * 864));
-    TRY(eng_alloc(e, &e->att, B * 65536 * 144));
-    TRY(eng_alloc(e, &e->hid, B * 65536 * 576));
-    for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &e->sb[s], B * (65536 >> (2 * s)) * (size_t)(144 << s)));
-    TRY(eng_alloc(e, &e->lat3, B * 1024 * 256));
+    TRY(eng_alloc(e, &e->xa, B * 65536 * C0s));
+    TRY(eng_alloc(e, &e->xb, B * 65536 * C0s));
+    TRY(eng_alloc(e, &e->xn, B * 65536 * C0s));
+    TRY(eng_alloc(e, &e->qkv, B * 65536 * 6 * C0s));
+    TRY(eng_alloc(e, &e->att, B * 65536 * C0s));
+    TRY(eng_alloc(e, &e->hid, B * 65536 * 4 * C0s));
+    for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &e->sb[s], B * e->tok_rows[s] * (C0s << s)));
+    TRY(eng_alloc(e, &e->lat3, B * e->tok_rows[3] * 256));
     TRY(eng_alloc(e, &e->crops_dev, B * 4));
     TRY(eng_alloc(e, &e->emb, B * 4096 * 256));
     TRY(eng_alloc(e, &e->fs1, B * 16384 * 64));
@@ -525,8 +576,10 @@ static GemmParams mk_gemm(const bf16_t* A, int64_t lda, int M, const LinW& w) {
     return p;
 }
 static const char* ln_run(const float* x, const LnW& w, float eps, int rows, int C, float* out_f, bf16_t* out_bf, int act, hipStream_t s,
-                          bf16_t* out_bf_add = nullptr, const float* addvec = nullptr, int add_mod = 0) {
+                          bf16_t* out_bf_add = nullptr, const float* addvec = nullptr, int add_mod = 0, const uint8_t* row_valid = nullptr,
+                          int valid_mod = 0) {
     LayerNormParams p;
+    p.row_valid = row_valid; p.valid_mod = valid_mod;
     p.x = x; p.ldx = C; p.gamma = w.g; p.beta = w.b; p.eps = eps; p.out_f = out_f; p.out_bf = out_bf; p.out_bf_add = out_bf_add;
     p.ldo = C; p.addvec = addvec; p.add_mod = add_mod; p.rows = rows; p.C = C; p.act = act;
     return launch_layernorm(p, s);
@@ -571,7 +624,8 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         const BlockSpec& bs = e->blocks[i];
         const BlockW& w = e->bw[i];
         const int N = n * tokens;
-        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, w.n1, 1e-6f, N, bs.din, nullptr, e->xn, ACT_NONE, s));
+        // window-padding rows (padded layout): the reference pads the normalised tokens with zeros before qkv
+        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, w.n1, 1e-6f, N, bs.din, nullptr, e->xn, ACT_NONE, s, nullptr, nullptr, 0, e->valid[stage], tokens));
         float* xres = x;
         int Nq = N;
         if (bs.din != bs.dout) {
@@ -587,7 +641,10 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
         const int nk = bs.window > 0 ? bs.window * bs.window : tokens;
-        ENG_KP(e, PC_HIERA_ATTN, 4.0 * 72.0 * (double)N * (bs.q_stride > 1 ? nk / 4 : nk) * bs.heads, 0.0, launch_hiera_attention(e->qkv, e->att, N / nk, nk, bs.heads, bs.q_stride > 1, s));
+        // global blocks of the padded layout: one "window" per image whose padding rows are masked out as keys
+        const uint8_t* kmask = (bs.window == 0 && e->valid[stage]) ? e->kmask2 : nullptr;
+        ENG_KP(e, PC_HIERA_ATTN, 4.0 * e->head_dim * (double)N * (bs.q_stride > 1 ? nk / 4 : nk) * bs.heads, 0.0,
+               launch_hiera_attention(e->qkv, e->att, N / nk, nk, bs.heads, e->head_dim, bs.q_stride > 1, kmask, s));
         {
             GemmParams g = mk_gemm(e->att, bs.dout, Nq, w.proj);
             g.Cf = xres; g.ldcf = bs.dout; g.res = xres; g.ldres = bs.dout;
@@ -606,17 +663,27 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             if ((int)i == e->stage_ends[stage]) { g.Cb = e->sb[stage]; g.ldcb = bs.dout; }
             ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
+        if (e->padded && bs.din != bs.dout && stage == 2) {
+            // the 64^2 grid leaves the stage-transition block in the bit-interleaved order; the 14x14 windows of the blocks that
+            // follow need the window-major padded layout (padding rows start as zeros and are re-zeroed by every norm1)
+            ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(x, 4096, xalt, e->tok_rows[2], e->pack_idx, bs.dout, n, s));
+            std::swap(x, xalt);
+            tokens = e->tok_rows[2];
+        }
     }
     // neck
     {
-        GemmParams g = mk_gemm(e->sb[3], e->stage_dims[3], n * 1024, e->neck3);
+        GemmParams g = mk_gemm(e->sb[3], e->stage_dims[3], n * e->tok_rows[3], e->neck3);
         g.Cf = e->lat3; g.ldcf = 256;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
     }
     {
-        GemmParams g = mk_gemm(e->sb[2], e->stage_dims[2], n * 4096, e->neck2);
-        g.Cf = e->emb + (size_t)slot0 * 4096 * 256; g.ldcf = 256; g.res = e->lat3; g.ldres = 256; g.res_shift = 2;
+        GemmParams g = mk_gemm(e->sb[2], e->stage_dims[2], n * e->tok_rows[2], e->neck2);
+        float* emb_slot = e->emb + (size_t)slot0 * 4096 * 256;
+        g.Cf = e->padded ? e->xa : emb_slot; g.ldcf = 256; g.res = e->lat3; g.ldres = 256; g.res_shift = 2;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        // padded layout -> the decoder's bit-interleaved order of the 64^2 grid (the residual stream buffers are free by now)
+        if (e->padded) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(e->xa, e->tok_rows[2], emb_slot, 4096, e->unpack_idx, 256, n, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[1], e->stage_dims[1], n * 16384, e->s1);

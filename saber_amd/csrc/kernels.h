@@ -36,15 +36,21 @@ struct LayerNormParams {
     const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-6f;
     float* out_f = nullptr; bf16_t* out_bf = nullptr; bf16_t* out_bf_add = nullptr; int64_t ldo = 0;
     const float* addvec = nullptr; int add_mod = 0;  // out_bf_add = bf16(y + addvec[row % add_mod])
+    const uint8_t* row_valid = nullptr; int valid_mod = 0;  // rows with row_valid[row % valid_mod] == 0 are written as zeros (window padding)
     int rows = 0, C = 0, act = ACT_NONE;
 };
 const char* launch_layernorm(const LayerNormParams& p, hipStream_t s);
+// out[img][r][:] = idx[r] >= 0 ? in[img][idx[r]][:] : 0   (re-ordering between the engine's token orders; fp32 rows of C floats)
+const char* launch_gather_rows(const float* in, int64_t in_rows, float* out, int64_t out_rows, const int* idx, int C, int n_images, hipStream_t s);
 const char* launch_add_to_bf16(const float* x, const float* y, int ymod, bf16_t* out_bf, float* out_f, int64_t rows, int C,
                                hipStream_t s);
 
 // ------------------------------------------------------------------ attention_hiera.hip
-// qkv: bf16 [tokens][3*heads*72]; out: bf16 [tokens_q][heads*72]; windows are contiguous runs of nk rows.
-const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int q_pool, hipStream_t s);
+// qkv: bf16 [tokens][3*heads*hd]; out: bf16 [tokens_q][heads*hd]; hd = 72 | 96 | 56; windows are contiguous runs of nk rows.
+// kmask (optional): one byte per key of a window (the same for every window), zero-padded to a multiple of 128 bytes; keys whose
+// byte is 0 take no part in the softmax (window-padding rows of the tiny/small/base+ trunks in their global-attention blocks).
+const char* launch_hiera_attention(const bf16_t* qkv, bf16_t* out, int n_windows, int nk, int heads, int hd, int q_pool,
+                                   const uint8_t* kmask, hipStream_t s);
 const char* hiera_attention_init_device();
 
 // ------------------------------------------------------------------ image_ops.hip

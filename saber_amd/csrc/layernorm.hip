@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.C + p.eps);
     const float* addv = p.addvec ? p.addvec + (int64_t)(row % p.add_mod) * p.C : nullptr;
+    // window-padding rows (tiny/small/base+ trunks): the reference pads the NORMALISED tokens with zeros
+    const bool zero_row = p.row_valid && !p.row_valid[row % p.valid_mod];
 #pragma unroll
     for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
         const int c = lane + 64 * i;
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
             float y2 = (v[i].z - mean) * rstd * g.z + b.z;
             float y3 = (v[i].w - mean) * rstd * g.w + b.w;
             if (p.act == ACT_GELU) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+            if (zero_row) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
             if (p.out_f) *reinterpret_cast<float4*>(p.out_f + (int64_t)row * p.ldo + 4 * c) = make_float4(y0, y1, y2, y3);
             if (p.out_bf)
                 *reinterpret_cast<uint2*>(p.out_bf + (int64_t)row * p.ldo + 4 * c) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
@@ -63,6 +66,7 @@ const char* launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if ((p.C & 3) || p.C > LN_MAX_CHUNKS * 256) return "layernorm: C must be a multiple of 4 and <= 1280";
     if ((p.ldx & 3) || (p.ldo & 3)) return "layernorm: strides must be multiples of 4";
     if (p.out_bf_add && (!p.addvec || p.add_mod <= 0)) return "layernorm: addvec missing";
+    if (p.row_valid && p.valid_mod <= 0) return "layernorm: valid_mod";
     hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     return nullptr;
 }
@@ -83,6 +87,30 @@ __global__ __launch_bounds__(256) void add_to_bf16_kernel(const float* __restric
         if (out_bf) *reinterpret_cast<uint2*>(out_bf + r * C + 4 * c) = make_uint2(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w));
         if (out_f) *reinterpret_cast<float4*>(out_f + r * C + 4 * c) = a;
     }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, int64_t in_rows, float* __restrict__ out, int64_t out_rows,
+                                                          const int* __restrict__ idx, int C, int64_t total) {
+    const int nvec = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nvec;
+        const int c = (int)(i - r * nvec);
+        const int64_t img = r / out_rows;
+        const int src = idx[r - img * out_rows];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src >= 0) v = *reinterpret_cast<const float4*>(in + (img * in_rows + src) * C + 4 * c);
+        *reinterpret_cast<float4*>(out + r * C + 4 * c) = v;
+    }
+}
+
+const char* launch_gather_rows(const float* in, int64_t in_rows, float* out, int64_t out_rows, const int* idx, int C, int n_images, hipStream_t s) {
+    if (n_images <= 0 || out_rows <= 0) return nullptr;
+    if (C & 3) return "gather_rows: C must be a multiple of 4";
+    const int64_t total = (int64_t)n_images * out_rows * (C >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, s, in, in_rows, out, out_rows, idx, C, total);
+    return nullptr;
 }
 
 const char* launch_add_to_bf16(const float* x, const float* y, int ymod, bf16_t* out_bf, float* out_f, int64_t rows, int C,

@@ -99,14 +99,16 @@ def test_layernorm(gpu_lib, rows, C, act):
     assert (from_bf(ob).double() - ref).abs().max().item() < 0.03 * ref.abs().max().item()
 
 
-def ref_hiera_attention(qkv, n_windows, nk, heads, q_pool):
-    hd = 72
+def ref_hiera_attention(qkv, n_windows, nk, heads, q_pool, hd=72, key_mask=None):
     t = qkv.view(n_windows, nk, 3, heads, hd).double()
     q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
     if q_pool:
         q = q.view(n_windows, nk // 4, 4, heads, hd).max(2).values
     q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
-    a = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
+    sc = q @ k.transpose(-1, -2) * hd ** -0.5
+    if key_mask is not None:
+        sc = sc.masked_fill(~key_mask[None, None, None, :], float("-inf"))
+    a = torch.softmax(sc, -1) @ v
     return a.transpose(1, 2).reshape(-1, heads * hd)
 
 
@@ -122,6 +124,32 @@ def test_hiera_attention(gpu_lib, n_windows, nk, heads, q_pool):
     got = from_bf(out).double()
     err = (got - ref).abs().max().item()
     assert err < 0.03, err  # |v| ~ 1.5: bf16 P and bf16 output rounding
+    assert ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 6e-3
+
+
+@pytest.mark.parametrize("n_windows,nk,heads,hd,q_pool,masked", [
+    # tiny/small (head_dim 96) and base+ (56): 8x8 / 4x4 windows, the 14x14 and 7x7 padded windows, global blocks whose token
+    # matrix carries the window-padding rows (4900 rows, 4096 of them real keys)
+    (9, 64, 1, 96, 0, 0), (5, 64, 2, 96, 1, 0), (33, 16, 2, 96, 0, 0), (7, 16, 4, 56, 1, 0), (26, 196, 4, 96, 0, 0), (11, 196, 8, 96, 1, 0),
+    (25, 49, 8, 96, 0, 0), (25, 49, 16, 56, 0, 0), (9, 196, 8, 56, 0, 0), (3, 196, 16, 56, 1, 0), (1, 4900, 4, 96, 0, 1), (2, 4900, 8, 56, 0, 1),
+    (3, 196, 8, 72, 0, 0), (2, 300, 2, 72, 0, 1),
+])
+def test_hiera_attention_all_trunks(gpu_lib, n_windows, nk, heads, hd, q_pool, masked):
+    g = torch.Generator().manual_seed(nk + heads + hd)
+    qkv, qd = bf(torch.randn(n_windows * nk, 3 * heads * hd, generator=g) * 1.5)
+    km = kd = None
+    if masked:
+        km = torch.rand(nk, generator=g) > 0.2
+        km[:8] = True
+        pad = torch.zeros((nk + 127) // 128 * 128, dtype=torch.uint8)
+        pad[:nk] = km.to(torch.uint8)
+        kd = pad.cuda()
+    ref = ref_hiera_attention(qkv, n_windows, nk, heads, q_pool, hd, km)
+    out = torch.zeros(ref.shape, dtype=torch.int16, device="cuda")
+    kcall(gpu_lib, gpu_lib.saber_k_hiera_attention_ex(ptr(qd), ptr(out), n_windows, nk, heads, hd, q_pool, ptr(kd) if masked else None, None))
+    got = from_bf(out).double()
+    err = (got - ref).abs().max().item()
+    assert err < 0.03, err
     assert ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 6e-3
 
 
