@@ -137,29 +137,32 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
 #pragma unroll
             for (int c = 0; c < CK; ++c) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kt], 0, 0, 0);
         }
+        // softmax in the exp2 domain with the scale folded into the exponent's fma: exp2(s * sc - max * sc), raw v_exp_f32
+        // (exp2f() adds a denormal-range fix-up of 4 more VALU instructions per element; results below 2^-126 flush to 0 either way)
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool kvalid = (kt * 16 + fg * 4 + r) < nk;
-                s[kt][r] = kvalid ? s[kt][r] * sc : -3.0e38f;
+                s[kt][r] = kvalid ? s[kt][r] : -3.0e38f;
                 mx = fmaxf(mx, s[kt][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmx = -mx * sc;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nmx));
                 s[kt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         bf16x8 pf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -304,26 +307,26 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
         bf16x8 pf[QT][4];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+            // online softmax in the exp2 domain; the scale rides in the exponent's fma and v_exp_f32 is used raw (see the small kernel)
             float mx = -3.0e38f;
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    s[t][kt][r] *= sc;
                     if (MASKED && !((mbits >> (4 * kt + r)) & 1u)) s[t][kt][r] = -3.0e38f;
                     mx = fmaxf(mx, s[t][kt][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m[t], mx);
-            const float alpha = exp2f(m[t] - mn);
+            const float mn = fmaxf(m[t], mx * sc);
+            const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
             m[t] = mn;
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float e = exp2f(s[t][kt][r] - mn);
+                    float e = __builtin_amdgcn_exp2f(fmaf(s[t][kt][r], sc, -mn));
                     if (MASKED && !((mbits >> (4 * kt + r)) & 1u)) e = 0.f;   // also covers a block with no valid key at all
                     s[t][kt][r] = e;
                     sum += e;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const float inv = l[t] > 0.f ? 1.0f / l[t] : 0.f;
+        const float inv = l[t] > 0.f ? __builtin_amdgcn_rcpf(l[t]) : 0.f;
         const int row = q0 + 16 * t + fi;
         if (MASKED && row >= nq) continue;
 #pragma unroll
@@ -365,10 +368,212 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256-key windows (the 16x16 windows of Hiera-L stage 2: 32 of the 48 blocks).  Persistent workgroups (one per CU, 8 waves x
+// 32 queries) walk over (window, head) tasks: the task's whole K and V (256 x HD each) go global -> LDS in one burst of
+// direct-to-LDS loads into DENSE rows of HD * 2 bytes (no staging registers, no padding), double-buffered, so the next task's
+// image and Q fragments are in flight while the current task runs its two 128-key halves out of LDS: one barrier per task.  Dense 144-B rows are conflict-free for the K fragment reads (36 dwords per row: 16 rows hit 16 distinct
+// bank quads); the chunks a fragment reads past a row's HD columns belong to the next row - finite data that meets the zero
+// padding of the Q fragments (QK^T) or lands in output columns >= HD that are never stored (PV).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* gptr_a;
+typedef __attribute__((address_space(3))) void* lptr_a;
+
+template <int HD>
+__global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_windows, int heads) {
+    using TR = HdTraits<HD>;
+    constexpr int CK = TR::CK, DT = TR::DT;
+    constexpr int ROWB = HD * 2;                    // dense row
+    constexpr int KBYTES = 256 * ROWB;              // 36 KB for HD = 72
+    constexpr int NINST = KBYTES / 1024;            // wave-instructions per operand
+    constexpr int BUF = 2 * KBYTES + 256;           // K image, V image, slack for the over-reads behind V's last rows
+    static_assert(KBYTES % 1024 == 0 && NINST % 4 == 0, "dense K/V image must split into whole 1-KB pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fg = lane >> 4;
+    // PERSISTENT: blocks b and b + 8 share an XCD; the (window, head) tasks of the windows w % 8 == b % 8 are dealt round-robin
+    // to the gridDim.x / 8 blocks of that XCD, so the 128-B lines that neighbouring heads share are fetched into one L2 only.
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const int nw_local = n_windows > xcd ? (n_windows - xcd + 7) >> 3 : 0;
+    const int ntask = nw_local * heads;
+    const int64_t rs = 3 * (int64_t)heads * HD;
+    const int64_t os = (int64_t)heads * HD;
+    const int q0 = wave * 32;
+    if (j0 >= ntask) return;
+    if (tid < 32) reinterpret_cast<uint4*>(smem + (tid >> 4) * BUF + 2 * KBYTES)[tid & 15] = make_uint4(0, 0, 0, 0);
+
+    auto task_ptr = [&](int u, int* h) -> int64_t {     // first token of the task's window
+        const int wl = u / heads;
+        *h = u - wl * heads;
+        return (int64_t)(wl * 8 + xcd) * 256;
+    };
+    // the window's K and V rows of head h, global -> LDS: 2 * NINST 1-KB pieces, NINST / 4 of each operand per wave
+    auto issue = [&](int64_t tok0, int h, char* buf) {
+#pragma unroll
+        for (int j = 0; j < (NINST + 7) / 8; ++j) {
+            const int piece = wave + 8 * j;
+            if (piece < NINST) {
+                const int o = piece * 1024 + lane * 16;
+                const int row = o / ROWB, ch = (o - row * ROWB) >> 4;
+                const bf16_t* src = qkv + (tok0 + row) * rs + h * HD + ch * 8;
+                __builtin_amdgcn_global_load_lds((gptr_a)(src + os), (lptr_a)(buf + piece * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_a)(src + 2 * os), (lptr_a)(buf + KBYTES + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // Q fragments of a task: asynchronous 16-B loads in inline asm, so that hipcc neither waits for them at the (distant) first
+    // use with vmcnt(0) nor orders them against the LDS-DMA; columns >= HD are zeroed after the hand-placed wait
+    auto q_issue = [&](int64_t tok0, int h, u32x4 (&q)[2][CK]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const int hdoff = 32 * c + 8 * fg;
+                const bf16_t* src = qkv + (tok0 + q0 + 16 * t + fi) * rs + h * HD + (hdoff < HD ? hdoff : 0);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[t][c]) : "v"(src) : "memory");
+            }
+    };
+    int h;
+    int64_t tok0 = task_ptr(j0, &h);
+    issue(tok0, h, smem);
+    u32x4 qraw[2][CK];
+    q_issue(tok0, h, qraw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float sc = TR::SCALE;
+    int it = 0;
+    for (int u = j0; u < ntask; u += nj, ++it) {
+        char* buf = smem + (it & 1) * BUF;
+        // this wave's pieces of the task's K/V image and its Q fragments have landed (wait at the end of the previous iteration);
+        // the barrier makes the whole image visible and says that every wave is done reading the other buffer, which is re-filled next
+        // (raw s_barrier: __syncthreads() would also drain the output stores still in flight with vmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf16x8 qc[2][CK];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const u32x4 z4 = {0u, 0u, 0u, 0u};
+                qc[t][c] = __builtin_bit_cast(bf16x8, (32 * c + 8 * fg) < HD ? qraw[t][c] : z4);
+            }
+        const int64_t tok_c = tok0;
+        const int h_c = h;
+        const bool more = u + nj < ntask;
+        if (more) {                                   // next task: K/V image into the other buffer, Q fragments into registers
+            tok0 = task_ptr(u + nj, &h);
+            issue(tok0, h, smem + ((it + 1) & 1) * BUF);
+            q_issue(tok0, h, qraw);
+        }
+        float m[2], l[2];
+        f32x4 o[2][DT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            m[t] = -3.0e38f;
+            l[t] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int kb = 0; kb < 2; ++kb) {
+            const char* kbase = buf + kb * 128 * ROWB;
+            const char* vbase = buf + KBYTES + kb * 128 * ROWB;
+            f32x4 s[2][8];
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                bf16x8 kf[CK];
+#pragma unroll
+                for (int c = 0; c < CK; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(kbase + (16 * kt + fi) * ROWB + (4 * c + fg) * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
+                }
+            }
+            bf16x8 pf[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = fmaxf(m[t], mx * sc);
+                const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+                m[t] = mn;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][kt][r], sc, -mn));
+                        s[t][kt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                l[t] = l[t] * alpha + sum;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    pf[t][ks] = pack8(s[t][2 * ks][0], s[t][2 * ks][1], s[t][2 * ks][2], s[t][2 * ks][3], s[t][2 * ks + 1][0],
+                                      s[t][2 * ks + 1][1], s[t][2 * ks + 1][2], s[t][2 * ks + 1][3]);
+            }
+            // V^T fragments through inline asm: a compiler-visible ds_read_b64_tr_b16 is ordered behind the direct-to-LDS loads
+            // of the NEXT task with s_waitcnt vmcnt(0), which would serialise the prefetch with this task's PV products
+            const uint32_t va = (uint32_t)(uintptr_t)(lptr_a)vbase + (4 * fg + (fi >> 2)) * ROWB + 8 * (fi & 3);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                u32x2 lo[4], hi[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[ks]) : "v"(va + 32 * ks * ROWB + 32 * dt) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[ks]) : "v"(va + (32 * ks + 16) * ROWB + 32 * dt) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 vf = cat4(__builtin_bit_cast(bf16x4, lo[ks]), __builtin_bit_cast(bf16x4, hi[ks]));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float inv = __builtin_amdgcn_rcpf(l[t]);
+            const int row = q0 + 16 * t + fi;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + 4 * fg;
+                if (d < HD)
+                    *reinterpret_cast<uint2*>(out + (tok_c + row) * os + h_c * HD + d) =
+                        make_uint2(pack_bf16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_bf16(o[t][dt][2] * inv, o[t][dt][3] * inv));
+            }
+        }
+        // the next task's loads were issued before this task's 2 * DT output stores: all but the youngest 2 * DT operations done
+        // = image and Q fragments landed, stores still draining
+        if (more) {
+            if (DT == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+#define WIN256_LDS(HD) (2 * (2 * 256 * (HD) * 2 + 256))
+
 template <int HD> static hipError_t attn_attrs() {
     constexpr int lds = K_LDS_BYTES + KB * HdTraits<HD>::VSTRIDE;
     hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (WIN256_LDS(HD) <= 160 * 1024)
+        if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_win256_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN256_LDS(HD));
     return st;
 }
 
@@ -391,6 +596,12 @@ static const char* launch_hd(const bf16_t* qkv, bf16_t* out, int n_windows, int 
     }
     if (q_pool && (nk & 3)) return "hiera_attention: q_pool needs nk % 4 == 0";
     const int nq = q_pool ? nk / 4 : nk;
+    extern int g_saber_debug_flags;
+    if constexpr (WIN256_LDS(HD) <= 160 * 1024) if (nk == 256 && !q_pool && !kmask && !(g_saber_debug_flags & 32)) {
+        const int tasks_per_xcd = ((n_windows + 7) / 8) * heads;       // persistent: one workgroup per CU, fewer when there is less work
+        hipLaunchKernelGGL((hiera_attn_win256_kernel<HD>), dim3(8 * (tasks_per_xcd < 32 ? tasks_per_xcd : 32)), dim3(512), WIN256_LDS(HD), s, qkv, out, n_windows, heads);
+        return nullptr;
+    }
     constexpr int lds = K_LDS_BYTES + KB * HdTraits<HD>::VSTRIDE;
     const dim3 grid(((n_windows + 7) / 8) * 8 * heads * ((nq + 63) / 64));
     if (kmask || (nk % KB) != 0 || (nq % 64) != 0)

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (__any(mx > m)) {        // rescale only when some row's running maximum grows (wave-uniform branch)
             const float mn = fmaxf(m, mx);
-            const float alpha = exp2f(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
             m = mn;
             l *= alpha;
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[kt][r] - m);
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
                 s[kt][r] = e;
                 sum += e;
             }

@@ -608,10 +608,10 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     dim3 grid(padded((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), 1, p.batch > 0 ? p.batch : 1);
     const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-    if (direct_ok && tiles256 >= 512 && !p.pool4 && !(p.dbg & 16)) {
+    if (direct_ok && tiles256 >= 512 && !(p.dbg & 16)) {
         // two co-resident workgroups per CU: one's epilogue overlaps the other's main loop
         hipLaunchKernelGGL(gemm_bf16_glds2_kernel, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), G2_LDS, stream, p);
-    } else if (direct_ok && tiles256 >= 256 && !p.pool4) {
+    } else if (direct_ok && tiles256 >= 256) {
         // big problems: 256x128 tiles, 8 waves, operands straight into a 3-stage LDS ring
         {
             const int slots = padded((p.M + 255) / 256, (p.N + BN - 1) / BN);

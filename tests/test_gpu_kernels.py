@@ -37,6 +37,7 @@ def kcall(lib, st):
 @pytest.mark.parametrize("M,N,K,act,use_res,pool4", [
     (300, 432, 144, 0, False, 0), (4096, 576, 2304, 0, True, 0), (1000, 2304, 576, 1, False, 0),
     (5, 1, 256, 0, False, 0), (64, 4, 256, 3, False, 0), (512, 288, 144, 0, False, 1), (777, 128, 64, 2, True, 0),
+    (131072, 288, 128, 0, False, 1), (65536 + 8, 200, 64, 0, True, 1),   # q-pool shortcut through the two direct-to-LDS kernels
 ])
 def test_gemm(gpu_lib, M, N, K, act, use_res, pool4):
     g = torch.Generator().manual_seed(M * 7 + N)
