@@ -56,18 +56,24 @@ int saber_k_mask_post(const float* lowres, int n, int crop_x0, int crop_y0, int 
 /* engine token order helpers (DESIGN.md "token order") */
 /* Folded image->token attention of the two-way transformer (reference: sam2 TwoWayAttentionBlock.cross_attn_image_to_token +
  * norm4, called from sam2/modeling/sam/transformer.py via saber/adapters/sam2/automask.py's predictor):
- * Xout[p][n] = LN(x_n + softmax_heads((x_n + pe_n) Kt_p^T + cb_p) VtT_p^T + bo).  X [P or 1][4096][256] bf16 (x_batch_stride 0 = shared),
- * pe [4096][256] bf16, Kt [P][64][256] bf16 (8 heads x 8 tokens, log2e/sqrt(d) folded in), cb [P][64], VtT [P][256][64] bf16. */
-int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Kt, const float* cb, const uint16_t* VtT,
-                    const float* bo, const float* gamma, const float* beta, float eps, uint16_t* Xout, int P, void* stream);
+ * Xout[p][n] = LN(x_n + softmax_heads(x_n Kt_p^T + kscale * blockdiag_h(tk_p[h]) peq_n[h] + cb_p) VtT_p^T + bo).
+ * X [P or 1][4096][256] bf16 (x_batch_stride 0 = shared); Kt [P][64][256] bf16 = the token keys folded through W_q (8 heads x 8
+ * tokens, log2e/sqrt(d) folded in); the positional term (pe_n Kt^T in the plain formula) enters through peq = pe W_q^T
+ * [4096][128] bf16 (model constant) and the un-folded token keys tk [P*8][128] f32; cb [P][64]; VtT [P][256][64] bf16. */
+int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* peq, const uint16_t* Kt, const float* tk, float kscale, const float* cb,
+                    const uint16_t* VtT, const float* bo, const float* gamma, const float* beta, float eps, uint16_t* Xout, int P, void* stream);
 
-/* Folded token->image attention (cross_attn_token_to_image / final_attn_token_to_image): out[p][t] = Wv (sum_n softmax_n(Qt_p[h,t].(x_n+pe_n)) x_n) + bv.
- * Qt [P][64][256] bf16 (folded queries), part_ws [P*split*64*256] f32, ml_ws [P*split*64*2] f32, out [P][8][256] bf16. */
-int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Qt, float* part_ws, float* ml_ws, int P,
-                    int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream);
+/* Folded token->image attention (cross_attn_token_to_image / final_attn_token_to_image):
+ * out[p][t] = Wv (sum_n softmax_n(Qt_p[h,t].x_n + qscale * tq_p[h,t].pek_n[h]) x_n) + bv.
+ * Qt [P][64][256] bf16 (queries folded through W_k), pek = pe W_k^T [4096][128] bf16 (model constant), tq [P*8][128] f32 (un-folded
+ * projected queries), part_ws [P*split*64*256] f32, ml_ws [P*split*64*2] f32, out [P][8][128] bf16. */
+int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pek, const uint16_t* Qt, const float* tq, float qscale, float* part_ws,
+                    float* ml_ws, int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream);
 
 /* development hook: bit flags read by experimental kernel variants (0 in production) */
 void saber_k_set_debug(int flags);
+/* development: device buffer (uint64 per block, wave and phase) that instrumented kernels fill with s_memtime sums; NULL = off */
+void saber_k_set_stamp_buffer(void* dev);
 
 int saber_k_perm_index(int y, int x, int stage);
 

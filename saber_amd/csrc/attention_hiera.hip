@@ -148,8 +148,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
                 s[kt][r] = kvalid ? s[kt][r] : -3.0e38f;
                 mx = fmaxf(mx, s[kt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor32_max(xor16_max(mx));
         const float nmx = -mx * sc;
         float sum = 0.f;
 #pragma unroll
@@ -160,8 +159,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
                 s[kt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor32_sum(xor16_sum(sum));
         const float inv = __builtin_amdgcn_rcpf(sum);
         bf16x8 pf[KS];
 #pragma unroll
@@ -316,8 +314,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
                     if (MASKED && !((mbits >> (4 * kt + r)) & 1u)) s[t][kt][r] = -3.0e38f;
                     mx = fmaxf(mx, s[t][kt][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor32_max(xor16_max(mx));
             const float mn = fmaxf(m[t], mx * sc);
             const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
             m[t] = mn;
@@ -331,8 +328,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
                     s[t][kt][r] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = xor32_sum(xor16_sum(sum));
             l[t] = l[t] * alpha + sum;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -499,8 +495,7 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
                 for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][kt][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = xor32_max(xor16_max(mx));
                 const float mn = fmaxf(m[t], mx * sc);
                 const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
                 m[t] = mn;
@@ -513,8 +508,7 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
                         s[t][kt][r] = e;
                         sum += e;
                     }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = xor32_sum(xor16_sum(sum));
                 l[t] = l[t] * alpha + sum;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)

@@ -81,16 +81,18 @@ extern "C" int saber_k_mask_post(const float* lowres, int n, int crop_x0, int cr
 
 extern "C" int saber_k_perm_index(int y, int x, int stage) { return perm_index(y, x, stage); }
 
-extern "C" int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Kt, const float* cb,
+extern "C" int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* peq, const uint16_t* Kt, const float* tk, float kscale, const float* cb,
                                const uint16_t* VtT, const float* bo, const float* gamma, const float* beta, float eps, uint16_t* Xout, int P,
                                void* stream) {
-    return kcheck(launch_dec_i2t(X, XMap{x_batch_stride, 1, 0}, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, P, (hipStream_t)stream));
+    return kcheck(launch_dec_i2t(X, XMap{x_batch_stride, 1, 0}, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, P, (hipStream_t)stream));
 }
 
-extern "C" int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pe, const uint16_t* Qt, float* part_ws, float* ml_ws,
-                               int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream) {
-    return kcheck(launch_dec_t2i(X, XMap{x_batch_stride, 1, 0}, pe, Qt, part_ws, ml_ws, P, split, Wv, bv, out, (hipStream_t)stream));
+extern "C" int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pek, const uint16_t* Qt, const float* tq, float qscale, float* part_ws,
+                               float* ml_ws, int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream) {
+    return kcheck(launch_dec_t2i(X, XMap{x_batch_stride, 1, 0}, pek, Qt, tq, qscale, part_ws, ml_ws, P, split, Wv, bv, out, (hipStream_t)stream));
 }
 
 int g_saber_debug_flags = 0;
+unsigned long long* g_saber_stamp_buf = nullptr;   // development: device buffer for in-kernel cycle stamps (nullptr in production)
+extern "C" void saber_k_set_stamp_buffer(void* dev) { g_saber_stamp_buf = (unsigned long long*)dev; }
 extern "C" void saber_k_set_debug(int flags) { g_saber_debug_flags = flags; }

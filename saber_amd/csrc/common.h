@@ -49,19 +49,47 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Cross-lane reductions over lane ^ 16 and lane ^ 32 (the two steps that leave a 16-lane DPP row).  __shfl_xor compiles to
+// ds_bpermute_b32, an LDS round trip of ~100 cycles on the critical path of every softmax / LayerNorm statistic; gfx950's
+// v_permlane16_swap / v_permlane32_swap are plain VALU instructions.  swap(x, x) leaves {x[own half], x[other half]} in the pair.
+__device__ __forceinline__ void xor16_pair(float x, float* a, float* b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    *a = __uint_as_float(r[0]); *b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xor32_pair(float x, float* a, float* b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    *a = __uint_as_float(r[0]); *b = __uint_as_float(r[1]);
+}
+// v_max_f32 without the canonicalising v_max(x, x) hipcc puts in front of fmaxf on values it cannot prove quiet
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float xor16_max(float x) { float a, b; xor16_pair(x, &a, &b); return vmax(a, b); }
+__device__ __forceinline__ float xor32_max(float x) { float a, b; xor32_pair(x, &a, &b); return vmax(a, b); }
+__device__ __forceinline__ float xor16_min(float x) { float a, b; xor16_pair(x, &a, &b); return vmin(a, b); }
+__device__ __forceinline__ float xor32_min(float x) { float a, b; xor32_pair(x, &a, &b); return vmin(a, b); }
+__device__ __forceinline__ float xor16_sum(float x) { float a, b; xor16_pair(x, &a, &b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float x) { float a, b; xor32_pair(x, &a, &b); return a + b; }
+
+// value of lane ^ 16 / lane ^ 32 (odd = this lane sits in the odd 16-lane row of its pair / in the upper half of the wave)
+__device__ __forceinline__ float shfl_xor16(float x, bool odd) { float a, b; xor16_pair(x, &a, &b); return odd ? a : b; }
+__device__ __forceinline__ float shfl_xor32(float x, bool upper) { float a, b; xor32_pair(x, &a, &b); return upper ? a : b; }
+
 __device__ __forceinline__ float wave_sum(float v) {
+    v = xor16_sum(xor32_sum(v));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+    v = xor16_max(xor32_max(v));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 __device__ __forceinline__ float wave_min(float v) {
+    v = xor16_min(xor32_min(v));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
     return v;
 }
 

@@ -100,16 +100,20 @@ const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, 
 
 // ------------------------------------------------------------------------------------------------ tokens -> image
 // grid = P * split, 512 threads.  Each block: 64 folded query rows over 4096/split keys of prompt p, in 64-key blocks.
-//  * score = Qt.(x + pe) is evaluated as [Qt | Qt].[x ; pe] (contraction 512): the positional encoding enters through the
-//    MFMA instead of a VALU add, so BOTH operand tiles are plain copies and go global -> LDS directly
-//    (global_load_lds_dwordx4, 2-stage ring, no staging registers, no ds_write).
+//  * score = Qt.x + Qt.pe.  Qt = W_k^T q (folded, per head) so the second term is q_h . (W_k pe)_h: a contraction of 16 per head
+//    against PEK = pe W_k^T [4096][128], which depends on the model only and is computed once at finalize.  A q tile's 16 rows
+//    are the 8 tokens of heads 2qt and 2qt+1, so ONE MFMA per 16 keys with the block-diagonal operand [q_2qt | 0 ; 0 | q_2qt+1]
+//    (k = 32) adds the positional term: 18 MFMAs, 18 fragment reads and 48 KB of tile per 64-key block instead of 32, 32 and 64.
+//  * both operand tiles are plain copies and go global -> LDS directly (global_load_lds_dwordx4, 2-stage ring, no staging
+//    registers, no ds_write).
 //  * one LDS image of the X tile (XOR-swizzled 512-B rows, source-side swizzle) serves the K operand (ds_read_b128 rows)
 //    and the V operand (ds_read_b64_tr_b16 with the same XOR).
 //  * 8 waves: wave = (key half kh) * 4 + (q tile); each wave keeps its own online-softmax partial over its 32 keys of
 //    every block; the two halves are merged through LDS at the end.  Two waves per SIMD hide each other's LDS latency.
 // Writes un-normalised partial O [P][split][64][256] and (m, l) [P][split][64][2] (log2 domain).
 #define T2I_KB 64
-#define T2I_STAGE (2 * T2I_KB * ROW_B)        // X tile + PE tile
+#define T2I_PEK_ROWB 256                      // one PEK row: 128 bf16
+#define T2I_STAGE (T2I_KB * ROW_B + T2I_KB * T2I_PEK_ROWB)   // X tile (32 KB) + PEK tile (16 KB)
 #define T2I_LDS (2 * T2I_STAGE)
 typedef __attribute__((address_space(1))) const void* gptr_d;
 typedef __attribute__((address_space(3))) void* lptr_d;
@@ -119,10 +123,14 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32
 }
 
 __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
-                                                      const bf16_t* __restrict__ pe, const bf16_t* __restrict__ Qt,
+                                                      const bf16_t* __restrict__ pek, const bf16_t* __restrict__ Qt,
+                                                      const float* __restrict__ tq, float qscale,
                                                       float* __restrict__ Opart, float* __restrict__ ML, int split,
-                                                      const bf16_t* __restrict__ Wv, const float* __restrict__ bv, bf16_t* __restrict__ out) {
+                                                      const bf16_t* __restrict__ Wv, const float* __restrict__ bv, bf16_t* __restrict__ out,
+                                                      unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // development only (stamps != nullptr), see tools/dec_stamps.py
+#define T2I_STAMP(k) do { if (stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qt = wave & 3, kh = wave >> 2;
@@ -130,13 +138,19 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
     const int p = blockIdx.x / split, sp = blockIdx.x - p * split;
     const int nkeys = 4096 / split, key0 = sp * nkeys, nkb = nkeys / T2I_KB;
     const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs + (int64_t)key0 * DC;   // image tokens of prompt p (see kernels.h XMap)
-    const bf16_t* Pp = pe + (int64_t)key0 * DC;
+    const bf16_t* Pp = pek + (int64_t)key0 * 128;
 
-    bf16x8 qf[8];
+    bf16x8 qf[8], pq;
     {
         const bf16_t* qrow = Qt + ((int64_t)p * 64 + qt * 16 + fi) * DC;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
+        // block-diagonal projected query: row fi = token (fi & 7) of head 2 qt + (fi >> 3); k = 8 fg .. 8 fg + 7 of [head A 16 | head B 16]
+        const int hsel = fg >> 1;
+        const float* qp = tq + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qt + hsel) + 8 * (fg & 1);
+        const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+        const float z = ((fi >> 3) == hsel) ? qscale : 0.f;
+        pq = pack8_d(a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z);
     }
     float m = -3.0e38f, l = 0.f;
     f32x4 o[16];
@@ -150,14 +164,24 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
         srow[i] = 2 * (wave * 4 + i) + (lane >> 5);
         schunk[i] = (lane & 31) ^ (srow[i] & 15);          // logical chunk that must land at physical slot lane & 31
     }
+    // PEK tile: 64 rows x 256 B = 16 pieces of 4 rows; wave w issues pieces 2w, 2w+1; 16-B chunks XOR-swizzled by (row & 15)
+    int prow[2], pchunk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        prow[i] = 4 * (wave * 2 + i) + (lane >> 4);
+        pchunk[i] = (lane & 15) ^ (prow[i] & 15);
+    }
     auto issue = [&](int kb, int stage) {
         char* sx = smem + stage * T2I_STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t off = (int64_t)(kb * T2I_KB + srow[i]) * DC + schunk[i] * 8;
             __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 4 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_d)(Pp + off), (lptr_d)(sx + T2I_KB * ROW_B + (wave * 4 + i) * 1024), 16, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_d)(Pp + (int64_t)(kb * T2I_KB + prow[i]) * 128 + pchunk[i] * 8),
+                                             (lptr_d)(sx + T2I_KB * ROW_B + (wave * 2 + i) * 1024), 16, 0, 0);
     };
     // per-lane LDS offsets that do not depend on the block
     int koff[8];                                        // K-operand fragment of key row (16kt + fi), k-step ks
@@ -169,26 +193,27 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
     for (int kb = 0; kb < nkb; ++kb) {
         const int stage = kb & 1;
         if (kb + 1 < nkb) issue(kb + 1, stage ^ 1);
+        T2I_STAMP(0);
         const char* xs = smem + stage * T2I_STAGE + kh * 32 * ROW_B;     // this wave's 32 keys
-        const char* ps = xs + T2I_KB * ROW_B;
+        const char* ps = smem + stage * T2I_STAGE + T2I_KB * ROW_B + kh * 32 * T2I_PEK_ROWB;
         f32x4 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x8 kp = *reinterpret_cast<const bf16x8*>(ps + (kt * 16 + fi) * T2I_PEK_ROWB + (((4 * qt + fg) ^ fi) << 4));
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kp, pq, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const bf16x8 kx = *reinterpret_cast<const bf16x8*>(xs + kt * 16 * ROW_B + koff[ks]);
-                const bf16x8 kp = *reinterpret_cast<const bf16x8*>(ps + kt * 16 * ROW_B + koff[ks]);
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kx, qf[ks], s[kt], 0, 0, 0);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kp, qf[ks], s[kt], 0, 0, 0);
             }
         }
+        T2I_STAMP(1);
         float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor32_max(xor16_max(mx));
         if (__any(mx > m)) {        // rescale only when some row's running maximum grows (wave-uniform branch)
             const float mn = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -208,10 +233,10 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
                 s[kt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor32_sum(xor16_sum(sum));
         l += sum;
         const bf16x8 pf = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
+        T2I_STAMP(2);
 #pragma unroll
         for (int dt = 0; dt < 16; ++dt) {
             const int sw = ((2 * dt + vsel) ^ (vrow & 15)) << 4;       // rows vrow and vrow+16 share (row & 15)
@@ -219,10 +244,15 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
             const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * ROW_B));
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
         }
+        T2I_STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next block landed (this wave's part)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T2I_STAMP(4);
         __builtin_amdgcn_s_barrier();
+        T2I_STAMP(5);
     }
+    if (stamps && lane == 0)
+        for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
     // merge the two key halves of each q tile: waves 4..7 park (m, l, O) in LDS, waves 0..3 combine and store
     float* mo = reinterpret_cast<float*>(smem) + (size_t)qt * 16 * 260;      // [16 q][256 + 4] floats per q tile
     if (kh == 1) {
@@ -318,12 +348,13 @@ __global__ __launch_bounds__(256) void dec_t2i_finish_kernel(const float* __rest
     }
 }
 
-const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
-                           const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
+const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, float* Opart, float* ML,
+                           int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
     if (P <= 0) return nullptr;
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
     if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
-    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, xm.stride, xm.div, xm.off, pe, Qt, Opart, ML, split, Wv, bv, out);
+    extern unsigned long long* g_saber_stamp_buf;
+    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
     if (split > 1) hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
@@ -331,25 +362,33 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pe, const bf1
 // ------------------------------------------------------------------------------------------------ image -> tokens
 // X_out[p][n] = LN(x_n + softmax_heads((x_n + pe_n).Kt + cb).Vt + b_o), one block per prompt, 32-row tiles.
 // Pure streaming kernel: the folded operands of the prompt live in REGISTERS (each wave owns one 16-column slice of Kt
-// for GEMM1 and a 64-channel slice of Vt^T for GEMM2), the X and PE tiles go global -> LDS directly through a 4-stage
-// ring (3 tiles in flight), and (x + pe).Kt is evaluated as x.Kt + pe.Kt inside the MFMA chain (no VALU add).
+// for GEMM1 and a 64-channel slice of Vt^T for GEMM2), the X and PEQ tiles go global -> LDS directly through a 4-stage
+// ring (3 tiles in flight).  (x + pe).Kt = x.Kt + pe.Kt, and since Kt = W_q^T k (folded, per head) the positional term is
+// k_h . (W_q pe)_h: a contraction of 16 per head against PEQ = pe W_q^T [4096][128] (model constant, computed at finalize).
+// A wave's 16 score columns are the 8 tokens of heads 2qr and 2qr+1, so one MFMA with the block-diagonal operand
+// [k_2qr | 0 ; 0 | k_2qr+1] (k = 32) adds it: 9 MFMAs and fragment reads per tile for GEMM1 instead of 16, 24 KB per stage instead of 32.
 // 8 waves: wave = (row tile rt) * 4 + (quarter qr).  Per tile: GEMM1 -> softmax -> P via LDS -> GEMM2 -> residual +
 // LayerNorm (row statistics exchanged through LDS) -> bf16 rows.  Normalisation of tile t is deferred until after the
 // barrier of tile t+1, so each tile costs ONE workgroup barrier.
 #define I2T_ROWS 32
-#define I2T_STAGE (2 * I2T_ROWS * ROW_B)          // X tile + PE tile (16 KB each)
+#define I2T_PEQ_ROWB 256                          // one PEQ row: 128 bf16
+#define I2T_STAGE (I2T_ROWS * ROW_B + I2T_ROWS * I2T_PEQ_ROWB)   // X tile (16 KB) + PEQ tile (8 KB)
 #define I2T_NSTAGE 4
 #define I2T_PSTRIDE 144                           // bytes per P row (64 bf16 + pad)
 #define I2T_PBUF_B (2 * 16 * I2T_PSTRIDE)           // one P buffer: [2 row tiles][16 rows][144 B]
 #define I2T_STAT_B (2 * 16 * 4 * 2 * 4)             // one statistics buffer: [2 row tiles][16 rows][4 quarters][sum, sumsq]
-#define I2T_LDS (I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B)
+#define I2T_OSCR_B (8 * 2048)                       // per wave: 16 rows x 128 B of the output tile, transposed into full-line stores
+#define I2T_LDS (I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B + I2T_OSCR_B)
 
-__global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ pe,
-                                                      const bf16_t* __restrict__ Kt, const float* __restrict__ cb,
+__global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
+                                                      const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
                                                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                      bf16_t* __restrict__ Xout, int nsplit, int dbg) {
+                                                      bf16_t* __restrict__ Xout, int nsplit, int dbg, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // development only (stamps != nullptr): per-wave cycle sums of the phases of the tile loop, see tools/dec_stamps.py
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define I2T_STAMP(k) do { if (stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
     char* pbuf = smem + I2T_NSTAGE * I2T_STAGE;                         // [2 rt][16 rows][144 B]
     float* stat = reinterpret_cast<float*>(pbuf + 2 * I2T_PBUF_B);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -360,7 +399,7 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
     const int NT = (4096 / I2T_ROWS) / nsplit;                  // tiles of this block
     const int64_t row0 = (int64_t)(blockIdx.x % nsplit) * NT * I2T_ROWS;
     const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs + row0 * DC;
-    const bf16_t* pep = pe + row0 * DC;
+    const bf16_t* pep = peq + row0 * 128;
     bf16_t* Xo = Xout + ((int64_t)p * 4096 + row0) * DC;
 
     // folded operands of this prompt, straight into registers
@@ -373,6 +412,14 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             vf[t][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(VtT + ((int64_t)p * 256 + 64 * qr + 16 * t + fi) * 64 + 32 * ks + 8 * fg));
+    bf16x8 kq;   // block-diagonal projected keys: row fi = token (fi & 7) of head 2 qr + (fi >> 3); k = 8 fg .. + 7 of [head A 16 | head B 16]
+    {
+        const int hsel = fg >> 1;
+        const float* kp = tk + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qr + hsel) + 8 * (fg & 1);
+        const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
+        const float z = ((fi >> 3) == hsel) ? kscale : 0.f;
+        kq = pack8_d(a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z);
+    }
     const float4 cb4 = *reinterpret_cast<const float4*>(cb + (int64_t)p * 64 + 16 * qr + 4 * fg);
     float4 bo4[4], g4[4], be4[4];
 #pragma unroll
@@ -381,22 +428,25 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
         g4[t] = *reinterpret_cast<const float4*>(gamma + 64 * qr + 16 * t + 4 * fg);
         be4[t] = *reinterpret_cast<const float4*>(beta + 64 * qr + 16 * t + 4 * fg);
     }
-    // direct-to-LDS: per stage 16 X + 16 PE wave-instructions (1 KB = 2 rows each); wave w issues instructions 2w, 2w+1
+    // direct-to-LDS: per stage 16 X wave-instructions (1 KB = 2 rows each; wave w issues 2w, 2w+1) and 8 PEQ ones (4 rows of
+    // 256 B each, 16-B chunks XOR-swizzled by row & 15; wave w issues piece w)
     int srow[2], schunk[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         srow[i] = 2 * (wave * 2 + i) + (lane >> 5);
         schunk[i] = (lane & 31) ^ (srow[i] & 15);
     }
+    const int prow = 4 * wave + (lane >> 4), pchunk = (lane & 15) ^ (prow & 15);
     auto issue = [&](int t) {
         char* sx = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t off = (int64_t)(t * I2T_ROWS + srow[i]) * DC + schunk[i] * 8;
             __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 2 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_d)(pep + off), (lptr_d)(sx + I2T_ROWS * ROW_B + (wave * 2 + i) * 1024), 16, 0, 0);
         }
+        __builtin_amdgcn_global_load_lds((gptr_d)(pep + (int64_t)(t * I2T_ROWS + prow) * 128 + pchunk * 8), (lptr_d)(sx + I2T_ROWS * ROW_B + wave * 1024), 16, 0, 0);
     };
+    const int poff = (16 * rt + fi) * I2T_PEQ_ROWB + (((4 * qr + fg) ^ fi) << 4);   // B fragment of the PEQ tile: row 16 rt + fi, columns 32 qr + 8 fg ..
     int xoff[8];      // B-operand fragment of row (16 rt + fi), k-step ks, in the swizzled tile
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) xoff[ks] = (16 * rt + fi) * ROW_B + (((4 * ks + fg) ^ fi) << 4);
@@ -407,6 +457,7 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
     const uint32_t prow_a = (uint32_t)(uintptr_t)(lptr_d)(pbuf + (rt * 16 + fi) * I2T_PSTRIDE);
     const uint32_t stat_a = (uint32_t)(uintptr_t)(lptr_d)(stat + ((rt * 16 + fi) * 4) * 2);
     const uint32_t smem_a = (uint32_t)(uintptr_t)(lptr_d)smem;
+    const uint32_t oscr_a = smem_a + I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B + wave * 2048;
     f32x2 g2[8], be2[8], bo2[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -423,53 +474,72 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
         const float mean = tot * (1.0f / DC);
         const float rstd = __builtin_amdgcn_rsqf(fmaxf(tsq * (1.0f / DC) - mean * mean, 0.f) + eps);
         const f32x2 mean2 = (f32x2){mean, mean}, rstd2 = (f32x2){rstd, rstd};
-        bf16_t* orow = Xo + (int64_t)(tp * I2T_ROWS + 16 * rt + fi) * DC + 64 * qr + 4 * fg;
+        // The lane owns 4 x 8 B of row (16 rt + fi); stored as such, every store instruction touches 16 rows with 32 B each and the
+        // CU's store path (~7 B/cycle for such row-per-lane stores) becomes the longest phase of the tile.  The wave's 16 x 128 B go
+        // through 2 KB of LDS instead (XOR-swizzled 16-B chunks) and leave as two instructions of 8 full 128-B lines each.
+        const uint32_t tb = oscr_a + fi * 128 + (fg & 1) * 8;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const f32x2 v0 = ((y2[2 * tt] - mean2) * rstd2) * g2[2 * tt] + be2[2 * tt];
             const f32x2 v1 = ((y2[2 * tt + 1] - mean2) * rstd2) * g2[2 * tt + 1] + be2[2 * tt + 1];
-            *reinterpret_cast<uint2*>(orow + 16 * tt) = make_uint2(pack_bf16(v0.x, v0.y), pack_bf16(v1.x, v1.y));
+            lds_write_b64(tb + (((2 * tt + (fg >> 1)) ^ (fi & 7)) << 4), pack_bf16(v0.x, v0.y), pack_bf16(v1.x, v1.y));
         }
+        u32x4 o0, o1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(o0), "=&v"(o1) : "v"(oscr_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4)) : "memory");
+        bf16_t* orow = Xo + (int64_t)(tp * I2T_ROWS + 16 * rt + (lane >> 3)) * DC + 64 * qr + 8 * (lane & 7);
+        *reinterpret_cast<u32x4*>(orow) = o0;
+        *reinterpret_cast<u32x4*>(orow + 8 * DC) = o1;
     };
 
     issue(0); issue(1); issue(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < NT; ++t) {
         const char* xs = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
         const char* ps = xs + I2T_ROWS * ROW_B;
         // GEMM1 (swapped): S^T[c][m] = Kt[c].x[m] + Kt[c].pe[m] + cb[c] for this wave's 16 columns c
-        f32x4 s = (f32x4){cb4.x, cb4.y, cb4.z, cb4.w}, s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 s = (f32x4){cb4.x, cb4.y, cb4.z, cb4.w}, s1;
+        {
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(ps + poff);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq, pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + xoff[ks]);
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(ps + xoff[ks]);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], xf, s, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], pf, s1, 0, 0, 0);
+        for (int ks = 0; ks < 8; ks += 2) {       // two accumulation chains
+            const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(xs + xoff[ks]);
+            const bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(xs + xoff[ks + 1]);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], xf0, s, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks + 1], xf1, s1, 0, 0, 0);
         }
         s += s1;
         // softmax over the 8 tokens of a head: this lane's 4 values + lane ^ 16
         {
             float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = xor16_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mx); sum += s[r]; }
-            sum += __shfl_xor(sum, 16, 64);
+            sum = xor16_sum(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);
             // LDS stores go through inline asm: a compiler-visible ds_write makes it wait vmcnt(0) for the direct-to-LDS loads in flight
             lds_write_b64(prow_a + (t & 1) * I2T_PBUF_B + (16 * qr + 4 * fg) * 2, pack_bf16(s[0] * inv, s[1] * inv), pack_bf16(s[2] * inv, s[3] * inv));
         }
         // tile t+1 (issued two iterations ago) must have landed before the barrier makes it visible to everyone; the younger
-        // loads and the bf16 stores stay in flight.  Queue behind L(t+1): [S(t-3)] L(t+2) [S(t-2)], 4 ops per group.
+        // loads and the bf16 stores stay in flight.  Queue behind L(t+1): [S(t-3)] L(t+2) [S(t-2)]; a load group is 3 ops, a store group 2.
+        I2T_STAMP(0);
         if (t + 3 >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (t < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (t == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (t < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (t == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        I2T_STAMP(1);
         __builtin_amdgcn_s_barrier();      // the ONE barrier per tile: P(t) and stat(t-1) complete, tile t+1 visible, slot of tile t-1 free
+        I2T_STAMP(2);
         if (t + 3 < NT) issue(t + 3);
+        I2T_STAMP(3);
         if (t > 0) finish_tile(t - 1);
+        I2T_STAMP(4);
         // GEMM2: Y^T[d][m] for this wave's 64 channels
         f32x4 y[4];
         {
@@ -506,16 +576,19 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
             sq2 = __builtin_elementwise_fma(y2[2 * tt + 1], y2[2 * tt + 1], sq2);
         }
         float sum = sum2.x + sum2.y, sq = sq2.x + sq2.y;
-        sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
-        sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        sum = xor16_sum(sum); sq = xor16_sum(sq);
+        sum = xor32_sum(sum); sq = xor32_sum(sq);
         if (fg == 0) lds_write_b64(stat_a + (t & 1) * I2T_STAT_B + qr * 8, __float_as_uint(sum), __float_as_uint(sq));
+        I2T_STAMP(5);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     finish_tile(NT - 1);
+    if (stamps && lane == 0)
+        for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
 }
 
-const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* VtT,
+const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* VtT,
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s) {
     if (P <= 0) return nullptr;
     int nsplit = 1;
@@ -523,7 +596,8 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf1
     extern int g_saber_debug_flags;
     if (g_saber_debug_flags >> 8) nsplit = g_saber_debug_flags >> 8;
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
-    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * nsplit), dim3(512), I2T_LDS, s, X, xm.stride, xm.div, xm.off, pe, Kt, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, g_saber_debug_flags & 255);
+    extern unsigned long long* g_saber_stamp_buf;
+    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * nsplit), dim3(512), I2T_LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, g_saber_debug_flags & 255, g_saber_stamp_buf);
     return nullptr;
 }
 
@@ -657,16 +731,14 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 v[ni][2] = acc[ni][2] + f1[ni].z; v[ni][3] = acc[ni][3] + f1[ni].w;
                 sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = xor32_sum(xor16_sum(sum));
             const float mean = sum * (1.0f / 64.0f);
             float var = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
-            var += __shfl_xor(var, 16, 64);
-            var += __shfl_xor(var, 32, 64);
+            var = xor32_sum(xor16_sum(var));
             const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / 64.0f) + 1e-6f);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
@@ -711,10 +783,10 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
                 // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
                 float k0 = fb0 ? part[1] : part[0], k1 = fb0 ? part[3] : part[2];
-                k0 += __shfl_xor(fb0 ? part[0] : part[1], 16, 64);
-                k1 += __shfl_xor(fb0 ? part[2] : part[3], 16, 64);
+                k0 += shfl_xor16(fb0 ? part[0] : part[1], (lane >> 4) & 1);
+                k1 += shfl_xor16(fb0 ? part[2] : part[3], (lane >> 4) & 1);
                 float mine = fb1 ? k1 : k0;
-                mine += __shfl_xor(fb1 ? k0 : k1, 32, 64);
+                mine += shfl_xor32(fb1 ? k0 : k1, lane >= 32);
                 if (pp == 0) px2.x = mine; else px2.y = mine;
             }
             *reinterpret_cast<float2*>(orow + hb * 256) = px2;

@@ -531,6 +531,23 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->dec_out_masks, P * 3 * 65536));
     TRY(eng_alloc(e, &e->dec_out_iou, P * 3));
     TRY(eng_alloc(e, &e->prep_minmax, 4));
+    // dense positional encoding projected by the image-side weight of every cross attention (model constants for dec_t2i / dec_i2t)
+    {
+        auto project = [&](AttnW& a, const LinW& w) -> int {
+            bf16_t* d = nullptr;
+            TRY(eng_alloc(e, &d, (size_t)4096 * 128));
+            GemmParams g;
+            g.A = e->dense_pe_bf; g.lda = 256; g.W = w.w; g.ldw = w.ldw; g.w_kpad = 1; g.M = 4096; g.N = 128; g.K = 256; g.Cb = d; g.ldcb = 128;
+            if (const char* m = launch_gemm(g, nullptr)) return eng_fail(e, SABER_ERR_INVALID, m);
+            a.pe_proj = d;
+            return SABER_OK;
+        };
+        for (int l = 0; l < 2; ++l) {
+            TRY(project(e->dl[l].t2i, e->dl[l].t2i.k));
+            TRY(project(e->dl[l].i2t, e->dl[l].i2t.q));
+        }
+        TRY(project(e->final_attn, e->final_attn.k));
+    }
     ENG_HIP(e, hipDeviceSynchronize());
     e->host_w.clear();
     e->finalized = true;
@@ -763,7 +780,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         g.Cf = e->tq; g.ldcf = 128;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tq, a.k.w, nullptr, 0, kScale, e->fold_q, nullptr, P, s));
-        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, e->dense_pe_bf, e->fold_q, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
+        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, a.pe_proj, e->fold_q, e->tq, kScale, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
         g = mk_gemm(e->t_att, 128, PT, a.o);
         g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
@@ -800,7 +817,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tk, w.i2t.q.w, w.i2t.q.b, 0, kScale, e->fold_k, e->fold_cb, P, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tv, w.i2t.o.w, nullptr, 1, 1.0f, e->fold_v, nullptr, P, s));
-        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, e->dense_pe_bf, e->fold_k, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
+        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, w.i2t.pe_proj, e->fold_k, e->tk, kScale, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
         X = e->keys_bf; xm = per_prompt;
     }
     TRY(t2i(e->final_attn, e->final_ln));

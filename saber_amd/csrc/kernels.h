@@ -97,10 +97,12 @@ const char* launch_mask_select(const float* masks4, const float* iou4, int P, in
 
 // ------------------------------------------------------------------ decoder_fused.hip
 const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, int mode, float scale, bf16_t* out, float* cb, int P, hipStream_t s);
-const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Qt, float* Opart, float* ML, int P, int split,
-                           const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
-const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* pe, const bf16_t* Kt, const float* cb, const bf16_t* Vt, const float* bo,
-                           const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s);
+// pek / peq: the dense positional encoding projected by the attention's image-side weight, bf16 [4096][128] in engine token order
+// (pe W_k^T for tokens->image, pe W_q^T for image->tokens); tq / tk: the token-side projections fp32 [P*8][128]; scale: head_dim^-0.5 log2(e)
+const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, float* Opart, float* ML,
+                           int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
+const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* Vt,
+                           const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s);
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap slot_map, const float* hyper, float* masks4, int P,
                                hipStream_t s);

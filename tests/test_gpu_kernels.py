@@ -281,20 +281,32 @@ def _dec_inputs(P, seed):
     return g, r, X, pe
 
 
+def _blockdiag_pe_scores(tproj, pproj, scale):
+    """scale * sum_i tproj[p, t, 16h + i] * pproj[n, 16h + i] -> [P, 64 = 8h + t, 4096] (the positional term of a folded attention)"""
+    P = tproj.shape[0]
+    tp = tproj.double().view(P, 8, 8, 16).permute(0, 2, 1, 3)          # [p][h][t][i]
+    pp = pproj.double().view(4096, 8, 16)                              # [n][h][i]
+    return scale * torch.einsum("phti,nhi->phtn", tp, pp).reshape(P, 64, 4096)
+
+
 @pytest.mark.parametrize("P,shared", [(3, False), (2, True), (70, False)])
 def test_dec_i2t(gpu_lib, P, shared):
     """Folded image->token attention + residual + LayerNorm (dec_i2t_kernel) against the plain formula in fp64:
-    out = LN(x + softmax_per_head((x + pe) Kt^T + cb) Vt + bo).  Scores live in the exp2 domain (log2e folded into Kt, cb)."""
+    out = LN(x + softmax_per_head(x Kt^T + kscale blockdiag(tk) peq^T + cb) Vt + bo).  Scores live in the exp2 domain."""
     g, r, X, pe = _dec_inputs(1 if shared else P, 11 + P)
     Kt = r(P, 64, 256, scale=0.08).to(torch.bfloat16)
+    peq = r(4096, 128, scale=1.0).to(torch.bfloat16)
+    tk = r(P * 8, 128, scale=1.0)
+    kscale = 0.3
     cb = r(P, 64)
     VtT = r(P, 256, 64, scale=0.5).to(torch.bfloat16)
     bo, gamma, beta = r(256), 1.0 + 0.1 * r(256), 0.1 * r(256)
     out = torch.zeros(P, 4096, 256, device="cuda", dtype=torch.bfloat16)
-    kcall(gpu_lib, gpu_lib.saber_k_dec_i2t(ptr(X), 0 if shared else 4096 * 256, ptr(pe), ptr(Kt), ptr(cb), ptr(VtT), ptr(bo), ptr(gamma), ptr(beta),
-                                          1e-5, ptr(out), P, None))
+    kcall(gpu_lib, gpu_lib.saber_k_dec_i2t(ptr(X), 0 if shared else 4096 * 256, ptr(peq), ptr(Kt), ptr(tk), kscale, ptr(cb), ptr(VtT), ptr(bo), ptr(gamma),
+                                          ptr(beta), 1e-5, ptr(out), P, None))
     Xd = X.double().expand(P, -1, -1)
-    S = (Xd + pe.double()) @ Kt.double().transpose(1, 2) + cb.double()[:, None, :]
+    tkb = (tk * kscale).to(torch.bfloat16).view(P, 8, 128)              # the kernel rounds the scaled projection to bf16 for the MFMA
+    S = Xd @ Kt.double().transpose(1, 2) + _blockdiag_pe_scores(tkb, peq, 1.0).transpose(1, 2) + cb.double()[:, None, :]
     Pm = torch.softmax(S.view(P, 4096, 8, 8) * np.log(2.0), dim=-1).view(P, 4096, 64)
     Y = Pm.to(torch.bfloat16).double() @ VtT.double().transpose(1, 2)        # the kernel rounds P to bf16 for the second MFMA
     ref = F.layer_norm(Xd + Y + bo.double(), (256,), gamma.double(), beta.double(), 1e-5)
@@ -305,17 +317,23 @@ def test_dec_i2t(gpu_lib, P, shared):
 
 @pytest.mark.parametrize("P,split,shared", [(3, 1, False), (2, 4, True), (5, 8, False)])
 def test_dec_t2i(gpu_lib, P, split, shared):
-    """Folded token->image attention (dec_t2i_kernel + finish): out[p][t][16h+i] = Wv[16h+i] . (sum_n softmax_n(Qt[8h+t] . (x_n + pe_n)) x_n) + bv."""
+    """Folded token->image attention (dec_t2i_kernel + finish):
+    out[p][t][16h+i] = Wv[16h+i] . (sum_n softmax_n(Qt[8h+t] . x_n + qscale tq[h,t] . pek_n[h]) x_n) + bv."""
     g, r, X, pe = _dec_inputs(1 if shared else P, 5 + P)
     Qt = r(P, 64, 256, scale=0.05).to(torch.bfloat16)
+    pek = r(4096, 128, scale=1.0).to(torch.bfloat16)
+    tq = r(P * 8, 128, scale=1.0)
+    qscale = 0.3
     Wv = (r(128, 256) / 16).to(torch.bfloat16)
     bv = r(128)
     part = torch.zeros(P * split * 64 * 256, device="cuda")
     ml = torch.zeros(P * split * 64 * 2, device="cuda")
     out = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
-    kcall(gpu_lib, gpu_lib.saber_k_dec_t2i(ptr(X), 0 if shared else 4096 * 256, ptr(pe), ptr(Qt), ptr(part), ptr(ml), P, split, ptr(Wv), ptr(bv), ptr(out), None))
+    kcall(gpu_lib, gpu_lib.saber_k_dec_t2i(ptr(X), 0 if shared else 4096 * 256, ptr(pek), ptr(Qt), ptr(tq), qscale, ptr(part), ptr(ml), P, split, ptr(Wv),
+                                          ptr(bv), ptr(out), None))
     Xd = X.double().expand(P, -1, -1)
-    S = Qt.double() @ (Xd + pe.double()).transpose(1, 2)                     # [P, 64, 4096], exp2 domain
+    tqb = (tq * qscale).to(torch.bfloat16).view(P, 8, 128)
+    S = Qt.double() @ Xd.transpose(1, 2) + _blockdiag_pe_scores(tqb, pek, 1.0)   # [P, 64, 4096], exp2 domain
     Pm = torch.softmax(S * np.log(2.0), dim=-1)
     Z = Pm @ Xd                                                              # [P, 64 = 8h + t, 256]
     Z = Z.view(P, 8, 8, 256)                                                 # [p][h][t][256]

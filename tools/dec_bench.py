@@ -20,13 +20,14 @@ g = torch.Generator(device="cuda").manual_seed(0)
 pe = bf(torch.randn(4096, 256, device="cuda", generator=g))
 for P in Ps:
     X = bf(torch.randn(P, 4096, 256, device="cuda", generator=g))
+    pp = bf(torch.randn(4096, 128, device="cuda", generator=g)); tproj = torch.randn(P * 8, 128, device="cuda", generator=g)
     if which == "i2t":
         Kt = bf(torch.randn(P, 64, 256, device="cuda", generator=g) * 0.05); cb = torch.randn(P, 64, device="cuda", generator=g)
         VtT = bf(torch.randn(P, 256, 64, device="cuda", generator=g)); bo = torch.randn(256, device="cuda", generator=g)
         ga = torch.ones(256, device="cuda"); be = torch.zeros(256, device="cuda"); out = torch.empty_like(X)
         for flags in [0, 0x100, 0x200, 0x400, 0x800]:
             lib.saber_k_set_debug(flags)
-            us = timeit(lambda: lib.saber_k_dec_i2t(ptr(X), 4096 * 256, ptr(pe), ptr(Kt), ptr(cb), ptr(VtT), ptr(bo), ptr(ga), ptr(be), 1e-5, ptr(out), P, None))
+            us = timeit(lambda: lib.saber_k_dec_i2t(ptr(X), 4096 * 256, ptr(pp), ptr(Kt), ptr(tproj), 0.3, ptr(cb), ptr(VtT), ptr(bo), ptr(ga), ptr(be), 1e-5, ptr(out), P, None))
             print(f"i2t P={P:5d} flags={flags:#06x}: {us:8.1f} us   {P * 4096 * 256 * 4 / us / 1e6:6.2f} TB/s", flush=True)
         lib.saber_k_set_debug(0)
     elif which == "t2i":
@@ -35,7 +36,7 @@ for P in Ps:
         out = torch.empty(P, 8, 128, device="cuda", dtype=torch.bfloat16)
         for split in (1, 2, 4, 8):
             part = torch.empty(P * split * 64 * 256, device="cuda"); ml = torch.empty(P * split * 64 * 2, device="cuda")
-            us = timeit(lambda: lib.saber_k_dec_t2i(ptr(X), 4096 * 256, ptr(pe), ptr(Qt), ptr(part), ptr(ml), P, split, ptr(Wv), ptr(bv), ptr(out), None))
+            us = timeit(lambda: lib.saber_k_dec_t2i(ptr(X), 4096 * 256, ptr(pp), ptr(Qt), ptr(tproj), 0.3, ptr(part), ptr(ml), P, split, ptr(Wv), ptr(bv), ptr(out), None))
             print(f"t2i P={P:5d} split={split}: {us:8.1f} us   {P * 4096 * 256 * 2 / us / 1e6:6.2f} TB/s", flush=True)
     elif which == "copy":
         out = torch.empty_like(X)
