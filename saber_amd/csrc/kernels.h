@@ -25,6 +25,7 @@ struct GemmParams {
     int pool4 = 0;       // rows 4q..4q+3 max-pooled into output row q (Hiera q-pool shortcut)
     int batch = 1;
     int dbg = 0;         // development flags (saber_k_set_debug), 0 in production
+    unsigned long long* stamps = nullptr;   // development: in-kernel cycle stamps (tools/gemm_stamps.py)
     int w_kpad = 0;      // W rows are zero-padded to a multiple of 64 in K (ldw >= padded K): enables the direct-to-LDS kernel
 };
 const char* launch_gemm(const GemmParams& p, hipStream_t stream);
