@@ -17,10 +17,6 @@
 
 #define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
 
-__global__ __launch_bounds__(256) void clamp_kernel(float* x, int64_t n, float lo, float hi) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
-}
-
 struct Cand {
     float box[4];       // xyxy in full-image coordinates (inclusive max edge, upstream batched_mask_to_box)
     float iou, stab;
@@ -187,16 +183,16 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                     }
             }
             ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * G * np, hipMemcpyHostToDevice, s));
-            TRY(eng_decode(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, e->amg_low1, e->amg_iou1, nullptr, s));
+            TRY(eng_decode(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, 0.f, e->amg_low1, e->amg_iou1, nullptr, s));
             const float* masks = e->amg_low1;
             const float* ious = e->amg_iou1;
             if (prm->use_m2m) {
-                hipLaunchKernelGGL(clamp_kernel, dim3(2048), dim3(256), 0, s, e->amg_low1, (int64_t)G * nm * 65536, -32.0f, 32.0f);
+                // the predictor's clamp of the returned low-res logits to +-32 is applied where they are read back as the mask prompt
                 h_pts2.resize((size_t)G * nm * 2);
                 for (size_t k = 0; k < (size_t)G * np; ++k)
                     for (int m = 0; m < M; ++m) { h_pts2[2 * (k * M + m)] = h_pts[2 * k]; h_pts2[2 * (k * M + m) + 1] = h_pts[2 * k + 1]; }
                 ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * G * nm, hipMemcpyHostToDevice, s));
-                TRY(eng_decode(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, e->amg_low2, e->amg_iou2, nullptr, s));
+                TRY(eng_decode(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, 32.0f, e->amg_low2, e->amg_iou2, nullptr, s));
                 masks = e->amg_low2;
                 ious = e->amg_iou2;
             }

@@ -46,7 +46,7 @@ const char* launch_prompt_tokens(const float* pts, const int* labels, int P, Pro
 __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
                                                              const float* __restrict__ image_embed_base, XMap em, const float* __restrict__ pos,
                                                              MaskEmbedWeights w, float* __restrict__ src_f,
-                                                             bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf) {
+                                                             bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf, float clamp_abs) {
     // one block = 64 tokens x ME_NP consecutive prompts: the image-embedding rows (fp32, shared by every prompt of the crop) are
     // read once per block instead of once per prompt
     __shared__ __attribute__((aligned(16))) float h2s[ME_NP][64][20];
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
         perm_coords(tok0 + tl, 2, &ty, &tx);
         const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4 + py * 2) * 256 + tx * 4 + px * 2;
         const float2 r0 = *reinterpret_cast<const float2*>(mp), r1 = *reinterpret_cast<const float2*>(mp + 256);
-        const float in[4] = {r0.x, r0.y, r1.x, r1.y};
+        // clamp_abs: SAM2ImagePredictor._predict clamps the low-res logits it hands back to +-32 before they are re-used as a mask
+        // prompt; the AMG driver passes the raw first-pass logits and has the clamp applied here instead of in a pass of its own
+        const float in[4] = {fminf(fmaxf(r0.x, -clamp_abs), clamp_abs), fminf(fmaxf(r0.y, -clamp_abs), clamp_abs),
+                             fminf(fmaxf(r1.x, -clamp_abs), clamp_abs), fminf(fmaxf(r1.y, -clamp_abs), clamp_abs)};
         float v[4], mu = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -158,10 +161,11 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
 }
 
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap em, const float* pos, MaskEmbedWeights w,
-                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s) {
+                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s) {
     if (P <= 0) return nullptr;
     if (em.div <= 0) return "mask_embed_src: XMap.div must be positive";
-    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(((P + ME_NP - 1) / ME_NP) * 64), dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf);
+    if (!(clamp_abs > 0.f)) clamp_abs = 3.0e38f;
+    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(((P + ME_NP - 1) / ME_NP) * 64), dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs);
     return nullptr;
 }
 
@@ -347,20 +351,6 @@ const char* launch_mask_dot(const bf16_t* up, const float* hyper, int P, float* 
 }
 
 // dynamic multimask: counts of mask0 > +delta, > -delta
-__global__ __launch_bounds__(256) void stab_count_kernel(const float* __restrict__ masks4, int* __restrict__ counts, float delta) {
-    const int p = blockIdx.y;
-    const float* m0 = masks4 + (int64_t)p * 4 * 65536;
-    int a = 0, u = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < 65536; i += gridDim.x * 256) {
-        const float v = m0[i];
-        a += v > delta;
-        u += v > -delta;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); u += __shfl_xor(u, o, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[2 * p], a); atomicAdd(&counts[2 * p + 1], u); }
-}
-
 __global__ __launch_bounds__(256) void mask_select_kernel(const float* __restrict__ masks4, const float* __restrict__ iou4, int multimask,
                                                           float* __restrict__ out_masks, float* __restrict__ out_iou,
                                                           const int* __restrict__ counts, float thresh) {
@@ -387,14 +377,52 @@ __global__ __launch_bounds__(256) void mask_select_kernel(const float* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0) out_iou[p] = iou4[p * 4 + sel];
 }
 
+// multimask_output=False (the m2m pass): stability of the single-mask output decides between it and the best of the three
+// multimask outputs (_dynamic_multimask_via_stability, delta 0.05 / threshold 0.98).  One block per prompt: count, decide, copy
+// the chosen 256x256 plane - one launch and one pass over mask 0 (L2-hot for the copy) instead of memset + count + select.
+__global__ __launch_bounds__(1024) void mask_select_dynamic_kernel(const float* __restrict__ masks4, const float* __restrict__ iou4,
+                                                                   float* __restrict__ out_masks, float* __restrict__ out_iou, float delta, float thresh) {
+    __shared__ int red[2][16];
+    __shared__ int sel_s;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const float4* m0 = reinterpret_cast<const float4*>(masks4 + (int64_t)p * 4 * 65536);
+    int a = 0, u = 0;
+#pragma unroll 4
+    for (int i = tid; i < 16384; i += 1024) {
+        const float4 v = m0[i];
+        a += (v.x > delta) + (v.y > delta) + (v.z > delta) + (v.w > delta);
+        u += (v.x > -delta) + (v.y > -delta) + (v.z > -delta) + (v.w > -delta);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); u += __shfl_xor(u, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = u; }
+    __syncthreads();
+    if (tid == 0) {
+        int ai = 0, au = 0;
+        for (int w = 0; w < 16; ++w) { ai += red[0][w]; au += red[1][w]; }
+        const float stab = au > 0 ? (float)ai / (float)au : 1.0f;
+        int sel = 0;
+        if (!(stab >= thresh)) {
+            sel = 1;
+            float best = iou4[p * 4 + 1];
+            if (iou4[p * 4 + 2] > best) { best = iou4[p * 4 + 2]; sel = 2; }
+            if (iou4[p * 4 + 3] > best) { best = iou4[p * 4 + 3]; sel = 3; }
+        }
+        sel_s = sel;
+        out_iou[p] = iou4[p * 4 + sel];
+    }
+    __syncthreads();
+    const float4* src = m0 + (int64_t)sel_s * 16384;
+    float4* dst = reinterpret_cast<float4*>(out_masks + (int64_t)p * 65536);
+#pragma unroll 4
+    for (int i = tid; i < 16384; i += 1024) dst[i] = src[i];
+}
+
 const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,
                                int* counts_ws, hipStream_t s) {
     if (P <= 0) return nullptr;
-    if (!multimask) {
-        hipMemsetAsync(counts_ws, 0, sizeof(int) * 2 * P, s);
-        hipLaunchKernelGGL(stab_count_kernel, dim3(16, P), dim3(256), 0, s, masks4, counts_ws, 0.05f);
-    }
-    hipLaunchKernelGGL(mask_select_kernel, dim3(16, P), dim3(256), 0, s, masks4, iou4, multimask, out_masks, out_iou, counts_ws, 0.98f);
+    if (!multimask) hipLaunchKernelGGL(mask_select_dynamic_kernel, dim3(P), dim3(1024), 0, s, masks4, iou4, out_masks, out_iou, 0.05f, 0.98f);
+    else hipLaunchKernelGGL(mask_select_kernel, dim3(16, P), dim3(256), 0, s, masks4, iou4, multimask, out_masks, out_iou, counts_ws, 0.98f);
     return nullptr;
 }
 

@@ -136,8 +136,9 @@ int eng_fail(saber_engine* e, int code, const std::string& msg);
 int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crops_host, int n, int slot0, hipStream_t s);
 // per_slot > 0: the prompts span consecutive slots, per_slot prompts each (crops of one AMG layer decoded in one batch);
 // per_slot = 0: all n prompts read slot `slot`.
+// mask_clamp > 0: the mask prompt is clamped to +-mask_clamp as it is read (SAM2ImagePredictor clamps the logits it returns to +-32)
 int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
-               const float* mask_in_dev, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s);
+               const float* mask_in_dev, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s);
 template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count);
 int eng_alloc_bytes(saber_engine* e, void** p, size_t bytes);
 void eng_free(saber_engine* e, void* p);

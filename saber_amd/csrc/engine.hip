@@ -750,7 +750,7 @@ static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
 // One chunk of P prompts.  The prompts may span several consecutive slots (crops of one AMG layer batched together): prompt p of
 // the chunk reads the features of slot slot0 + (p_base + p) / per_slot.
 static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, int multimask,
-                        const float* mask_in, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+                        const float* mask_in, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
     const int T = 8;
     const int PT = P * T;
     const size_t o256 = (size_t)slot0 * 4096 * 256;
@@ -769,7 +769,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         for (int sl = slot0 + p_base / per_slot; sl <= slot_last; ++sl) TRY(ensure_shared(e, sl, s));
         X = e->src0_bf + o256; xm = slots;
     } else {
-        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, slots, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, slots, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, mask_clamp, s));
         X = e->keys_bf; xm = per_prompt;
     }
 
@@ -857,7 +857,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
 }
 
 int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
-               const float* mask_in_dev, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+               const float* mask_in_dev, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
     if (!pts_dev || n < 0 || per_slot < 0) return eng_fail(e, SABER_ERR_INVALID, "decode: bad argument");
     if (per_slot == 0 || per_slot > n) per_slot = n > 0 ? n : 1;      // every prompt reads slot `slot`
@@ -868,7 +868,7 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
     for (int p0 = 0; p0 < n; p0 += e->max_prompts) {
         const int P = std::min(e->max_prompts, n - p0);
         TRY(decode_chunk(e, slot, per_slot, p0, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
-                         mask_in_dev ? mask_in_dev + (size_t)p0 * 65536 : nullptr,
+                         mask_in_dev ? mask_in_dev + (size_t)p0 * 65536 : nullptr, mask_clamp,
                          out_lowres ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
                          out_obj ? out_obj + p0 : nullptr, s));
     }
@@ -880,7 +880,7 @@ extern "C" int saber_decode_points(saber_engine* e, int slot, const float* pts_d
                                    const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream) {
     if (!e) return SABER_ERR_INVALID;
     ENG_HIP(e, hipSetDevice(e->device));
-    return eng_decode(e, slot, 0, pts_dev, labels_dev, n, multimask, mask_in_dev, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
+    return eng_decode(e, slot, 0, pts_dev, labels_dev, n, multimask, mask_in_dev, 0.f, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ label plane

@@ -83,7 +83,7 @@ struct MaskEmbedWeights {
 // launch, `div` consecutive prompts per crop (slot): {slot stride, div, index of the launch's first prompt within the batch}.
 struct XMap { int64_t stride; int div; int off; };
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap emb_map, const float* pos, MaskEmbedWeights w,
-                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, hipStream_t s);
+                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s);   // clamp_abs > 0: mask_in is clamped to +-clamp_abs on load
 
 // fp32 multi-head attention for the two-way transformer.  q [B][nq][heads*hd], k/v [B or 1][nk][heads*hd].
 // Output is bf16 (it always feeds the out_proj GEMM).
