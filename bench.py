@@ -170,6 +170,16 @@ def main():
                        "masks_per_slice": n_masks / max(1, a.steps), "algorithmic_tflop_per_slice": alg_flops_slice / 1e12},
             "achieved_tflops_algorithmic": alg_flops_slice * world * a.steps / dt / 1e12,
         }
+    if rank == 0:
+        # the stitch that follows the gather (utils.separate_masks, propagation.py:189) on the device; reported beside the metric, not in it
+        vol = (gathered if world > 1 else planes).view(torch.int16)
+        eng.separate_masks(vol, 100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, n_lab = eng.separate_masks(vol, 100)
+        torch.cuda.synchronize()
+        out["stitch"] = {"what": "3-D connected components of the gathered label planes on rank 0's GPU (saber_separate_masks)",
+                         "slices": int(vol.shape[0]), "ms": (time.perf_counter() - t0) * 1e3, "labels": n_lab}
     if rank == 0 and world == 1 and not a.no_profile:
         eng.profile_begin()
         step(0)

@@ -118,6 +118,14 @@ int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, const int* orde
  * remove_duplicate_masks' IoU (saber/segmenters/utils.py:21-29); IoU = inter / (area_i + area_j - inter). */
 int saber_mask_pair_intersections(saber_engine* e, const uint32_t* bits_dev, int n, int H, int W, int32_t* out_inter_dev, void* stream);
 
+/* 3-D connected components of the stitched label volume (replaces saber.segmenters.utils.separate_masks,
+ * saber/segmenters/utils.py:88-131, the last step of propagationSegmenter.slice_by_slice, propagation.py:189): foreground =
+ * plane value != 0, 26-connectivity, components below min_mask_area * 10 voxels dropped (utils.py:113-119), survivors numbered
+ * 1..K in scipy.ndimage.label's order.  planes_dev: (Z,H,W) uint16, out_dev: (Z,H,W) uint32, both on the engine's device;
+ * Z*H*W < 2^31.  Synchronises the stream (the label count is returned). */
+int saber_separate_masks(saber_engine* e, const uint16_t* planes_dev, int Z, int H, int W, int min_mask_area, uint32_t* out_dev,
+                         int* out_n_labels, void* stream);
+
 /* Per-launch HIP-event profiling of the engine's own kernels, by kernel class (events are recorded on the
  * stream the kernels are launched on).  Class order: 0 gemm_bf16, 1 hiera_attention, 2 layernorm,
  * 3 decoder_attention, 4 elementwise, 5 image_ops, 6 mask_post, 7 decoder_t2i, 8 decoder_i2t, 9 decoder_upscale.  flops / bytes are ALGORITHMIC. */

@@ -145,6 +145,16 @@ class Engine:
         self._check(self.lib.saber_mask_pair_intersections(self.h, _ptr(bits) if n else None, n, H, W, _ptr(inter) if n else None, _stream()))
         return inter
 
+    def separate_masks(self, planes: torch.Tensor, min_mask_area: int = 100):
+        """utils.separate_masks on the device.  planes: (Z,H,W) uint16 / int16 device tensor of per-slice label planes.
+        Returns ((Z,H,W) int32 device tensor holding the uint32 labels, number of labels)."""
+        assert planes.is_cuda and planes.dim() == 3 and planes.is_contiguous() and planes.dtype in (torch.uint16, torch.int16)
+        Z, H, W = planes.shape
+        out = torch.empty((Z, H, W), dtype=torch.int32, device=planes.device)
+        n = C.c_int(0)
+        self._check(self.lib.saber_separate_masks(self.h, _ptr(planes), Z, H, W, int(min_mask_area), _ptr(out), C.byref(n), _stream()))
+        return out, n.value
+
     def profile_begin(self):
         self._check(self.lib.saber_profile_begin(self.h))
 

@@ -55,10 +55,11 @@ def shard_bounds(Z: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def segment_volume_sharded(volume, slice_fn: Callable[[int], torch.Tensor], stitch: bool = True, min_mask_area: int = 100,
-                           group=None) -> Optional[np.ndarray]:
+                           group=None, engine=None) -> Optional[np.ndarray]:
     """Slice-parallel slice_by_slice.  `volume` only supplies the shape (Z,H,W); `slice_fn(z)` returns the uint16
     label plane of slice z as a tensor on this rank's device.  All ranks receive every plane (all_gather of equal,
-    zero-padded chunks); the (Z,H,W) uint32 stitched labels are returned (reference: utils.separate_masks)."""
+    zero-padded chunks); the (Z,H,W) uint32 stitched labels are returned (reference: utils.separate_masks).  With `engine`
+    given and the planes on its device the stitch runs there (saber_separate_masks, bit-identical to the host path)."""
     import torch.distributed as dist
     Z, H, W = volume.shape
     dist_on = dist.is_available() and dist.is_initialized()
@@ -83,6 +84,14 @@ def segment_volume_sharded(volume, slice_fn: Callable[[int], torch.Tensor], stit
         dist.all_gather_into_tensor(full.view(torch.uint8), local.view(torch.uint8), group=group)
     else:
         full = local
+    if stitch and engine is not None and full.is_cuda:
+        parts = []
+        for r in range(world):
+            a, b = shard_bounds(Z, world, r)
+            parts.append(full[r * chunk: r * chunk + (b - a)])
+        planes_dev = parts[0] if world == 1 and parts[0].shape[0] == Z else torch.cat(parts, 0)
+        labels, _ = engine.separate_masks(planes_dev.contiguous(), min_mask_area=min_mask_area)
+        return labels.cpu().numpy().view(np.uint32)
     planes = np.empty((Z, H, W), dtype=np.uint16)
     full_np = full.cpu().numpy().view(np.uint16)
     for r in range(world):
