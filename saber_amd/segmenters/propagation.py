@@ -88,4 +88,4 @@ class propagationSegmenter(saber3D):
                                               remove_repeating_masks=self.remove_repeating_masks)
             return plane
 
-        return segment_volume_sharded(volume, one, stitch=stitch)
+        return segment_volume_sharded(volume, one, stitch=stitch, engine=eng)   # 3-D CC on the device (saber_separate_masks)

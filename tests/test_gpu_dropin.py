@@ -1,0 +1,61 @@
+"""GPU: the drop-in boundary.  The reference's own call shapes - get_adapter(SAM2AdapterConfig) ->
+BaseAdapter.segment_image_2d, saber2D.segment_image, propagationSegmenter.slice_by_slice - run on the HIP engine, and the
+device-resident z-loop (slice_by_slice_device: bit-packed masks, label planes painted on the device, 3-D CC on the device)
+returns the identical uint32 label volume as the reference-shaped loop over numpy dict lists."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def segmenter():
+    import os
+    os.environ["SABER_AMD_SEEDED_WEIGHTS"] = "1"               # no checkpoint offline: deterministic synthetic weights
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.segmenters.propagation import propagationSegmenter
+    # thresholds low enough that the seeded (untrained) decoder's masks survive the AMG filters; the reference's default trunk
+    amg = cfgAMG(npoints=8, crop_n_layers=1, pred_iou_thresh=0.2, stability_score_thresh=0.3, sam2_cfg="small")
+    cfg = SAM2AdapterConfig(cfg="small", amg_cfg=amg, min_mask_area=50)
+    return propagationSegmenter(deviceID=0, cfg=cfg, min_mask_area=50)
+
+
+def _volume(Z=3, S=384):
+    rng = np.random.default_rng(11)
+    vol = rng.normal(32768, 3000, (Z, S, S))
+    zz, yy, xx = np.mgrid[:Z, :S, :S]
+    for _ in range(9):
+        cy, cx, r = rng.integers(40, S - 40, 2).tolist() + [int(rng.integers(15, 60))]
+        vol[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] += rng.choice([-6000, 6000])
+    return np.clip(vol, 0, 65535).astype(np.float32)
+
+
+def test_adapter_contract(segmenter):
+    from saber_amd.adapters.base import BaseAdapter
+    ad = segmenter.adapter
+    assert isinstance(ad, BaseAdapter)
+    masks = ad.segment_image_2d(_volume()[0])
+    assert isinstance(masks, list) and len(masks) > 0
+    m = masks[0]
+    for k in ("segmentation", "area", "bbox", "predicted_iou", "point_coords", "stability_score", "crop_box"):
+        assert k in m, k
+    assert m["segmentation"].dtype == bool and m["segmentation"].shape == (384, 384) and m["area"] == int(m["segmentation"].sum())
+    ys, xs = np.where(m["segmentation"])
+    assert list(m["bbox"]) == [xs.min(), ys.min(), xs.max() - xs.min(), ys.max() - ys.min()]
+    for name in ("set_volume", "segment_volume", "propagate_in_video", "add_new_mask", "reset_state"):
+        assert hasattr(ad, name)
+    with pytest.raises(RuntimeError, match="set_volume"):          # reference error behaviour (predictor.py:251-257)
+        ad.segment_volume(0, [], (3, 384, 384))
+    with pytest.raises(NotImplementedError):                       # video propagation is a 'next' row: loud, not silent
+        ad.set_volume(_volume())
+
+
+def test_slice_loop_device_equals_reference_shaped_loop(segmenter):
+    vol = _volume()
+    ref = segmenter.slice_by_slice(vol)                            # dict lists on the host, numpy paint loop, host 3-D CC
+    dev = segmenter.slice_by_slice_device(vol)                     # everything on the device
+    assert ref.dtype == np.uint32 and dev.dtype == np.uint32 and ref.shape == vol.shape
+    assert ref.max() > 0, "no component survived: the test volume / thresholds no longer exercise the path"
+    assert np.array_equal(ref, dev)
