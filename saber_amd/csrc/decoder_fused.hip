@@ -370,21 +370,29 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
 // 8 waves: wave = (row tile rt) * 4 + (quarter qr).  Per tile: GEMM1 -> softmax -> P via LDS -> GEMM2 -> residual +
 // LayerNorm (row statistics exchanged through LDS) -> bf16 rows.  Normalisation of tile t is deferred until after the
 // barrier of tile t+1, so each tile costs ONE workgroup barrier.
-#define I2T_ROWS 32
+// RT = 16-row tiles per workgroup (4 waves each).  RT = 1: 4-wave workgroups of 62 KB LDS, TWO per CU: they share no barrier, drift
+// apart, and one's MFMA phases overlap the other's softmax / LayerNorm / store phases (RT = 2, one 8-wave workgroup per CU, keeps
+// both halves of a SIMD in the same phase all the time).
 #define I2T_PEQ_ROWB 256                          // one PEQ row: 128 bf16
-#define I2T_STAGE (I2T_ROWS * ROW_B + I2T_ROWS * I2T_PEQ_ROWB)   // X tile (16 KB) + PEQ tile (8 KB)
 #define I2T_NSTAGE 4
 #define I2T_PSTRIDE 144                           // bytes per P row (64 bf16 + pad)
-#define I2T_PBUF_B (2 * 16 * I2T_PSTRIDE)           // one P buffer: [2 row tiles][16 rows][144 B]
-#define I2T_STAT_B (2 * 16 * 4 * 2 * 4)             // one statistics buffer: [2 row tiles][16 rows][4 quarters][sum, sumsq]
-#define I2T_OSCR_B (8 * 2048)                       // per wave: 16 rows x 128 B of the output tile, transposed into full-line stores
-#define I2T_LDS (I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B + I2T_OSCR_B)
+template <int RT> struct I2TCfg {
+    static constexpr int ROWS = 16 * RT;
+    static constexpr int STAGE = ROWS * ROW_B + ROWS * I2T_PEQ_ROWB;   // X tile + PEQ tile
+    static constexpr int PBUF_B = RT * 16 * I2T_PSTRIDE;                // one P buffer: [RT][16 rows][144 B]
+    static constexpr int STAT_B = RT * 16 * 4 * 2 * 4;                  // one statistics buffer: [RT][16 rows][4 quarters][sum, sumsq]
+    static constexpr int OSCR_B = 4 * RT * 2048;                        // per wave: 16 rows x 128 B of the output tile, transposed into full-line stores
+    static constexpr int LDS = I2T_NSTAGE * STAGE + 2 * PBUF_B + 2 * STAT_B + OSCR_B;
+};
 
-__global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
+template <int RT>
+__global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
                                                       const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
                                                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                       bf16_t* __restrict__ Xout, int nsplit, int dbg, unsigned long long* __restrict__ stamps) {
+    using CF = I2TCfg<RT>;
+    constexpr int I2T_ROWS = CF::ROWS, I2T_STAGE = CF::STAGE, I2T_PBUF_B = CF::PBUF_B, I2T_STAT_B = CF::STAT_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // development only (stamps != nullptr): per-wave cycle sums of the phases of the tile loop, see tools/dec_stamps.py
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -585,19 +593,22 @@ __global__ __launch_bounds__(512) void dec_i2t_kernel(const bf16_t* __restrict__
     __builtin_amdgcn_s_barrier();
     finish_tile(NT - 1);
     if (stamps && lane == 0)
-        for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
+        for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * (4 * RT) + wave) * 6 + k] = ts[k];
 }
 
 const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* VtT,
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s) {
     if (P <= 0) return nullptr;
     int nsplit = 1;
-    while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's 128 tiles over several blocks
+    while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's tiles over several blocks
     extern int g_saber_debug_flags;
     if (g_saber_debug_flags >> 8) nsplit = g_saber_debug_flags >> 8;
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
-    hipLaunchKernelGGL(dec_i2t_kernel, dim3(P * nsplit), dim3(512), I2T_LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, g_saber_debug_flags & 255, g_saber_stamp_buf);
+    if (g_saber_debug_flags & 1)
+        hipLaunchKernelGGL(dec_i2t_kernel<2>, dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+    else
+        hipLaunchKernelGGL(dec_i2t_kernel<1>, dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
     return nullptr;
 }
 
@@ -806,7 +817,8 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
 
 const char* decoder_fused_init_device() {
     hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2I_LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, I2T_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }

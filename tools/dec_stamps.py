@@ -13,16 +13,18 @@ pp = bf(torch.randn(4096, 128, device="cuda", generator=g)); tproj = torch.randn
 Kt = bf(torch.randn(P, 64, 256, device="cuda", generator=g) * 0.05); cb = torch.randn(P, 64, device="cuda", generator=g)
 VtT = bf(torch.randn(P, 256, 64, device="cuda", generator=g)); bo = torch.randn(256, device="cuda", generator=g)
 ga = torch.ones(256, device="cuda"); be = torch.zeros(256, device="cuda"); out = torch.empty_like(X)
+RT = 2 if int(os.environ.get("DBG", "0"), 0) & 1 else 1
+lib.saber_k_set_debug(int(os.environ.get("DBG", "0"), 0))
 st = torch.zeros(P * 8 * 6, dtype=torch.int64, device="cuda")
 call = lambda: lib.saber_k_dec_i2t(ptr(X), 4096 * 256, ptr(pp), ptr(Kt), ptr(tproj), 0.3, ptr(cb), ptr(VtT), ptr(bo), ptr(ga), ptr(be), 1e-5, ptr(out), P, None)
 for _ in range(3): call()
 lib.saber_k_set_stamp_buffer(ptr(st)); call(); torch.cuda.synchronize(); lib.saber_k_set_stamp_buffer(None)
-s = st.view(P, 8, 6).double().cpu() / 128.0   # per tile
+s = st[:P * 4 * RT * 6].view(P, 4 * RT, 6).double().cpu() / (4096.0 / (16 * RT))   # per tile
 names = ["gemm1+softmax+Pwrite", "vmcnt wait", "barrier", "issue DMA", "finish_tile(t-1)+stores", "gemm2+residual+stats"]
 print("cycles per tile (s_memtime ticks), mean over blocks; per wave:")
 for k, n in enumerate(names):
-    print(f"  {n:28s} " + " ".join(f"{s[:, w, k].mean():7.0f}" for w in range(8)) + f"   | all {s[:, :, k].mean():7.0f}")
-print("  total per tile", s.sum(-1).mean().item())
+    print(f"  {n:28s} " + " ".join(f"{s[:, w, k].mean():7.0f}" for w in range(4 * RT)) + f"   | all {s[:, :, k].mean():7.0f}")
+print("  total per tile", s.sum(-1).mean().item(), f"(tiles of {16 * RT} rows)")
 # ---- t2i (64-key blocks, 64 per prompt)
 Qt = bf(torch.randn(P, 64, 256, device="cuda", generator=g) * 0.05)
 Wv = bf(torch.randn(128, 256, device="cuda", generator=g) / 16); bv = torch.randn(128, device="cuda", generator=g)
