@@ -560,14 +560,230 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
         }
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Global attention of Hiera-L (blocks 23, 33, 43: every image is ONE window of 4096 keys) and any other window whose key
+// count is a multiple of 256.  Same building blocks as the 256-key kernel - dense direct-to-LDS K/V images, 8 waves x 32
+// queries, asynchronous Q loads, inline-asm V^T reads - arranged as ONE CONTINUOUS STREAM of 128-key blocks through a
+// 3-stage ring: a task is (window, head, 256-query chunk), its key blocks follow each other in the stream and the first
+// blocks of the next task are already in flight while the current task finishes (online softmax across blocks, one raw
+// barrier per block).  The register-staged kernel above keeps 64 queries per workgroup, re-stages K/V through VGPRs with two
+// barriers per block and runs at ~340 TFLOP/s on this shape.
+#define ST_KB 128
+template <int HD>
+__global__ __launch_bounds__(512) void hiera_attn_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_windows, int nk, int heads) {
+    using TR = HdTraits<HD>;
+    constexpr int CK = TR::CK, DT = TR::DT;
+    constexpr int ROWB = HD * 2;                    // dense row
+    constexpr int KBYTES = ST_KB * ROWB;            // 18 KB for HD = 72
+    constexpr int NPIECE = 2 * KBYTES / 1024;       // 1-KB pieces of one stream item (K image then V image)
+    constexpr int PPW = (NPIECE + 7) / 8;           // pieces per wave (the surplus ones repeat the last piece: same bytes, same place)
+    constexpr int STAGE = 2 * KBYTES + 256;         // + slack for the over-reads behind V's last rows
+    constexpr int NQL = 2 * CK;                     // Q loads per wave and task
+    static_assert((2 * KBYTES) % 1024 == 0, "K/V image must split into whole 1-KB pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fg = lane >> 4;
+    const int chunks = nk / 256, nkb = nk / ST_KB;
+    // tasks of this XCD (blocks b, b + 8, ... share an L2): with one chunk per (window, head) the heads of a window stay together
+    // (their 144-B slices share 128-B lines); with several chunks all chunks of a (window, head) pair do (they share its K/V)
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const int npairs = n_windows * heads;
+    const int nloc = chunks == 1 ? (n_windows > xcd ? (n_windows - xcd + 7) >> 3 : 0) * heads : (npairs > xcd ? (npairs - xcd + 7) >> 3 : 0);
+    const int ntask = nloc * chunks;
+    if (j0 >= ntask) return;
+    const int64_t rs = 3 * (int64_t)heads * HD;
+    const int64_t os = (int64_t)heads * HD;
+    const int q0 = wave * 32;
+    if (tid < 48) reinterpret_cast<uint4*>(smem + (tid >> 4) * STAGE + 2 * KBYTES)[tid & 15] = make_uint4(0, 0, 0, 0);
+
+    auto task_of = [&](int t, int* h, int* qbase) -> int64_t {      // first token of the task's window, head, first query of the chunk
+        const int ul = t / chunks, c = t - ul * chunks;
+        int w;
+        if (chunks == 1) { const int wl = ul / heads; *h = ul - wl * heads; w = wl * 8 + xcd; }
+        else { const int u = ul * 8 + xcd; w = u / heads; *h = u - w * heads; }
+        *qbase = c * 256;
+        return (int64_t)w * nk;
+    };
+    auto issue_item = [&](int64_t tok0, int h, int kb, int stage) {
+        char* buf = smem + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int piece = min(wave + 8 * j, NPIECE - 1);
+            const int o = (piece * 1024 + lane * 16) % KBYTES;
+            const int row = o / ROWB, ch = (o - row * ROWB) >> 4;
+            const bf16_t* src = qkv + (tok0 + kb * ST_KB + row) * rs + h * HD + ch * 8 + (piece * 1024 < KBYTES ? os : 2 * os);
+            __builtin_amdgcn_global_load_lds((gptr_a)src, (lptr_a)(buf + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto q_issue = [&](int64_t tok0, int h, int qbase, u32x4 (&q)[2][CK]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const int hdoff = 32 * c + 8 * fg;
+                const bf16_t* src = qkv + (tok0 + qbase + q0 + 16 * t + fi) * rs + h * HD + (hdoff < HD ? hdoff : 0);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[t][c]) : "v"(src) : "memory");
+            }
+    };
+    // issue cursor
+    int ti = j0, kbi = 0, hi, qbi;
+    int64_t toki = task_of(ti, &hi, &qbi);
+    int si = 0;
+    u32x4 qraw[2][CK];
+    // ops (this wave) of the stream items in flight, oldest first: PPW, or PPW + NQL for the first block of a task
+    int n1 = 0, n2 = 0;                               // items i+1 and i+2 relative to the item being computed
+    auto issue_next = [&]() -> int {                  // issue the item under the cursor, advance, return its op count (0 if the stream has ended)
+        if (ti >= ntask) return 0;
+        issue_item(toki, hi, kbi, si);
+        int ops = PPW;
+        if (kbi == 0) { q_issue(toki, hi, qbi, qraw); ops += NQL; }
+        si = si == 2 ? 0 : si + 1;
+        if (++kbi == nkb) { kbi = 0; ti += nj; if (ti < ntask) toki = task_of(ti, &hi, &qbi); }
+        return ops;
+    };
+    auto wait_younger = [&](int younger) {            // all operations except the `younger` most recent ones have completed
+        if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == PPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else if (younger == PPW + NQL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + NQL) : "memory");
+        else if (younger == 2 * PPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (younger == 2 * PPW + NQL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW + NQL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // not reachable (a task has >= 2 blocks): stay safe
+    };
+    // compute cursor
+    int tc = j0, kbc = 0, hc, qbc, sc_ = 0;
+    int64_t tokc = task_of(tc, &hc, &qbc);
+    (void)issue_next();                               // item 0 (with the first task's Q)
+    n1 = issue_next();                                // item 1
+    wait_younger(n1);
+    bf16x8 qc[2][CK];
+    float m[2], l[2];
+    f32x4 o[2][DT];
+    const float sc = TR::SCALE;
+    while (tc < ntask) {
+        // item (tc, kbc) has landed for this wave (wait at the end of the previous iteration); the barrier makes it visible to
+        // everyone and says every wave is done with the stage that is re-filled next
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kbc == 0) {                               // a new task starts: its Q fragments arrived together with its first block
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int c = 0; c < CK; ++c) {
+                    const u32x4 z4 = {0u, 0u, 0u, 0u};
+                    qc[t][c] = __builtin_bit_cast(bf16x8, (32 * c + 8 * fg) < HD ? qraw[t][c] : z4);
+                }
+                m[t] = -3.0e38f;
+                l[t] = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        n2 = issue_next();                            // item i + 2 into the stage of item i - 1
+        const char* kbase = smem + sc_ * STAGE;
+        const char* vbase = kbase + KBYTES;
+        {
+            f32x4 s[2][8];
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                bf16x8 kf[CK];
+#pragma unroll
+                for (int c = 0; c < CK; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(kbase + (16 * kt + fi) * ROWB + (4 * c + fg) * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
+                }
+            }
+            bf16x8 pf[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][kt][r]);
+                mx = xor32_max(xor16_max(mx));
+                const float mn = fmaxf(m[t], mx * sc);
+                const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+                m[t] = mn;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][kt][r], sc, -mn));
+                        s[t][kt][r] = e;
+                        sum += e;
+                    }
+                sum = xor32_sum(xor16_sum(sum));
+                l[t] = l[t] * alpha + sum;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    pf[t][ks] = pack8(s[t][2 * ks][0], s[t][2 * ks][1], s[t][2 * ks][2], s[t][2 * ks][3], s[t][2 * ks + 1][0],
+                                      s[t][2 * ks + 1][1], s[t][2 * ks + 1][2], s[t][2 * ks + 1][3]);
+            }
+            const uint32_t va = (uint32_t)(uintptr_t)(lptr_a)vbase + (4 * fg + (fi >> 2)) * ROWB + 8 * (fi & 3);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                u32x2 lo[4], hi2[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[ks]) : "v"(va + 32 * ks * ROWB + 32 * dt) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi2[ks]) : "v"(va + (32 * ks + 16) * ROWB + 32 * dt) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 vf = cat4(__builtin_bit_cast(bf16x4, lo[ks]), __builtin_bit_cast(bf16x4, hi2[ks]));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
+                }
+            }
+        }
+        // the next item must have landed before the next barrier; the one after it (and its Q loads) may stay in flight.  The wait
+        // precedes the output stores of a finished task so that they are not waited for here.
+        wait_younger(n2);
+        n1 = n2;
+        sc_ = sc_ == 2 ? 0 : sc_ + 1;
+        if (++kbc == nkb) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float inv = __builtin_amdgcn_rcpf(l[t]);
+                const int row = qbc + q0 + 16 * t + fi;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int d = 16 * dt + 4 * fg;
+                    if (d < HD)
+                        *reinterpret_cast<uint2*>(out + (tokc + row) * os + hc * HD + d) =
+                            make_uint2(pack_bf16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_bf16(o[t][dt][2] * inv, o[t][dt][3] * inv));
+                }
+            }
+            kbc = 0;
+            tc += nj;
+            if (tc < ntask) tokc = task_of(tc, &hc, &qbc);
+        }
+    }
+}
+#define STREAM_LDS(HD) (3 * (2 * ST_KB * (HD) * 2 + 256))
+
 #define WIN256_LDS(HD) (2 * (2 * 256 * (HD) * 2 + 256))
 
 template <int HD> static hipError_t attn_attrs() {
     constexpr int lds = K_LDS_BYTES + KB * HdTraits<HD>::VSTRIDE;
     hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_large_kernel<1, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if constexpr (WIN256_LDS(HD) <= 160 * 1024)
+    if constexpr (WIN256_LDS(HD) <= 160 * 1024) {
         if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_win256_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN256_LDS(HD));
+        if constexpr (HD == 72)
+            if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(hiera_attn_stream_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS(HD));
+    }
     return st;
 }
 
@@ -591,9 +807,15 @@ static const char* launch_hd(const bf16_t* qkv, bf16_t* out, int n_windows, int 
     if (q_pool && (nk & 3)) return "hiera_attention: q_pool needs nk % 4 == 0";
     const int nq = q_pool ? nk / 4 : nk;
     extern int g_saber_debug_flags;
-    if constexpr (WIN256_LDS(HD) <= 160 * 1024) if (nk == 256 && !q_pool && !kmask && !(g_saber_debug_flags & 32)) {
+    if constexpr (WIN256_LDS(HD) <= 160 * 1024) if (nk == 256 && !q_pool && !kmask && !(g_saber_debug_flags & (32 | 2))) {
         const int tasks_per_xcd = ((n_windows + 7) / 8) * heads;       // persistent: one workgroup per CU, fewer when there is less work
         hipLaunchKernelGGL((hiera_attn_win256_kernel<HD>), dim3(8 * (tasks_per_xcd < 32 ? tasks_per_xcd : 32)), dim3(512), WIN256_LDS(HD), s, qkv, out, n_windows, heads);
+        return nullptr;
+    }
+    if constexpr (HD == 72) if (nk >= 256 && (nk % 256) == 0 && !q_pool && !kmask && !(g_saber_debug_flags & 32)) {
+        const int chunks = nk / 256;
+        const int loc = ((n_windows * heads + 7) / 8) * chunks;          // tasks of the busiest XCD
+        hipLaunchKernelGGL((hiera_attn_stream_kernel<HD>), dim3(8 * (loc < 32 ? loc : 32)), dim3(512), STREAM_LDS(HD), s, qkv, out, n_windows, nk, heads);
         return nullptr;
     }
     constexpr int lds = K_LDS_BYTES + KB * HdTraits<HD>::VSTRIDE;

@@ -136,6 +136,7 @@ def ref_hiera_attention(qkv, n_windows, nk, heads, q_pool, hd=72, key_mask=None)
 
 @pytest.mark.parametrize("n_windows,nk,heads,q_pool", [
     (9, 64, 2, 0), (5, 64, 4, 1), (33, 16, 4, 0), (7, 16, 8, 1), (3, 256, 8, 0), (2, 256, 16, 1), (1, 4096, 8, 0), (2, 128, 2, 0),
+    (3, 512, 4, 0), (11, 1024, 2, 0), (21, 256, 8, 0), (2, 4096, 3, 0),   # streaming kernel: several tasks per block, chunked queries
 ])
 def test_hiera_attention(gpu_lib, n_windows, nk, heads, q_pool):
     g = torch.Generator().manual_seed(nk + heads)
