@@ -43,6 +43,7 @@ const char* launch_prompt_tokens(const float* pts, const int* labels, int P, Pro
 // token computes the 16-channel hidden vector from its 4x4 logit patch; phase 2, thread d produces channel d
 // of every token (coalesced 512-B rows).
 #define ME_NP 8
+template <bool MFMA2>
 __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
                                                              const float* __restrict__ image_embed_base, XMap em, const float* __restrict__ pos,
                                                              MaskEmbedWeights w, float* __restrict__ src_f,
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
     // one block = 64 tokens x ME_NP consecutive prompts: the image-embedding rows (fp32, shared by every prompt of the crop) are
     // read once per block instead of once per prompt
     __shared__ __attribute__((aligned(16))) float h2s[ME_NP][64][20];
+    __shared__ __attribute__((aligned(16))) char oscr[MFMA2 ? 4 * 8192 : 16];   // MFMA2: per wave 16 token rows x 512 B for the full-line stores
     const int tid = threadIdx.x;
     const int pg = blockIdx.x >> 6, tok0 = (blockIdx.x & 63) * 64;
     const int p0 = pg * ME_NP, np = min(ME_NP, P - p0);
@@ -117,6 +119,64 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
         *reinterpret_cast<float4*>(&h2s[pi][tl][4 * q]) = o;
     }
     __syncthreads();
+    if constexpr (MFMA2) {
+        // phase 2 on the matrix cores (only the bf16 src is wanted): the 1x1 conv 16 -> 256 is [16 tokens] x [256] over k = 16 (zero-
+        // padded to 32) = 16 MFMAs per wave, token group and prompt, instead of 64 FMAs per 8 bytes of output on the VALU (which made
+        // this kernel VALU-bound at half the HBM write rate).  Wave w owns tokens 16 w .. 16 w + 15; W3 (bf16) and image_embed + b3
+        // stay in registers across the prompts; the tile leaves through LDS as full 512-B token rows (dwordx4).
+        const int lane = tid & 63, wv = tid >> 6, fi = lane & 15, fg = lane >> 4;
+        bf16x8 w3f[16];
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (fg < 2) {
+                const float4 a = *reinterpret_cast<const float4*>(w.w3 + (16 * nt + fi) * 16 + 8 * fg), b = *reinterpret_cast<const float4*>(w.w3 + (16 * nt + fi) * 16 + 8 * fg + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            }
+            const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            w3f[nt] = __builtin_bit_cast(bf16x8, u);
+        }
+        const int tok = tok0 + 16 * wv + fi;
+        float4 eb[16];
+        int cur_slot = -1;
+        char* my = oscr + wv * 8192;
+        for (int pi = 0; pi < np; ++pi) {
+            const int p = p0 + pi;
+            const int slot = (p + em.off) / em.div;
+            if (slot != cur_slot) {        // wave-uniform: prompts of a block share the crop unless the block straddles two crops
+                const float* ep = image_embed_base + (int64_t)slot * em.stride + (int64_t)tok * DEC_C;
+#pragma unroll
+                for (int nt = 0; nt < 16; ++nt) {
+                    const float4 e = *reinterpret_cast<const float4*>(ep + 16 * nt + 4 * fg), b3 = *reinterpret_cast<const float4*>(w.b3 + 16 * nt + 4 * fg);
+                    eb[nt] = make_float4(e.x + b3.x, e.y + b3.y, e.z + b3.z, e.w + b3.w);
+                }
+                cur_slot = slot;
+            }
+            float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (fg < 2) {
+                const float4 a = *reinterpret_cast<const float4*>(&h2s[pi][16 * wv + fi][8 * fg]), b = *reinterpret_cast<const float4*>(&h2s[pi][16 * wv + fi][8 * fg + 4]);
+                hv[0] = a.x; hv[1] = a.y; hv[2] = a.z; hv[3] = a.w; hv[4] = b.x; hv[5] = b.y; hv[6] = b.z; hv[7] = b.w;
+            }
+            const uint4 hu = make_uint4(pack_bf16(hv[0], hv[1]), pack_bf16(hv[2], hv[3]), pack_bf16(hv[4], hv[5]), pack_bf16(hv[6], hv[7]));
+            const bf16x8 hf = __builtin_bit_cast(bf16x8, hu);
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) {
+                const f32x4 z = {eb[nt].x, eb[nt].y, eb[nt].z, eb[nt].w};
+                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[nt], hf, z, 0, 0, 0);    // a[r] = src[token fi][channel 16 nt + 4 fg + r]
+                *reinterpret_cast<uint2*>(my + fi * 512 + (((2 * nt + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+            }
+            __builtin_amdgcn_wave_barrier();
+            bf16_t* dst = src_bf + ((int64_t)p * 4096 + tok0 + 16 * wv) * DEC_C;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 2 * j + (lane >> 5), chunk = lane & 31;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(my + row * 512 + ((chunk ^ (row & 15)) << 4));
+                *reinterpret_cast<u32x4*>(dst + row * DEC_C + chunk * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     // phase 2: thread = (4 consecutive channels, one of 4 token rows): one wave writes one whole 512-B token row per store
     const int c0 = (tid & 63) * 4, tr = tid >> 6;
     float w3[4][16];
@@ -165,7 +225,9 @@ const char* launch_mask_embed_src(const float* mask_in, int P, const float* imag
     if (P <= 0) return nullptr;
     if (em.div <= 0) return "mask_embed_src: XMap.div must be positive";
     if (!(clamp_abs > 0.f)) clamp_abs = 3.0e38f;
-    hipLaunchKernelGGL(mask_embed_src_kernel, dim3(((P + ME_NP - 1) / ME_NP) * 64), dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs);
+    const dim3 grid(((P + ME_NP - 1) / ME_NP) * 64);
+    if (!src_f && !srcpos_bf && src_bf) hipLaunchKernelGGL(mask_embed_src_kernel<true>, grid, dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs);
+    else hipLaunchKernelGGL(mask_embed_src_kernel<false>, grid, dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs);
     return nullptr;
 }
 
