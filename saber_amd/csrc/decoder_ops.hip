@@ -494,6 +494,9 @@ const char* launch_mask_select(const float* masks4, const float* iou4, int P, in
 // One block per (mask, band of 4 full-image rows); a wave covers 64 consecutive x of one row, so
 // __ballot gives two packed 32-bit words directly.  fp32 full-res logits never touch HBM.
 #define MP_ROWS 64   // output rows per block (16 per wave): one set of atomics per block, not per row
+// PRE: the horizontal taps (x0, weight) of every 64-pixel chunk depend on x alone; for W <= 1024 they are computed once per block
+// into registers instead of once per pixel, row and mask (they were half of the VALU work of the pixel loop)
+template <bool PRE>
 __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ lowres, const int* __restrict__ idx, int crop_x0,
                                                         int crop_y0, int crop_w, int crop_h, int H, int W, float thr, float offset,
                                                         uint32_t* __restrict__ bits, MaskStats* __restrict__ stats) {
@@ -506,6 +509,19 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
     const int W32 = (W + 31) >> 5;
     const float sy_scale = 256.0f / (float)crop_h, sx_scale = 256.0f / (float)crop_w;
     int area = 0, inter = 0, uni = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+    int x0a[16];
+    float lxa[16];
+    if (PRE) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int x = 64 * c + lane, cx = x - crop_x0;
+            float sx = ((float)cx + 0.5f) * sx_scale - 0.5f;
+            sx = fmaxf(sx, 0.f);
+            const int x0i = min((int)sx, 255);
+            x0a[c] = (x < W && cx >= 0 && cx < crop_w) ? x0i : -1;
+            lxa[c] = sx - (float)x0i;
+        }
+    }
     for (int r = 0; r < MP_ROWS / 4; ++r) {
         const int y = blockIdx.x * MP_ROWS + wave * (MP_ROWS / 4) + r;
         if (y >= H) break;  // wave-uniform
@@ -531,11 +547,22 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
         const float* vr = vrow[wave];
         unsigned long long mybits = 0ull;   // lane k keeps the 64-pixel chunk k (k + 64j for very wide images: flushed below)
         int rowarea = 0;
-        for (int xb = 0; xb < W; xb += 64) {
+#pragma unroll
+        for (int cc = 0; cc < (PRE ? 16 : 1); ++cc)
+        for (int xb = PRE ? 64 * cc : 0; xb < (PRE ? min(W, 64 * cc + 64) : W); xb += 64) {
             const int x = xb + lane;
             const int cx = x - crop_x0;
             bool on = false, hi = false, lo = false;
-            if (x < W && cx >= 0 && cx < crop_w) {
+            if (PRE) {
+                const int x0i = x0a[cc];
+                if (x0i >= 0) {
+                    const float lx = lxa[cc];
+                    const float v = (1.0f - lx) * vr[x0i] + lx * vr[min(x0i + 1, 255)];
+                    on = v > thr;
+                    hi = v > thr + offset;
+                    lo = v > thr - offset;
+                }
+            } else if (x < W && cx >= 0 && cx < crop_w) {
                 float sx = ((float)cx + 0.5f) * sx_scale - 0.5f;
                 sx = fmaxf(sx, 0.f);
                 const int x0i = min((int)sx, 255);
@@ -599,8 +626,9 @@ const char* launch_mask_post(const float* lowres, const int* idx, int n, int cro
     if (n <= 0) return nullptr;
     if (crop_w <= 0 || crop_h <= 0) return "mask_post: empty crop";
     hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, n);
-    hipLaunchKernelGGL(mask_post_kernel, dim3((H + MP_ROWS - 1) / MP_ROWS, n), dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr,
-                       offset, bits, stats);
+    const dim3 grid((H + MP_ROWS - 1) / MP_ROWS, n);
+    if (W <= 1024) hipLaunchKernelGGL(mask_post_kernel<true>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
+    else hipLaunchKernelGGL(mask_post_kernel<false>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
     return nullptr;
 }
 
