@@ -755,6 +755,221 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmParams p) {
         for (int k = 0; k < 6; ++k) p.stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
 }
 
+__global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
+    constexpr int A_BYTES = 256 * BK2 * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* epi_lds = smem + P2_NST * P2_STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves: rows 128 wm .., columns 64 wn ..
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int padded = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    const int64_t z = blockIdx.z;
+    const bf16_t* __restrict__ A = p.A + z * p.strideA;
+    const bf16_t* __restrict__ W = p.W + z * p.strideW;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int nk = (p.K + BK2 - 1) / BK2;
+
+    // one wave-instruction = 16 rows x 64 B; per K-tile 16 A pieces + 16 W pieces, 2 + 2 per wave
+    const int lrow = lane >> 2, lslot = lane & 3;
+    int prow[2], pchunk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        prow[i] = (wave * 2 + i) * 16 + lrow;
+        pchunk[i] = lslot ^ g2perm(prow[i]);
+    }
+    auto next_tile = [&](int L, int* tm, int* tn) {
+        while (L < padded && !tile_map(L, tiles_m, tiles_n, tm, tn)) L += gridDim.x;
+        return L;
+    };
+    int Li, tmi = 0, tni = 0, kti = 0, si = 0;
+    const bf16_t* asrc[2];
+    const bf16_t* wsrc[2];
+    auto set_issue_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            asrc[i] = A + (int64_t)min(tmi * 256 + prow[i], p.M - 1) * p.lda;
+            wsrc[i] = W + (int64_t)min(tni * 256 + prow[i], p.N - 1) * p.ldw;
+        }
+    };
+    // one K-tile = 4 pieces per wave (A0, W0, A1, W1); piece q of the issue cursor's K-tile, then advance() moves the cursor
+    auto issue_piece = [&](int q) {
+        char* sa = smem + si * P2_STAGE;
+        const int i = q >> 1;
+        const int k = kti * BK2 + pchunk[i] * 8;
+        if (q & 1) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + k), (lptr_t)(sa + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (k < p.K ? k : 0)), (lptr_t)(sa + (wave * 2 + i) * 1024), 16, 0, 0);   // K tail of A: any finite data, W supplies the zeros
+    };
+    auto advance = [&]() {
+        si = (si + 1) & (P2_NST - 1);
+        if (++kti == nk) {
+            kti = 0;
+            Li = next_tile(Li + gridDim.x, &tmi, &tni);
+            if (Li < padded) set_issue_tile();
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_piece(q);
+        advance();
+    };
+    Li = next_tile(blockIdx.x, &tmi, &tni);
+    if (Li >= padded) return;                      // block-uniform
+    set_issue_tile();
+    int Lc = Li, tmc = tmi, tnc = tni, ktc = 0, sc = 0;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 bias4[4];
+    auto load_bias = [&](int tn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tn * 256 + wn * 64 + j * 16 + fg * 4;
+            bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_bias(tnc);
+    auto wait_next = [&](int ahead) {               // all K-tiles older than the (ahead - 1) youngest ones have landed (4 DMAs per tile and wave)
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // STAGGERED: the two wave groups (rows 0-127: waves 0-3, rows 128-255: waves 4-7; wave w and w + 4 share a SIMD) run half an
+    // iteration apart.  In every half-step one group of each SIMD feeds the matrix core with the 32 MFMAs of its K-tile while the
+    // other one does the memory work - 12 fragment reads of the next K-tile and 4 LDS-DMA issues - behind them:
+    //     half-step 2t     : group 0  MFMA(t)                    | group 1  read(t), issue(t + 3)
+    //     half-step 2t + 1 : group 0  read(t + 1), issue(t + 3)  | group 1  MFMA(t)
+    // The stage of K-tile t - 1 is free from half-step 2t - 1 on (group 1 read it in 2t - 2), which is when tile t + 3 goes into it;
+    // tile t + 1 was issued in half-steps 2t - 4 / 2t - 3 and must have landed (own pieces, counted vmcnt) before the barrier that
+    // ends half-step 2t.
+    const int grp = wave >> 2;
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define P2S_STAMP(k) do { if (p.stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
+    int issued = 0;                                 // K-tiles of the stream this wave has issued
+    int computed = 0;                               // K-tiles of the stream consumed so far (index of the current one)
+    for (int i = 0; i < 3 && Li < padded; ++i) { issue(); ++issued; }
+    // tile 0 landed (own pieces) -> barrier -> group 0 pre-reads its fragments of tile 0
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 af[8], wf[4];
+    auto read_frags = [&](int stage) {
+        const char* sa = smem + stage * P2_STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + j * 16 + fi, fg));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 128 + i * 16 + fi, fg));
+    };
+    auto mfma_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    auto wait_tile = [&](int t) {                   // own pieces of stream tile t have landed: everything but the tiles issued after it
+        const int younger = issued - (t + 1);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto epilogue = [&]() {
+        const int m0 = tmc * 256, n0 = tnc * 256;
+        bf16_t* Cb = p.Cb + z * p.strideCb;
+        const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(epi_lds + wave * 2048);
+        const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // rows 0-7; rows 8-15 are +1024 (same swizzle)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+                if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+                }
+                const int chunk = j * 2 + (fg >> 1);
+                // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS loads in
+                // flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous rows
+                const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            u32x4 val0, val1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(val0), "=&v"(val1) : "v"(tb_r0), "v"(tb_r0 + 1024) : "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+                const int m = m0 + wm * 128 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
+                if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
+            }
+        }
+        ktc = 0;
+        Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
+        if (Lc < padded) load_bias(tnc);
+    };
+    if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
+    // two straight-line loops (one per group) with the same barrier sequence: a single loop that branches on the group inside
+    // every half-step made hipcc spill 215 VGPRs
+    // (All four LDS-DMA issues stay in the memory half-step: moving two of them between the MFMAs made the pieces land later and
+    // the MFMA half-step longer - 330 us instead of 303 us on the fc1 shape.)
+    if (grp == 0) {
+        read_frags(0);
+        while (Lc < padded) {
+            const int t = computed;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mfma_tile();                                    // half-step 2t
+            P2S_STAMP(0);
+            wait_tile(t + 1);
+            P2S_STAMP(1);
+            __builtin_amdgcn_s_barrier();
+            P2S_STAMP(2);
+            sc = (sc + 1) & (P2_NST - 1);
+            read_frags(sc);                                 // half-step 2t + 1: fragments of the next stream tile (a surplus read of a stale stage at the stream's end is harmless)
+            if (Li < padded) { issue(); ++issued; }
+            P2S_STAMP(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ++computed;
+            if (++ktc == nk) { epilogue(); P2S_STAMP(4); }
+            P2S_STAMP(5);
+        }
+    } else {
+        while (Lc < padded) {
+            const int t = computed;
+            read_frags(sc);                                 // half-step 2t
+            if (Li < padded) { issue(); ++issued; }
+            P2S_STAMP(0);
+            wait_tile(t + 1);
+            P2S_STAMP(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            P2S_STAMP(2);
+            mfma_tile();                                    // half-step 2t + 1
+            P2S_STAMP(3);
+            __builtin_amdgcn_s_barrier();
+            sc = (sc + 1) & (P2_NST - 1);
+            ++computed;
+            if (++ktc == nk) { epilogue(); P2S_STAMP(4); }
+            P2S_STAMP(5);
+        }
+    }
+    if (p.stamps && lane == 0)
+        for (int k = 0; k < 6; ++k) p.stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
+}
+
+
 #define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2) + 4 * 2048)
 #define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2) + 8 * 2048)
 
@@ -765,6 +980,7 @@ const char* gemm_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_256);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
@@ -791,10 +1007,11 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1;
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && p.N >= 1024 && (p.dbg & 64)) || (p.dbg & 128))) {   // experimental: within 5 % of the 256x128 kernels on the Hiera shapes, off by default
+    if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && p.N >= 1024 && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);
-        hipLaunchKernelGGL(gemm_bf16_p256_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
+        if (p.dbg & 2) hipLaunchKernelGGL(gemm_bf16_p256_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
+        else hipLaunchKernelGGL(gemm_bf16_p256s_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
     } else if (direct_ok && tiles256 >= 512 && !(p.dbg & 16)) {
         // two co-resident workgroups per CU: one's epilogue overlaps the other's main loop
         hipLaunchKernelGGL(gemm_bf16_glds2_kernel, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), G2_LDS, stream, p);
