@@ -188,7 +188,7 @@ def main():
         total_ms = sum(v["ms"] for v in prof.values())
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(),
-                           "kernel": "gemm_bf16 (gemm_bf16_glds2_kernel + gemm_bf16_glds_kernel<4> + gemm_bf16_kernel<T>)", "launches_per_slice": g["launches"],
+                           "kernel": "gemm_bf16 (gemm_bf16_glds2_kernel + gemm_bf16_p256s_kernel + gemm_bf16_glds_kernel<4> + gemm_bf16_kernel<T>)", "launches_per_slice": g["launches"],
                            "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
                            "algorithmic_gflop_per_launch": g["flops"] / max(1, g["launches"]) / 1e9,
                            "kernel_ms_per_slice": g["ms"], "share_of_kernel_time": g["ms"] / total_ms if total_ms else None}
