@@ -74,6 +74,22 @@ __device__ __forceinline__ float xor32_sum(float x) { float a, b; xor32_pair(x, 
 __device__ __forceinline__ float shfl_xor16(float x, bool odd) { float a, b; xor16_pair(x, &a, &b); return odd ? a : b; }
 __device__ __forceinline__ float shfl_xor32(float x, bool upper) { float a, b; xor32_pair(x, &a, &b); return upper ? a : b; }
 
+// two GELUs at once: the fma / mul / add steps as packed-f32 instructions (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: two lanes'
+// worth of work per issue slot), min / exp2 / rcp per component.  Same arithmetic as gelu_erf.
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    f32x2 x2 = x * x;
+    x2.x = fminf(x2.x, 50.0f); x2.y = fminf(x2.y, 50.0f);
+    f32x2 q = __builtin_elementwise_fma(x2, (f32x2){1.01426305e-3f, 1.01426305e-3f}, (f32x2){-1.06775724e-1f, -1.06775724e-1f});
+    q = __builtin_elementwise_fma(q, x2, (f32x2){-2.30112134f, -2.30112134f});
+    const f32x2 t = x * q;
+    f32x2 d;
+    d.x = __builtin_amdgcn_exp2f(t.x); d.y = __builtin_amdgcn_exp2f(t.y);
+    d = d + (f32x2){1.0f, 1.0f};
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = xor16_sum(xor32_sum(v));
 #pragma unroll

@@ -751,12 +751,12 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
             var = xor32_sum(xor16_sum(var));
             const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / 64.0f) + 1e-6f);
+            const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                v[ni][0] = gelu_erf((v[ni][0] - mean) * rstd * gg[ni].x + be[ni].x);
-                v[ni][1] = gelu_erf((v[ni][1] - mean) * rstd * gg[ni].y + be[ni].y);
-                v[ni][2] = gelu_erf((v[ni][2] - mean) * rstd * gg[ni].z + be[ni].z);
-                v[ni][3] = gelu_erf((v[ni][3] - mean) * rstd * gg[ni].w + be[ni].w);
+                const f32x2 a = gelu_erf2(((f32x2){v[ni][0], v[ni][1]} - mean2) * rstd2 * (f32x2){gg[ni].x, gg[ni].y} + (f32x2){be[ni].x, be[ni].y});
+                const f32x2 b = gelu_erf2(((f32x2){v[ni][2], v[ni][3]} - mean2) * rstd2 * (f32x2){gg[ni].z, gg[ni].w} + (f32x2){be[ni].z, be[ni].w});
+                v[ni][0] = a.x; v[ni][1] = a.y; v[ni][2] = b.x; v[ni][3] = b.y;
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -786,8 +786,9 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 for (int hh = 0; hh < 2; ++hh) {
                     const int nl = 2 * pp + hh;
                     const uint2 fb = f0[pos2][hh];
-                    const float u0 = gelu_erf(c2[nl][0] + __uint_as_float(fb.x << 16)), u1 = gelu_erf(c2[nl][1] + __uint_as_float(fb.x & 0xffff0000u));
-                    const float u2 = gelu_erf(c2[nl][2] + __uint_as_float(fb.y << 16)), u3 = gelu_erf(c2[nl][3] + __uint_as_float(fb.y & 0xffff0000u));
+                    const f32x2 ua = gelu_erf2((f32x2){c2[nl][0], c2[nl][1]} + (f32x2){__uint_as_float(fb.x << 16), __uint_as_float(fb.x & 0xffff0000u)});
+                    const f32x2 ub = gelu_erf2((f32x2){c2[nl][2], c2[nl][3]} + (f32x2){__uint_as_float(fb.y << 16), __uint_as_float(fb.y & 0xffff0000u)});
+                    const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
                 }
