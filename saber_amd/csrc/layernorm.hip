@@ -7,57 +7,76 @@
 
 #define LN_MAX_CHUNKS 5  // 5 * 64 lanes * 4 floats = 1280 channels
 
+// One wave per row, LN_RPW consecutive rows per wave: gamma / beta (and the row's x) live in registers, so a row costs one load and
+// one store instruction per 1-KB chunk instead of three loads (gamma and beta were re-fetched for every row).
+#define LN_RPW 8
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
-    const float* x = p.x + (int64_t)row * p.ldx;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+    if (row0 >= p.rows) return;
     const int nvec = p.C >> 2;
-    float4 v[LN_MAX_CHUNKS];
-    float s = 0.f;
+    float4 g[NCH], b[NCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
-        if (c < nvec) {
-            v[i] = *reinterpret_cast<const float4*>(x + 4 * c);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nvec) { g[i] = *reinterpret_cast<const float4*>(p.gamma + 4 * c); b[i] = *reinterpret_cast<const float4*>(p.beta + 4 * c); }
+        else { g[i] = make_float4(0.f, 0.f, 0.f, 0.f); b[i] = g[i]; }
     }
-    const float mean = wave_sum(s) / (float)p.C;
-    float q = 0.f;
+    const float invC = 1.0f / (float)p.C;
+    float4 v[NCH], vn[NCH];
+    auto load_row = [&](int64_t row, float4 (&dst)[NCH]) {
+        const float* x = p.x + row * p.ldx;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nvec) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b * b) + (cc * cc + d * d);
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            dst[i] = c < nvec ? *reinterpret_cast<const float4*>(x + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.C + p.eps);
-    const float* addv = p.addvec ? p.addvec + (int64_t)(row % p.add_mod) * p.C : nullptr;
-    // window-padding rows (tiny/small/base+ trunks): the reference pads the NORMALISED tokens with zeros
-    const bool zero_row = p.row_valid && !p.row_valid[row % p.valid_mod];
+    };
+    load_row(row0, v);
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= p.rows) break;
+        if (rr + 1 < LN_RPW && row + 1 < p.rows) load_row(row + 1, vn);      // next row in flight while this one is reduced
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nvec) {
-            const float4 g = *reinterpret_cast<const float4*>(p.gamma + 4 * c);
-            const float4 b = *reinterpret_cast<const float4*>(p.beta + 4 * c);
-            float y0 = (v[i].x - mean) * rstd * g.x + b.x;
-            float y1 = (v[i].y - mean) * rstd * g.y + b.y;
-            float y2 = (v[i].z - mean) * rstd * g.z + b.z;
-            float y3 = (v[i].w - mean) * rstd * g.w + b.w;
-            if (p.act == ACT_GELU) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
-            if (zero_row) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
-            if (p.out_f) *reinterpret_cast<float4*>(p.out_f + (int64_t)row * p.ldo + 4 * c) = make_float4(y0, y1, y2, y3);
-            if (p.out_bf)
-                *reinterpret_cast<uint2*>(p.out_bf + (int64_t)row * p.ldo + 4 * c) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
-            if (p.out_bf_add) {
-                const float4 a = *reinterpret_cast<const float4*>(addv + 4 * c);
-                *reinterpret_cast<uint2*>(p.out_bf_add + (int64_t)row * p.ldo + 4 * c) =
-                    make_uint2(pack_bf16(y0 + a.x, y1 + a.y), pack_bf16(y2 + a.z, y3 + a.w));
+        for (int i = 0; i < NCH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + bb * bb) + (cc * cc + d * d);
             }
         }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + p.eps);
+        const float* addv = p.addvec ? p.addvec + (int64_t)(row % p.add_mod) * p.C : nullptr;
+        // window-padding rows (tiny/small/base+ trunks): the reference pads the NORMALISED tokens with zeros
+        const bool zero_row = p.row_valid && !p.row_valid[row % p.valid_mod];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float y0 = (v[i].x - mean) * rstd * g[i].x + b[i].x;
+                float y1 = (v[i].y - mean) * rstd * g[i].y + b[i].y;
+                float y2 = (v[i].z - mean) * rstd * g[i].z + b[i].z;
+                float y3 = (v[i].w - mean) * rstd * g[i].w + b[i].w;
+                if (p.act == ACT_GELU) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+                if (zero_row) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
+                if (p.out_f) *reinterpret_cast<float4*>(p.out_f + row * p.ldo + 4 * c) = make_float4(y0, y1, y2, y3);
+                if (p.out_bf)
+                    *reinterpret_cast<uint2*>(p.out_bf + row * p.ldo + 4 * c) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+                if (p.out_bf_add) {
+                    const float4 a = *reinterpret_cast<const float4*>(addv + 4 * c);
+                    *reinterpret_cast<uint2*>(p.out_bf_add + row * p.ldo + 4 * c) =
+                        make_uint2(pack_bf16(y0 + a.x, y1 + a.y), pack_bf16(y2 + a.z, y3 + a.w));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v[i] = vn[i];
     }
 }
 
@@ -67,7 +86,12 @@ const char* launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if ((p.ldx & 3) || (p.ldo & 3)) return "layernorm: strides must be multiples of 4";
     if (p.out_bf_add && (!p.addvec || p.add_mod <= 0)) return "layernorm: addvec missing";
     if (p.row_valid && p.valid_mod <= 0) return "layernorm: valid_mod";
-    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)((p.rows + 4 * LN_RPW - 1) / (4 * LN_RPW)));
+    const int nch = (p.C / 4 + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, p);
+    else if (nch == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, p);
+    else if (nch == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(layernorm_kernel<LN_MAX_CHUNKS>, grid, dim3(256), 0, s, p);
     return nullptr;
 }
 
