@@ -143,6 +143,33 @@ def test_amg_parity(engine, image, oracle_large, large_weights, layers, nms):
         assert [m.bbox_xywh[0], m.bbox_xywh[1], m.bbox_xywh[2], m.bbox_xywh[3]] == [xs.min(), ys.min(), xs.max() - xs.min(), ys.max() - ys.min()]
 
 
+def test_amg_parity_non_square_image(engine, large_weights):
+    """ragged input: a 600 x 840 image (crop boxes, point grids, bilinear up-sampling to a non-square crop, bit rows that are not a
+    multiple of 32 wide)"""
+    from oracle.sam2_ref import ImagePredictorRef
+    from oracle.amg_ref import amg_from_saber_cfg
+    from saber_amd.engine import make_amg_params, unpack_bits
+    cfg, Wnp = large_weights
+    rng = np.random.default_rng(21)
+    H, W = 600, 840
+    img = rng.uniform(0, 1, (H, W)).astype(np.float32)
+    yy, xx = np.mgrid[:H, :W]
+    for _ in range(8):
+        cy, cx, r = rng.integers(60, H - 60), rng.integers(60, W - 60), rng.integers(25, 90)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
+    amg = dict(npoints=6, crop_n_layers=0, box_nms_thresh=1.0, pred_iou_thresh=0.5, stability_score_thresh=0.8)
+    ref = amg_from_saber_cfg(ImagePredictorRef(Wnp, cfg), amg).generate(np.repeat(img[..., None], 3, 2))
+    bits, meta = engine.amg_generate(torch.from_numpy(img).cuda(), make_amg_params(amg), max_masks=512)
+    got = unpack_bits(bits, W)
+    print(f"non-square AMG: oracle {len(ref)} masks, engine {len(meta)} masks")
+    assert len(ref) >= 5 and got.shape[1:] == (H, W)
+    assert abs(len(ref) - len(meta)) <= max(2, int(0.15 * len(ref)))
+    ious = _match_masks(list(got), [r["segmentation"] for r in ref])
+    assert np.mean(np.array(ious) > 0.97) >= 0.8
+    for m, g in zip(meta, got):
+        assert m.area == int(g.sum())
+
+
 def test_label_plane(engine):
     rng = np.random.default_rng(0)
     H, W = 96, 160
