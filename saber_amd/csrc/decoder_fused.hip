@@ -111,10 +111,16 @@ const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, 
 //  * 8 waves: wave = (key half kh) * 4 + (q tile); each wave keeps its own online-softmax partial over its 32 keys of
 //    every block; the two halves are merged through LDS at the end.  Two waves per SIMD hide each other's LDS latency.
 // Writes un-normalised partial O [P][split][64][256] and (m, l) [P][split][64][2] (log2 domain).
-#define T2I_KB 64
+// NW = waves per workgroup.  NW = 8 (default): 64-key blocks, wave = (key half) * 4 + (q tile), 2-stage ring, the halves merged through LDS at
+// the end.  NW = 4: 32-key blocks, wave = q tile over ALL keys (no merge), 3-stage ring of 24-KB stages, TWO workgroups per
+// CU that share no barrier and drift apart (one's MFMA phases overlap the other's softmax / LDS-DMA issue phases).
 #define T2I_PEK_ROWB 256                      // one PEK row: 128 bf16
-#define T2I_STAGE (T2I_KB * ROW_B + T2I_KB * T2I_PEK_ROWB)   // X tile (32 KB) + PEK tile (16 KB)
-#define T2I_LDS (2 * T2I_STAGE)
+template <int NW> struct T2ICfg {
+    static constexpr int KB = 8 * NW;                                   // keys per block iteration
+    static constexpr int STAGE = KB * ROW_B + KB * T2I_PEK_ROWB;        // X tile + PEK tile
+    static constexpr int NST = NW == 4 ? 3 : 2;
+    static constexpr int LDS = NST * STAGE;                             // NW = 4: 72 KB >= the 66.5 KB the v_proj tail needs
+};
 typedef __attribute__((address_space(1))) const void* gptr_d;
 typedef __attribute__((address_space(3))) void* lptr_d;
 __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32_t hi) {
@@ -122,12 +128,14 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-__global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
                                                       const bf16_t* __restrict__ pek, const bf16_t* __restrict__ Qt,
                                                       const float* __restrict__ tq, float qscale,
                                                       float* __restrict__ Opart, float* __restrict__ ML, int split,
                                                       const bf16_t* __restrict__ Wv, const float* __restrict__ bv, bf16_t* __restrict__ out,
                                                       unsigned long long* __restrict__ stamps) {
+    constexpr int T2I_KB = T2ICfg<NW>::KB, T2I_STAGE = T2ICfg<NW>::STAGE, NST = T2ICfg<NW>::NST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // development only (stamps != nullptr), see tools/dec_stamps.py
 #define T2I_STAMP(k) do { if (stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
@@ -190,13 +198,18 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
     const int vrow = 4 * fg + (fi >> 2);                // tr-read row within the 32-key half (+16 for the second read)
     const int vsel = (fi & 3) >> 1, vlow = (fi & 1) * 8;
 
+    // NST - 1 tiles in flight; a tile = 6 operations per wave (4 X pieces + 2 PEK pieces)
     issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST == 3 && nkb > 1) { issue(1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
+    int stage = 0;
     for (int kb = 0; kb < nkb; ++kb) {
-        const int stage = kb & 1;
-        if (kb + 1 < nkb) issue(kb + 1, stage ^ 1);
+        {
+            const int kn = kb + NST - 1;                    // the stage it goes into was read in the previous iteration
+            if (kn < nkb) issue(kn, kn % NST);
+        }
         T2I_STAMP(0);
         const char* xs = smem + stage * T2I_STAGE + kh * 32 * ROW_B;     // this wave's 32 keys
         const char* ps = smem + stage * T2I_STAGE + T2I_KB * ROW_B + kh * 32 * T2I_PEK_ROWB;
@@ -245,22 +258,31 @@ __global__ __launch_bounds__(512) void dec_t2i_kernel(const bf16_t* __restrict__
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
         }
         T2I_STAMP(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next block landed (this wave's part)
+        // next block landed (this wave's part); with 3 stages the one after it stays in flight
+        if (NST == 3 && kb + 2 < nkb) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         T2I_STAMP(4);
         __builtin_amdgcn_s_barrier();
         T2I_STAMP(5);
+        stage = stage + 1 == NST ? 0 : stage + 1;
     }
     if (stamps && lane == 0)
-        for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
+        for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * NW + wave) * 6 + k] = ts[k];
     // merge the two key halves of each q tile: waves 4..7 park (m, l, O) in LDS, waves 0..3 combine and store
     float* mo = reinterpret_cast<float*>(smem) + (size_t)qt * 16 * 260;      // [16 q][256 + 4] floats per q tile
-    if (kh == 1) {
+    if (NW == 8 && kh == 1) {
 #pragma unroll
         for (int dt = 0; dt < 16; ++dt) *reinterpret_cast<float4*>(mo + fi * 260 + 16 * dt + 4 * fg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
         if (fg == 0) { mo[fi * 260 + 256] = m; mo[fi * 260 + 257] = l; }
     }
     __syncthreads();
+    if (NW == 4) {            // no second key half: the "other half" is empty
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) *reinterpret_cast<float4*>(mo + fi * 260 + 16 * dt + 4 * fg) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fg == 0) { mo[fi * 260 + 256] = -3.0e38f; mo[fi * 260 + 257] = 0.f; }
+        __builtin_amdgcn_wave_barrier();
+    }
     if (kh == 0) {
         const float m2 = mo[fi * 260 + 256], l2 = mo[fi * 260 + 257];
         const float mn = fmaxf(m, m2);
@@ -354,7 +376,11 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
     if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
-    hipLaunchKernelGGL(dec_t2i_kernel, dim3(P * split), dim3(512), T2I_LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+    extern int g_saber_debug_flags;
+    if (!(g_saber_debug_flags & 4))   // 4-wave workgroups (two per CU, no key-half merge) measure the same as one 8-wave workgroup: kept as an option
+        hipLaunchKernelGGL(dec_t2i_kernel<8>, dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+    else
+        hipLaunchKernelGGL(dec_t2i_kernel<4>, dim3(P * split), dim3(256), T2ICfg<4>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
     if (split > 1) hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
@@ -817,7 +843,8 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
 }
 
 const char* decoder_fused_init_device() {
-    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2I_LDS);
+    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<4>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);

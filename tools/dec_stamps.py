@@ -33,9 +33,10 @@ part = torch.empty(P * 64 * 256, device="cuda"); ml = torch.empty(P * 64 * 2, de
 call2 = lambda: lib.saber_k_dec_t2i(ptr(X), 4096 * 256, ptr(pp), ptr(Qt), ptr(tproj), 0.3, ptr(part), ptr(ml), P, 1, ptr(Wv), ptr(bv), ptr(o2), None)
 for _ in range(3): call2()
 st.zero_(); lib.saber_k_set_stamp_buffer(ptr(st)); call2(); torch.cuda.synchronize(); lib.saber_k_set_stamp_buffer(None)
-s = st.view(P, 8, 6).double().cpu() / 64.0
-names = ["issue DMA", "QK^T (32 ds_read + 32 mfma)", "softmax", "PV (32 tr_read + 16 mfma)", "vmcnt wait", "barrier"]
-print("t2i cycles per 64-key block; per wave:")
+NW = 4 if int(os.environ.get("DBG", "0"), 0) & 4 else 8
+s = st[:P * NW * 6].view(P, NW, 6).double().cpu() / (4096.0 / (8 * NW))
+names = ["issue DMA", "QK^T (18 ds_read + 18 mfma)", "softmax", "PV (32 tr_read + 16 mfma)", "vmcnt wait", "barrier"]
+print(f"t2i cycles per {8 * NW}-key block; per wave:")
 for k, n in enumerate(names):
-    print(f"  {n:28s} " + " ".join(f"{s[:, w, k].mean():7.0f}" for w in range(8)) + f"   | all {s[:, :, k].mean():7.0f}")
+    print(f"  {n:28s} " + " ".join(f"{s[:, w, k].mean():7.0f}" for w in range(NW)) + f"   | all {s[:, :, k].mean():7.0f}")
 print("  total per block", s.sum(-1).mean().item())
