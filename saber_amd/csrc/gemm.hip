@@ -517,16 +517,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         bf16_t* Cb = p.Cb + z * p.strideCb;
         const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(smem + wave * 2048);
         const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+        // the wave's 4 bias vectors: unconditional loads from clamped addresses, ONE wait (a load inside a branch is waited for
+        // with vmcnt(0) on its own: that was 16 dependent L2 round trips per tile)
+        float4 bias4[4];
+        {
+            const float* bp = p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const float4*>(bp + min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (!p.bias) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fg * 4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (p.bias && n + 3 < p.N) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
+                float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
                 if (p.act == ACT_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -553,22 +558,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     } else if (fast_f32) {
         float* Cf = p.Cf + z * p.strideCf;
-        const float* res = p.res ? p.res + z * p.strideRes : nullptr;
+        // bias and residual: unconditional loads from clamped addresses (clamped lanes are never stored), the residual rows of group
+        // i + 1 in flight while group i is stored - not one waited-for load per accumulator tile
+        const float* bp = p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W);
+        const float* rp = p.res ? p.res + z * p.strideRes : p.Cf + z * p.strideCf;     // no residual: any readable fp32 (discarded)
+        const int64_t ldr = p.res ? p.ldres : p.ldcf;
+        int ncol[4];
+        float4 bias4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ncol[j] = min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4);
+            bias4[j] = *reinterpret_cast<const float4*>(bp + ncol[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!p.bias) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // per 16-row group: its 4 residual vectors back to back, one wait, 4 stores (16 registers: the kernel lives on 128 VGPRs)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 64 + i * 16 + fi;
+            const float* rrow = rp + (int64_t)min(m, p.M - 1) * ldr;
             float4 rr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4);
-                rr[j] = res ? *reinterpret_cast<const float4*>(res + (int64_t)min(m, p.M - 1) * p.ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(rrow + ncol[j]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + fg * 4;
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias && n + 3 < p.N) b = *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n);
-                const float4 v = make_float4(acc[i][j][0] + b.x + rr[j].x, acc[i][j][1] + b.y + rr[j].y, acc[i][j][2] + b.z + rr[j].z, acc[i][j][3] + b.w + rr[j].w);
+                float4 v = make_float4(acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w);
+                if (p.res) { v.x += rr[j].x; v.y += rr[j].y; v.z += rr[j].z; v.w += rr[j].w; }
                 if (m < p.M && n + 3 < p.N) *reinterpret_cast<float4*>(Cf + (int64_t)m * p.ldcf + n) = v;
             }
         }
@@ -659,7 +675,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = tn * 256 + wn * 64 + j * 16 + fg * 4;
-            bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional load from a clamped address + select: a load inside a branch is waited for on its own with vmcnt(0), which
+            // here also drains the LDS-DMA pieces in flight
+            const float4 bv = *reinterpret_cast<const float4*>((p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W)) + min(n, p.N - 4));
+            bias4[j] = (p.bias && n + 3 < p.N) ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     load_bias(tnc);
@@ -828,7 +847,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = tn * 256 + wn * 64 + j * 16 + fg * 4;
-            bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + z * p.strideBias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional load from a clamped address + select: a load inside a branch is waited for on its own with vmcnt(0), which
+            // here also drains the LDS-DMA pieces in flight
+            const float4 bv = *reinterpret_cast<const float4*>((p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W)) + min(n, p.N - 4));
+            bias4[j] = (p.bias && n + 3 < p.N) ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     load_bias(tnc);

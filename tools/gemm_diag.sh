@@ -1,2 +1,3 @@
 #!/bin/bash
-for d in 0 64 66; do echo "== DBG=$d"; DBG=$d M0=21 python tools/gemm_bench.py 2>&1 | grep -E "N= 1728|N= 2304|N= 3456|N= 4608|M=   4096|M=   8192" ; echo "-- gelu"; ACT=1 DBG=$d M0=21 python tools/gemm_bench.py 2>&1 | grep -E "N= 2304|N= 4608"; done
+echo "== bf16 out"; M0=21 python tools/gemm_bench.py 2>&1 | grep -E "M=  86016|M= 344064|M=1376256|M=  21504"
+echo "== fp32 + residual"; RES=1 M0=21 python tools/gemm_bench.py 2>&1 | grep -E "M=  86016|M= 344064|M=1376256|M=  21504"
