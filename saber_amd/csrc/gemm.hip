@@ -902,6 +902,37 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     };
     auto epilogue = [&]() {
         const int m0 = tmc * 256, n0 = tnc * 256;
+        if (p.Cf) {
+            // fp32 output (+ fp32 residual): the narrow proj / fc2 of stages 0-1, which are bound by the CU's load/store path - a
+            // 256-wide tile reads the A panel once where the 128-wide kernels read it two or three times.  Per 16-row group: the 4
+            // residual vectors back to back (clamped addresses, clamped lanes are never stored), one wait, 4 stores.
+            float* Cf = p.Cf + z * p.strideCf;
+            const float* rp = p.res ? p.res + z * p.strideRes : Cf;
+            const int64_t ldr = p.res ? p.ldres : p.ldcf;
+            int ncol[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ncol[j] = min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + fi;
+                const float* rrow = rp + (int64_t)min(m, p.M - 1) * ldr;
+                float4 rr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(rrow + ncol[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                    float4 v = make_float4(acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w);
+                    if (p.res) { v.x += rr[j].x; v.y += rr[j].y; v.z += rr[j].z; v.w += rr[j].w; }
+                    if (m < p.M && n + 3 < p.N) *reinterpret_cast<float4*>(Cf + (int64_t)m * p.ldcf + n) = v;
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            ktc = 0;
+            Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
+            if (Lc < padded) load_bias(tnc);
+            return;
+        }
         bf16_t* Cb = p.Cb + z * p.strideCb;
         const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(epi_lds + wave * 2048);
         const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // rows 0-7; rows 8-15 are +1024 (same swizzle)
@@ -1028,8 +1059,11 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1;
+    const bool f32_narrow = p.Cf && !p.Cb && !p.pool4 && p.act == ACT_NONE && (p.N & 3) == 0 && (p.ldcf & 3) == 0 && grid.z == 1 && p.N <= 320 &&
+                            (!p.res || (p.res_shift == 0 && p.res_mod == 0 && (p.ldres & 3) == 0));
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && p.N >= 1024 && !(p.dbg & 64)) || (p.dbg & 128))) {
+    if (direct_ok && ((bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) ||
+                      (f32_narrow && (p.dbg & 128)))) {   // fp32 narrow outputs: measured 6-45 % slower than the 256x128 kernel on the stage-0/1 shapes, forced only
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);
         if (p.dbg & 2) hipLaunchKernelGGL(gemm_bf16_p256_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
