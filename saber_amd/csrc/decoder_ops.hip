@@ -522,23 +522,37 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
             lxa[c] = sx - (float)x0i;
         }
     }
-    for (int r = 0; r < MP_ROWS / 4; ++r) {
-        const int y = blockIdx.x * MP_ROWS + wave * (MP_ROWS / 4) + r;
-        if (y >= H) break;  // wave-uniform
-        uint32_t* brow = bits + ((int64_t)mi * H + y) * W32;
+    // the two source rows of output row y; the pair of the NEXT row is fetched before the pixel loop of the current one (the wave walks
+    // 16 rows one after the other and each needed a dependent global load -> LDS -> pixel loop chain)
+    auto fetch = [&](int y, float4* a, float4* b, float* ly) -> bool {
         const int cy = y - crop_y0;
-        if (cy < 0 || cy >= crop_h) {  // wave-uniform: rows outside the crop are all zero
-            for (int wd = lane; wd < W32; wd += 64) brow[wd] = 0u;
-            continue;
-        }
+        if (y >= H || cy < 0 || cy >= crop_h) return false;       // wave-uniform
         float sy = ((float)cy + 0.5f) * sy_scale - 0.5f;
         sy = fmaxf(sy, 0.f);
         const int y0i = min((int)sy, 255), y1i = min(y0i + 1, 255);
-        const float ly = sy - (float)y0i;
+        *ly = sy - (float)y0i;
+        *a = *reinterpret_cast<const float4*>(src + y0i * 256 + lane * 4);
+        *b = *reinterpret_cast<const float4*>(src + y1i * 256 + lane * 4);
+        return true;
+    };
+    const int ybase = blockIdx.x * MP_ROWS + wave * (MP_ROWS / 4);
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+    float nly = 0.f;
+    bool nin = fetch(ybase, &na, &nb, &nly);
+    for (int r = 0; r < MP_ROWS / 4; ++r) {
+        const int y = ybase + r;
+        if (y >= H) break;  // wave-uniform
+        uint32_t* brow = bits + ((int64_t)mi * H + y) * W32;
+        const float4 a = na, b = nb;
+        const float ly = nly;
+        const bool in_crop = nin;
+        nin = (r + 1 < MP_ROWS / 4) ? fetch(y + 1, &na, &nb, &nly) : false;
+        if (!in_crop) {  // wave-uniform: rows outside the crop are all zero
+            for (int wd = lane; wd < W32; wd += 64) brow[wd] = 0u;
+            continue;
+        }
         __builtin_amdgcn_wave_barrier();
         {
-            const float4 a = *reinterpret_cast<const float4*>(src + y0i * 256 + lane * 4);
-            const float4 b = *reinterpret_cast<const float4*>(src + y1i * 256 + lane * 4);
             float* vw = vrow[wave] + lane * 4;
             vw[0] = (1.0f - ly) * a.x + ly * b.x; vw[1] = (1.0f - ly) * a.y + ly * b.y;
             vw[2] = (1.0f - ly) * a.z + ly * b.z; vw[3] = (1.0f - ly) * a.w + ly * b.w;
