@@ -31,12 +31,14 @@ import torch
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--crop-n-layers", type=int, default=2, help="cfgAMG.crop_n_layers (SABER default 2)")
     ap.add_argument("--npoints", type=int, default=32)
     ap.add_argument("--max-images", type=int, default=21, help="crops encoded per batched pass (21 = every crop of the default 1+4+16 AMG pyramid)")
     ap.add_argument("--max-prompts", type=int, default=1024, help="prompts decoded per batched pass")
+    ap.add_argument("--workers", type=int, default=2, help="engine handles per GPU, each on its own thread and HIP stream, slices dealt round-robin "
+                    "(the reference's GPUPool runs one thread per GPU; kernels of two slices in flight fill each other's idle issue slots)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -102,10 +104,18 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    # SABER_AMD_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL, the
+    # gather staged through host memory).  Never set by the driver; the number it prints is not a multi-GPU measurement.
+    rehearsal = os.environ.get("SABER_AMD_BENCH_REHEARSAL", "0") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -124,31 +134,56 @@ def main():
     pool = [torch.from_numpy(saber_ref.synthetic_slice(seed=1000 * rank + i)).cuda() for i in range(2)]
     torch.cuda.synchronize()
 
-    def step(i, planes=None):
-        plane, n_masks = segment_slice_to_plane(eng, pool[i % len(pool)], params, min_mask_area=50)
+    def step(i, planes=None, engine=None):
+        plane, n_masks = segment_slice_to_plane(engine or eng, pool[i % len(pool)], params, min_mask_area=50)
         if planes is not None:
             planes[i] = plane
         return n_masks
 
-    for i in range(a.warmup):
-        step(i)
+    engines = [eng] + [Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts) for _ in range(a.workers - 1)]
+    streams = [torch.cuda.Stream() for _ in engines]
+
+    def run_steps(first, count, planes=None):
+        """`count` slices starting at index `first`; with several workers they are dealt round-robin to the engine handles, each driven
+        from its own thread on its own stream (the C-ABI calls release the GIL)."""
+        if len(engines) == 1:
+            return sum(step(first + i, planes) for i in range(count))
+        import threading
+        totals = [0] * len(engines)
+
+        def work(w):
+            with torch.cuda.stream(streams[w]):
+                for i in range(w, count, len(engines)):
+                    totals[w] += step(first + i, planes, engines[w])
+                streams[w].synchronize()
+        th = [threading.Thread(target=work, args=(w,)) for w in range(len(engines))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return sum(totals)
+
+    run_steps(0, max(a.warmup, len(engines) if a.warmup else 0))
     planes = torch.zeros((a.steps, 1024, 1024), dtype=torch.uint16, device="cuda")
     gathered = torch.zeros((world * a.steps, 1024, 1024), dtype=torch.uint16, device="cuda") if world > 1 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_masks = 0
-    for i in range(a.steps):
-        n_masks += step(i, planes)
+    n_masks = run_steps(0, a.steps, planes)
     if world > 1:
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), planes.view(torch.uint8))
+        if rehearsal:
+            host = torch.empty(gathered.view(torch.uint8).shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, planes.view(torch.uint8).cpu())
+            gathered.view(torch.uint8).copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered.view(torch.uint8), planes.view(torch.uint8))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -165,8 +200,8 @@ def main():
             "config": {"workload": f"1024x1024 uint16 EM slice -> prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults: npoints={a.npoints}, "
                                    f"crop_n_layers={a.crop_n_layers} -> {n_crops} crops, {n_first} grid prompts + {3 * n_first} m2m refinements, multimask) "
                                    f"-> dedup/sort -> uint16 label plane; BASELINE configs[1]",
-                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)", "slices_per_rank": a.steps,
-                       "parallelism": f"slice-sharded x{world}, all_gather of label planes" if world > 1 else "single GPU",
+                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)", "slices_per_rank": a.steps, "engine_handles_per_gpu": a.workers,
+                       "parallelism": (f"REHEARSAL on one GPU (gloo), not a multi-GPU measurement, x{world}" if rehearsal else f"slice-sharded x{world}, all_gather of label planes") if world > 1 else "single GPU",
                        "masks_per_slice": n_masks / max(1, a.steps), "algorithmic_tflop_per_slice": alg_flops_slice / 1e12},
             "achieved_tflops_algorithmic": alg_flops_slice * world * a.steps / dt / 1e12,
         }
@@ -215,7 +250,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, weights, img01, a.crop_n_layers)
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
+    for e_ in engines:
+        e_.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -15,16 +15,17 @@ from saber_amd.adapters.sam2 import amg as fmask
 _ENGINES: Dict[Any, Any] = {}
 
 
-def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 21, max_prompts: int = 1024):
+def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 21, max_prompts: int = 1024, replica: int = 0):
     """One engine per (device, trunk, weights): the reference builds a second SAM2 copy for AMG (SURVEY 3.4);
-    here adapter and generator share one handle."""
+    here adapter and generator share one handle.  replica > 0: further handles of the same model on the same device (the z-loop keeps
+    two slices in flight per GPU, one handle per thread)."""
     from saber_amd.engine import Engine
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     if dev.type != "cuda":
         raise RuntimeError(f"the MI355X engine needs a ROCm device, got '{dev}' (there is no CPU fallback)")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     src = pretrained_weights.resolve_weights(sam2_cfg, checkpoint)
-    key = (idx, sam2_cfg, tuple(sorted(src.items())))
+    key = (idx, sam2_cfg, tuple(sorted(src.items())), replica)
     if key not in _ENGINES:
         _ENGINES[key] = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, **src)
     return _ENGINES[key]

@@ -73,19 +73,28 @@ class propagationSegmenter(saber3D):
         return utils.separate_masks(final)
 
     @torch.inference_mode()
-    def slice_by_slice_device(self, volume, text_prompt: str = None, stitch: bool = True):
+    def slice_by_slice_device(self, volume, text_prompt: str = None, stitch: bool = True, handles_per_gpu: int = 2):
         """Same result as slice_by_slice, computed with device-resident masks and z-sharded over the ranks of the
         default torch.distributed process group (single process: all slices)."""
         from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
         gen = self.adapter._generator()
         eng, params = gen.base_generator.engine, gen.base_generator.params
+        engines = [eng]
+        if handles_per_gpu > 1:
+            from saber_amd.adapters.sam2.automask import get_engine
+            cfg = self.adapter_cfg
+            engines += [get_engine(cfg.cfg, eng.device, getattr(cfg, "checkpoint", None), max_images=eng.max_images,
+                                   max_prompts=eng.max_prompts, replica=r) for r in range(1, handles_per_gpu)]
 
-        def one(z):
-            sl = volume[z]
-            if isinstance(sl, np.ndarray):
-                sl = torch.from_numpy(np.ascontiguousarray(sl if sl.dtype == np.uint16 else sl.astype(np.float32))).to(eng.device)
-            plane, _ = segment_slice_to_plane(eng, sl, params, min_mask_area=self.min_mask_area,
-                                              remove_repeating_masks=self.remove_repeating_masks)
-            return plane
+        def make(engine):
+            def one(z):
+                sl = volume[z]
+                if isinstance(sl, np.ndarray):
+                    sl = torch.from_numpy(np.ascontiguousarray(sl if sl.dtype == np.uint16 else sl.astype(np.float32))).to(engine.device)
+                plane, _ = segment_slice_to_plane(engine, sl, params, min_mask_area=self.min_mask_area,
+                                                  remove_repeating_masks=self.remove_repeating_masks)
+                return plane
+            return one
 
+        one = [make(e) for e in engines]
         return segment_volume_sharded(volume, one, stitch=stitch, engine=eng)   # 3-D CC on the device (saber_separate_masks)

@@ -9,13 +9,16 @@ from saber_amd.weights import seeded_weights
 from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
 from oracle import saber_ref   # synthetic input recipe only
 Z = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-eng = Engine("large", device=0, weights=seeded_weights(get_config("large"), 0), max_images=21, max_prompts=1024)
+W_ = seeded_weights(get_config("large"), 0)
+eng = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024)
+eng2 = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024)   # two slices in flight per GPU, as slice_by_slice_device does
 params = make_amg_params({})
 vol = saber_ref.synthetic_volume(seed=1, depth=Z)
 dev = torch.from_numpy(vol).cuda()
 segment_slice_to_plane(eng, dev[0], params, min_mask_area=50)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-out = segment_volume_sharded(vol, lambda z: segment_slice_to_plane(eng, dev[z], params, min_mask_area=50)[0], stitch=True, engine=eng)
+fns = [lambda z, e=e: segment_slice_to_plane(e, dev[z], params, min_mask_area=50)[0] for e in (eng, eng2)]
+out = segment_volume_sharded(vol, fns, stitch=True, engine=eng)
 dt = time.perf_counter() - t0
 print(f"Z={Z}: {dt:.2f} s end to end = {Z / dt:.2f} slices/s (label volume {out.shape} {out.dtype}, {int(out.max())} labels)")
