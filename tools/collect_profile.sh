@@ -1,13 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root:  bash tools/collect_profile.sh r01
+# (--workers 1: with the default two slices in flight the kernels of the two streams overlap and stretch each other's durations;
+#  bench.py's own roofline figures are measured on a single-handle step too)
 # 1) kernel-trace + stats of bench.py, 2) two separate PMC passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.
 set -u
 TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --workers 1 --no-cpu-baseline --no-encoder-only > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile > $OUT/bench_write.log 2>&1
 python3 tools/summarize_pmc.py $OUT $TAG
 ls -la $OUT
