@@ -383,3 +383,44 @@ def test_dec_t2i(gpu_lib, P, split, shared):
     err = (out.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err < 0.02 * scale, (err, scale)      # P is rounded to bf16 before the PV MFMA, output stored as bf16
+
+
+def test_hand_synchronised_kernels_are_run_to_run_identical(gpu_lib):
+    """Race screen for the kernels that order LDS-DMA traffic by hand (counted vmcnt + raw barriers): the same launch repeated must be
+    bit-identical every time (a read that overtakes its DMA shows up as run-to-run differences long before it fails a tolerance)."""
+    g = torch.Generator().manual_seed(99)
+    # staggered 256x256 GEMM (its normal route: >= 1024 tiles, N >= 1024)
+    M, N, K = 256 * 130, 2304, 576
+    _, Ad = bf(torch.randn(M, K, generator=g))
+    _, Wd = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g).cuda()
+    outs = []
+    for _ in range(6):
+        o = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias), None, None, ptr(o), M, N, K, 1, 0, 0, 0, 0, None))
+        outs.append(o)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    # streaming global attention and the 256-key window kernel
+    for nw, nk, heads in ((5, 4096, 8), (70, 256, 8)):
+        _, qd = bf(torch.randn(nw * nk, 3 * heads * 72, generator=g) * 1.5)
+        outs = []
+        for _ in range(6):
+            o = torch.zeros(nw * nk, heads * 72, dtype=torch.int16, device="cuda")
+            kcall(gpu_lib, gpu_lib.saber_k_hiera_attention(ptr(qd), ptr(o), nw, nk, heads, 0, None))
+            outs.append(o)
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+    # decoder streaming kernels
+    P = 300
+    gg, r, X, pe = _dec_inputs(P, 123)
+    Kt = r(P, 64, 256, scale=0.08).to(torch.bfloat16); peq = r(4096, 128).to(torch.bfloat16); tk = r(P * 8, 128); cb = r(P, 64)
+    VtT = r(P, 256, 64, scale=0.5).to(torch.bfloat16); bo, gamma, beta = r(256), 1.0 + 0.1 * r(256), 0.1 * r(256)
+    Wv = (r(128, 256) / 16).to(torch.bfloat16); bv = r(128)
+    part = torch.zeros(P * 64 * 256, device="cuda"); ml = torch.zeros(P * 64 * 2, device="cuda")
+    o1, o2 = [], []
+    for _ in range(4):
+        a = torch.zeros(P, 4096, 256, device="cuda", dtype=torch.bfloat16)
+        kcall(gpu_lib, gpu_lib.saber_k_dec_i2t(ptr(X), 4096 * 256, ptr(peq), ptr(Kt), ptr(tk), 0.3, ptr(cb), ptr(VtT), ptr(bo), ptr(gamma), ptr(beta), 1e-5, ptr(a), P, None))
+        b = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
+        kcall(gpu_lib, gpu_lib.saber_k_dec_t2i(ptr(X), 4096 * 256, ptr(peq), ptr(Kt), ptr(tk), 0.3, ptr(part), ptr(ml), P, 1, ptr(Wv), ptr(bv), ptr(b), None))
+        o1.append(a); o2.append(b)
+    assert all(torch.equal(o1[0], o) for o in o1[1:]) and all(torch.equal(o2[0], o) for o in o2[1:])
