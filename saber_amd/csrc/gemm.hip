@@ -595,184 +595,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // ------------------------------------------------------------------------------------------------
 // 256x256 tiles, 8 waves of 128x64, K-tiles of 32 through a 4-stage direct-to-LDS ring (128 KB, three K-tiles in flight), PERSISTENT
-// with one continuous K-tile stream across tiles; bf16 output only (qkv / fc1 of the Hiera blocks: the widest matrices).
+// with one continuous K-tile stream across tiles (gemm_bf16_p256s_kernel; bf16 output only: qkv / fc1 of the Hiera blocks.  An fp32 +
+// residual epilogue in the same kernel cost 19 SGPR spills and 12 % of the main loop's speed, and was slower than the 256x128 kernel
+// on every fp32 shape anyway: those stay on gemm_bf16_glds2_kernel).
 // Why: in the 256x128 kernels every K-tile costs a wave 3 LDS-DMA issues (60-185 cycles each, the vector-memory path is shared
 // with the epilogue's stores) for 16 MFMAs (256 cycles); here it is 4 issues for 32 MFMAs, and half the L2 -> LDS bytes per FLOP.
 #define P2_STAGE ((256 + 256) * BK2 * 2)
 #define P2_NST 4
 #define P2_LDS (P2_NST * P2_STAGE + 8 * 2048)
-
-__global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmParams p) {
-    constexpr int A_BYTES = 256 * BK2 * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* epi_lds = smem + P2_NST * P2_STAGE;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves: rows 128 wm .., columns 64 wn ..
-    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-    const int padded = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    const int64_t z = blockIdx.z;
-    const bf16_t* __restrict__ A = p.A + z * p.strideA;
-    const bf16_t* __restrict__ W = p.W + z * p.strideW;
-    const int fi = lane & 15, fg = lane >> 4;
-    const int nk = (p.K + BK2 - 1) / BK2;
-
-    // one wave-instruction = 16 rows x 64 B; per K-tile 16 A pieces + 16 W pieces, 2 + 2 per wave
-    const int lrow = lane >> 2, lslot = lane & 3;
-    int prow[2], pchunk[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        prow[i] = (wave * 2 + i) * 16 + lrow;
-        pchunk[i] = lslot ^ g2perm(prow[i]);
-    }
-    auto next_tile = [&](int L, int* tm, int* tn) {
-        while (L < padded && !tile_map(L, tiles_m, tiles_n, tm, tn)) L += gridDim.x;
-        return L;
-    };
-    int Li, tmi = 0, tni = 0, kti = 0, si = 0;
-    const bf16_t* asrc[2];
-    const bf16_t* wsrc[2];
-    auto set_issue_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            asrc[i] = A + (int64_t)min(tmi * 256 + prow[i], p.M - 1) * p.lda;
-            wsrc[i] = W + (int64_t)min(tni * 256 + prow[i], p.N - 1) * p.ldw;
-        }
-    };
-    // one K-tile = 4 pieces per wave (A0, W0, A1, W1); piece q of the issue cursor's K-tile, then advance() moves the cursor
-    auto issue_piece = [&](int q) {
-        char* sa = smem + si * P2_STAGE;
-        const int i = q >> 1;
-        const int k = kti * BK2 + pchunk[i] * 8;
-        if (q & 1) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + k), (lptr_t)(sa + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (k < p.K ? k : 0)), (lptr_t)(sa + (wave * 2 + i) * 1024), 16, 0, 0);   // K tail of A: any finite data, W supplies the zeros
-    };
-    auto advance = [&]() {
-        si = (si + 1) & (P2_NST - 1);
-        if (++kti == nk) {
-            kti = 0;
-            Li = next_tile(Li + gridDim.x, &tmi, &tni);
-            if (Li < padded) set_issue_tile();
-        }
-    };
-    auto issue = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) issue_piece(q);
-        advance();
-    };
-    Li = next_tile(blockIdx.x, &tmi, &tni);
-    if (Li >= padded) return;                      // block-uniform
-    set_issue_tile();
-    int Lc = Li, tmc = tmi, tnc = tni, ktc = 0, sc = 0;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bias4[4];
-    auto load_bias = [&](int tn) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = tn * 256 + wn * 64 + j * 16 + fg * 4;
-            // unconditional load from a clamped address + select: a load inside a branch is waited for on its own with vmcnt(0), which
-            // here also drains the LDS-DMA pieces in flight
-            const float4 bv = *reinterpret_cast<const float4*>((p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W)) + min(n, p.N - 4));
-            bias4[j] = (p.bias && n + 3 < p.N) ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    load_bias(tnc);
-    auto wait_next = [&](int ahead) {               // all K-tiles older than the (ahead - 1) youngest ones have landed (4 DMAs per tile and wave)
-        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    int ahead = 0;                                  // K-tiles issued but not yet computed
-    for (int i = 0; i < 3 && Li < padded; ++i) { issue(); ++ahead; }
-    wait_next(ahead);
-    __builtin_amdgcn_s_barrier();
-    // The LDS-DMA issues of the next K-tile (each holds the wave's issue port for 60-185 cycles) are spread BETWEEN the rows of MFMAs:
-    // the matrix core works through the queued MFMAs of this wave and of its SIMD partner while a piece is being issued, instead
-    // of both waves of a SIMD first issuing four pieces each and only then starting their MFMAs.
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define P2_STAMP(k) do { if (p.stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
-    if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
-    while (Lc < padded) {
-        const bool more = Li < padded;              // the stage filled now was computed in the previous iteration (every wave is past its reads)
-        P2_STAMP(0);
-        const char* sa = smem + sc * P2_STAGE;
-        const char* sw = sa + A_BYTES;
-        bf16x8 af[8], wf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + j * 16 + fi, fg));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 128 + i * 16 + fi, fg));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-            if ((i & 1) && more && !(p.dbg & 32)) issue_piece(i >> 1);
-        }
-        if (more && (p.dbg & 32)) { for (int q = 0; q < 4; ++q) issue_piece(q); }
-        if (more) { advance(); ++ahead; }
-        P2_STAMP(1);
-        P2_STAMP(2);
-        --ahead;
-        // the K-tile computed next must have landed (this wave's pieces) before the barrier; younger ones stay in flight.  The wait
-        // sits BEFORE the epilogue so that the epilogue's stores (younger in the in-order vmcnt queue) are not waited for here.
-        wait_next(ahead);
-        P2_STAMP(3);
-        sc = (sc + 1) & (P2_NST - 1);
-        if (++ktc == nk) {
-            const int m0 = tmc * 256, n0 = tnc * 256;
-            bf16_t* Cb = p.Cb + z * p.strideCb;
-            const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(epi_lds + wave * 2048);
-            const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // rows 0-7; rows 8-15 are +1024 (same swizzle)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
-                    if (p.act == ACT_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                    } else if (p.act == ACT_RELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    } else if (p.act == ACT_SIGMOID) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-                    }
-                    const int chunk = j * 2 + (fg >> 1);
-                    // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS loads in
-                    // flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous rows
-                    const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
-                    asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
-                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                u32x4 val0, val1;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(val0), "=&v"(val1) : "v"(tb_r0), "v"(tb_r0 + 1024) : "memory");
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int row = it * 8 + (lane >> 3), chunk = lane & 7;
-                    const int m = m0 + wm * 128 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
-                    if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
-                }
-            }
-            ktc = 0;
-            Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
-            if (Lc < padded) load_bias(tnc);
-            P2_STAMP(4);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        P2_STAMP(5);
-    }
-    if (p.stamps && lane == 0)
-        for (int k = 0; k < 6; ++k) p.stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
-}
 
 __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     constexpr int A_BYTES = 256 * BK2 * 2;
@@ -902,37 +732,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     };
     auto epilogue = [&]() {
         const int m0 = tmc * 256, n0 = tnc * 256;
-        if (p.Cf) {
-            // fp32 output (+ fp32 residual): the narrow proj / fc2 of stages 0-1, which are bound by the CU's load/store path - a
-            // 256-wide tile reads the A panel once where the 128-wide kernels read it two or three times.  Per 16-row group: the 4
-            // residual vectors back to back (clamped addresses, clamped lanes are never stored), one wait, 4 stores.
-            float* Cf = p.Cf + z * p.strideCf;
-            const float* rp = p.res ? p.res + z * p.strideRes : Cf;
-            const int64_t ldr = p.res ? p.ldres : p.ldcf;
-            int ncol[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ncol[j] = min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + wm * 128 + i * 16 + fi;
-                const float* rrow = rp + (int64_t)min(m, p.M - 1) * ldr;
-                float4 rr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(rrow + ncol[j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * 64 + j * 16 + fg * 4;
-                    float4 v = make_float4(acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w);
-                    if (p.res) { v.x += rr[j].x; v.y += rr[j].y; v.z += rr[j].z; v.w += rr[j].w; }
-                    if (m < p.M && n + 3 < p.N) *reinterpret_cast<float4*>(Cf + (int64_t)m * p.ldcf + n) = v;
-                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            ktc = 0;
-            Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
-            if (Lc < padded) load_bias(tnc);
-            return;
-        }
         bf16_t* Cb = p.Cb + z * p.strideCb;
         const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(epi_lds + wave * 2048);
         const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // rows 0-7; rows 8-15 are +1024 (same swizzle)
@@ -1032,7 +831,6 @@ const char* gemm_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_128);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_256);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
@@ -1059,15 +857,11 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1;
-    const bool f32_narrow = p.Cf && !p.Cb && !p.pool4 && p.act == ACT_NONE && (p.N & 3) == 0 && (p.ldcf & 3) == 0 && grid.z == 1 && p.N <= 320 &&
-                            (!p.res || (p.res_shift == 0 && p.res_mod == 0 && (p.ldres & 3) == 0));
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (direct_ok && ((bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) ||
-                      (f32_narrow && (p.dbg & 128)))) {   // fp32 narrow outputs: measured 6-45 % slower than the 256x128 kernel on the stage-0/1 shapes, forced only
+    if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);
-        if (p.dbg & 2) hipLaunchKernelGGL(gemm_bf16_p256_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
-        else hipLaunchKernelGGL(gemm_bf16_p256s_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
+        hipLaunchKernelGGL(gemm_bf16_p256s_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
     } else if (direct_ok && tiles256 >= 512 && !(p.dbg & 16)) {
         // two co-resident workgroups per CU: one's epilogue overlaps the other's main loop
         hipLaunchKernelGGL(gemm_bf16_glds2_kernel, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), G2_LDS, stream, p);

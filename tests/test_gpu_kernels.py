@@ -90,26 +90,6 @@ def test_gemm_p256(gpu_lib, M, N, K, act):
     assert errb < 5e-3, errb
 
 
-@pytest.mark.parametrize("M,N,K,use_res", [(1000, 144, 576, True), (2049, 288, 64, True), (700, 144, 192, False)])
-def test_gemm_p256_fp32_narrow(gpu_lib, M, N, K, use_res):
-    """fp32 (+ residual) epilogue of the 256x256 kernel (narrow proj / fc2 of stages 0-1), forced through the debug flag"""
-    g = torch.Generator().manual_seed(M + N + K)
-    A, Ad = bf(torch.randn(M, K, generator=g))
-    W, Wd = bf(torch.randn(N, K, generator=g) / K ** 0.5)
-    bias = torch.randn(N, generator=g)
-    res = torch.randn(M, N, generator=g) if use_res else None
-    ref = A.double() @ W.double().T + bias.double() + (res.double() if use_res else 0.0)
-    out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda")
-    bias_d, res_d = bias.cuda(), (res.cuda() if use_res else None)
-    gpu_lib.saber_k_set_debug(128)
-    try:
-        kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias_d), ptr(res_d), ptr(out_f), None, M, N, K, 0, 0, 0, 0, 0, None))
-    finally:
-        gpu_lib.saber_k_set_debug(0)
-    err = (out_f.cpu().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
-    assert err < 2e-5, err
-
-
 def test_gemm_act_last_and_res_mod(gpu_lib):
     g = torch.Generator().manual_seed(3)
     M, N, K = 640, 128, 64

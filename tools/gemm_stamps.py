@@ -1,4 +1,6 @@
-"""In-kernel cycle stamps of the persistent 256x256 GEMM (development): python tools/gemm_stamps.py M N K [act]"""
+"""In-kernel cycle stamps of the staggered persistent 256x256 GEMM (development): python tools/gemm_stamps.py M N K [act]
+Columns per wave; for waves 0-3 the phases are [MFMA, wait, barrier, fragment reads + LDS-DMA issue], for waves 4-7
+[fragment reads + issue, wait, barrier, MFMA]; then the epilogue (per tile) and the second barrier."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,14 +10,14 @@ def ptr(t): return C.c_void_p(t.data_ptr())
 M, N, K = [int(x) for x in sys.argv[1:4]]; act = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 A = torch.randn(M, K, device="cuda").to(torch.bfloat16); W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-lib.saber_k_set_debug(int(os.environ.get("DBG", "64"), 0))
+lib.saber_k_set_debug(int(os.environ.get("DBG", "128"), 0))
 call = lambda: lib.saber_k_gemm_ld(ptr(A), K, ptr(W), K, 1, ptr(bias), None, None, ptr(out), M, N, K, act, None)
 for _ in range(3): call()
 st = torch.zeros(256 * 8 * 6, dtype=torch.int64, device="cuda")
 lib.saber_k_set_stamp_buffer(ptr(st)); call(); torch.cuda.synchronize(); lib.saber_k_set_stamp_buffer(None)
 tiles = ((M + 255) // 256) * ((N + 255) // 256); nk = (K + 31) // 32
 s = st.view(256, 8, 6).double().cpu()
-names = ["issue DMA (early waves)", "ds_read + 32 mfma", "issue DMA (late waves)", "vmcnt wait", "epilogue (per tile)", "barrier"]
+names = ["half-step 2t", "vmcnt wait", "barrier", "half-step 2t+1", "epilogue (per tile)", "barrier 2"]
 per_block_iters = tiles / 256.0 * nk
 print(f"tiles {tiles} ({tiles/256:.2f} per block), {nk} K-tiles each; cycles per K-tile iteration (epilogue: per tile), per wave:")
 for k, n in enumerate(names):
