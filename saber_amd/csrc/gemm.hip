@@ -604,6 +604,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define P2_NST 4
 #define P2_LDS (P2_NST * P2_STAGE + 8 * 2048)
 
+template <bool STAMPS>
 __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     constexpr int A_BYTES = 256 * BK2 * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     // ends half-step 2t.
     const int grp = wave >> 2;
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define P2S_STAMP(k) do { if (p.stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
+#define P2S_STAMP(k) do { if (STAMPS) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
     int issued = 0;                                 // K-tiles of the stream this wave has issued
     int computed = 0;                               // K-tiles of the stream consumed so far (index of the current one)
     for (int i = 0; i < 3 && Li < padded; ++i) { issue(); ++issued; }
@@ -717,12 +718,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 128 + i * 16 + fi, fg));
     };
+    // The MFMA cluster must stay inside its half-step: MFMAs touch no memory, so hipcc is free to move them across the raw barriers and
+    // the inline-asm waits (it did, depending on unrelated edits: 305 us <-> 335 us on the fc1 shape).  s_setprio around the cluster
+    // keeps it together (cdna_hip_programming.md T5) and sched_barrier(0) pins its place.
     auto mfma_tile = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto wait_tile = [&](int t) {                   // own pieces of stream tile t have landed: everything but the tiles issued after it
         const int younger = issued - (t + 1);
@@ -743,13 +751,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
                 if (p.act == ACT_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (p.act == ACT_SIGMOID) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-                }
+                }                                              // (only ACT_NONE / ACT_GELU are routed to this kernel)
                 const int chunk = j * 2 + (fg >> 1);
                 // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS loads in
                 // flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous rows
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
         Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
         if (Lc < padded) load_bias(tnc);
     };
-    if (p.stamps) tprev = __builtin_amdgcn_s_memtime();
+    if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
     // two straight-line loops (one per group) with the same barrier sequence: a single loop that branches on the group inside
     // every half-step made hipcc spill 215 VGPRs
     // (All four LDS-DMA issues stay in the memory half-step: moving two of them between the MFMAs made the pieces land later and
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
             P2S_STAMP(5);
         }
     }
-    if (p.stamps && lane == 0)
+    if (STAMPS && lane == 0)
         for (int k = 0; k < 6; ++k) p.stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
 }
 
@@ -831,7 +833,8 @@ const char* gemm_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_128);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_256);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
@@ -856,12 +859,13 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     dim3 grid(padded((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), 1, p.batch > 0 ? p.batch : 1);
     const bool direct_ok = p.w_kpad || (p.K % BK) == 0;
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-    const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1;
+    const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1 && (p.act == ACT_NONE || p.act == ACT_GELU);
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);
-        hipLaunchKernelGGL(gemm_bf16_p256s_kernel, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
+        if (p.stamps) hipLaunchKernelGGL(gemm_bf16_p256s_kernel<true>, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);   // development build with cycle stamps
+        else hipLaunchKernelGGL(gemm_bf16_p256s_kernel<false>, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
     } else if (direct_ok && tiles256 >= 512 && !(p.dbg & 16)) {
         // two co-resident workgroups per CU: one's epilogue overlaps the other's main loop
         hipLaunchKernelGGL(gemm_bf16_glds2_kernel, dim3(padded((p.M + 255) / 256, (p.N + BN - 1) / BN), 1, grid.z), dim3(512), G2_LDS, stream, p);
