@@ -19,6 +19,11 @@
  *                                                                     saber/adapters/sam2/predictor.py:70
  *   saber_label_plane
  *       <- the paint loop of propagationSegmenter.slice_by_slice      saber/segmenters/propagation.py:185-186
+ *   saber_separate_masks
+ *       <- separate_masks(vol_masks, min_mask_area)                   saber/segmenters/utils.py:88-131
+ *   saber_smooth_labels / saber_gaussian_smoothing_3d
+ *       <- fast_3d_gaussian_smoothing(volume, scale, deviceID)        saber/filters/masks.py:230-287
+ *          gaussian_smoothing_3d(volume, sigma, device)               saber/filters/gaussian.py:76-138
  *
  * Conventions: plain pointers and sizes only; every *_dev pointer is device memory owned by the
  * caller (e.g. a PyTorch-ROCm tensor's data_ptr()); `stream` is a hipStream_t (NULL = default
@@ -125,6 +130,20 @@ int saber_mask_pair_intersections(saber_engine* e, const uint32_t* bits_dev, int
  * Z*H*W < 2^31.  Synchronises the stream (the label count is returned). */
 int saber_separate_masks(saber_engine* e, const uint16_t* planes_dev, int Z, int H, int W, int min_mask_area, uint32_t* out_dev,
                          int* out_n_labels, void* stream);
+
+/* Per-label adaptive 3-D Gaussian smoothing of a label volume (replaces saber.filters.masks.fast_3d_gaussian_smoothing,
+ * saber/filters/masks.py:230-287; applied to the segmenter's output by segment_tomogram_core, saber/entry_points/inference_core.py:68-74
+ * with scale = 0.05).  For each label value v != 0, ascending: sigma = scale * 2 (3 |vol == v| / 4 pi)^(1/3) (masks.py:289-309), separable
+ * zero-padded Gaussian of int(6 sigma + 1) (made odd) taps along x, y, z in fp32 (gaussian.py:97-131), out[field > 0.5] = (uint8) v,
+ * later labels overwriting earlier ones.  labels_dev: (Z,H,W) of elem_bytes 1, 2 or 4 (unsigned), values <= 2^22; out_dev: (Z,H,W)
+ * uint8 (label values wrap modulo 256 exactly as the reference's uint8 result array does).  *out_n_labels = labels found.
+ * Only a created handle is needed (no weights / finalize).  Synchronises the stream (per-label statistics come back to the host). */
+int saber_smooth_labels(saber_engine* e, const void* labels_dev, int elem_bytes, int Z, int H, int W, double scale, uint8_t* out_dev,
+                        int* out_n_labels, void* stream);
+
+/* The separable filter itself on one 0/1 mask with a given sigma (saber/filters/gaussian.py:76-138): mask_dev (Z,H,W) uint8,
+ * out_dev (Z,H,W) float32. */
+int saber_gaussian_smoothing_3d(saber_engine* e, const uint8_t* mask_dev, int Z, int H, int W, double sigma, float* out_dev, void* stream);
 
 /* Per-launch HIP-event profiling of the engine's own kernels, by kernel class (events are recorded on the
  * stream the kernels are launched on).  Class order: 0 gemm_bf16, 1 hiera_attention, 2 layernorm,

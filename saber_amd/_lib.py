@@ -59,6 +59,8 @@ SIGNATURES = {
     "saber_label_plane": (_i, [_vp, _vp, C.POINTER(_i), _i, _i, _i, _vp, _vp]),
     "saber_mask_pair_intersections": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "saber_separate_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
+    "saber_smooth_labels": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_double, _vp, C.POINTER(_i), _vp]),
+    "saber_gaussian_smoothing_3d": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp]),
     "saber_profile_begin": (_i, [_vp]),
     "saber_profile_end": (_i, [_vp, C.POINTER(ProfileClass), _i]),
     "saber_encoder_flops": (C.c_double, [_vp]),

@@ -52,6 +52,25 @@ class Engine:
             self._check(self.lib.saber_engine_set_weight(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
         self._check(self.lib.saber_engine_finalize(self.h))
 
+    @classmethod
+    def bare(cls, device: int = 0) -> "Engine":
+        """A handle without model weights: enough for the volume post-processing calls (separate_masks, smooth_labels,
+        gaussian_smoothing_3d), which only need the device binding and the per-handle error string."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("saber_amd.Engine needs a ROCm device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(f"cuda:{device}")
+        self.device_index = device
+        h = C.c_void_p()
+        st = self.lib.saber_engine_create(device, b"tiny", 1, 1, C.byref(h))
+        if st != 0:
+            raise RuntimeError(self.lib.saber_last_error(None).decode())
+        self.h = h
+        self.cfg = None
+        self.max_images = self.max_prompts = 0
+        return self
+
     def _check(self, st: int):
         if st != 0:
             msg = self.lib.saber_last_error(self.h).decode()
@@ -154,6 +173,26 @@ class Engine:
         n = C.c_int(0)
         self._check(self.lib.saber_separate_masks(self.h, _ptr(planes), Z, H, W, int(min_mask_area), _ptr(out), C.byref(n), _stream()))
         return out, n.value
+
+    def smooth_labels(self, labels: torch.Tensor, scale: float = 0.075):
+        """filters.masks.fast_3d_gaussian_smoothing on the device.  labels: (Z,H,W) device tensor of uint8 / (u)int16 / (u)int32 label
+        values (non-negative).  Returns ((Z,H,W) uint8 device tensor, number of labels found)."""
+        assert labels.is_cuda and labels.dim() == 3 and labels.is_contiguous()
+        if labels.dtype not in (torch.uint8, torch.int16, torch.uint16, torch.int32, torch.uint32):
+            raise ValueError(f"smooth_labels: unsupported dtype {labels.dtype}")
+        Z, H, W = labels.shape
+        out = torch.empty((Z, H, W), dtype=torch.uint8, device=labels.device)
+        n = C.c_int(0)
+        self._check(self.lib.saber_smooth_labels(self.h, _ptr(labels), labels.element_size(), Z, H, W, float(scale), _ptr(out), C.byref(n), _stream()))
+        return out, n.value
+
+    def gaussian_smoothing_3d(self, mask: torch.Tensor, sigma: float) -> torch.Tensor:
+        """filters.gaussian.gaussian_smoothing_3d on the device.  mask: (Z,H,W) bool / uint8 0-1 device tensor -> float32 field."""
+        assert mask.is_cuda and mask.dim() == 3 and mask.is_contiguous() and mask.dtype in (torch.bool, torch.uint8)
+        Z, H, W = mask.shape
+        out = torch.empty((Z, H, W), dtype=torch.float32, device=mask.device)
+        self._check(self.lib.saber_gaussian_smoothing_3d(self.h, _ptr(mask), Z, H, W, float(sigma), _ptr(out), _stream()))
+        return out
 
     def profile_begin(self):
         self._check(self.lib.saber_profile_begin(self.h))

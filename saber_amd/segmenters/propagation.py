@@ -73,9 +73,11 @@ class propagationSegmenter(saber3D):
         return utils.separate_masks(final)
 
     @torch.inference_mode()
-    def slice_by_slice_device(self, volume, text_prompt: str = None, stitch: bool = True, handles_per_gpu: int = 2):
+    def slice_by_slice_device(self, volume, text_prompt: str = None, stitch: bool = True, handles_per_gpu: int = 2,
+                              smooth_scale: float = None):
         """Same result as slice_by_slice, computed with device-resident masks and z-sharded over the ranks of the
-        default torch.distributed process group (single process: all slices)."""
+        default torch.distributed process group (single process: all slices).  smooth_scale=0.05 appends the adaptive Gaussian
+        smoothing segment_tomogram_core applies to the result (inference_core.py:68-74), still on the device (uint8 output)."""
         from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
         gen = self.adapter._generator()
         eng, params = gen.base_generator.engine, gen.base_generator.params
@@ -97,4 +99,4 @@ class propagationSegmenter(saber3D):
             return one
 
         one = [make(e) for e in engines]
-        return segment_volume_sharded(volume, one, stitch=stitch, engine=eng)   # 3-D CC on the device (saber_separate_masks)
+        return segment_volume_sharded(volume, one, stitch=stitch, engine=eng, smooth_scale=smooth_scale)   # 3-D CC (+ smoothing) on the device

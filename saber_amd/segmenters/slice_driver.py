@@ -55,13 +55,15 @@ def shard_bounds(Z: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area: int = 100,
-                           group=None, engine=None) -> Optional[np.ndarray]:
+                           group=None, engine=None, smooth_scale: Optional[float] = None) -> Optional[np.ndarray]:
     """Slice-parallel slice_by_slice.  `volume` only supplies the shape (Z,H,W); `slice_fn(z)` returns the uint16
     label plane of slice z as a tensor on this rank's device.  All ranks receive every plane (all_gather of equal,
     zero-padded chunks); the (Z,H,W) uint32 stitched labels are returned (reference: utils.separate_masks).  With `engine`
     given and the planes on its device the stitch runs there (saber_separate_masks, bit-identical to the host path).
     `slice_fn` may be a LIST of callables, one per engine handle of this rank: its slices are then dealt round-robin to one thread
-    per handle, each on its own HIP stream (two slices in flight per GPU fill each other's idle issue slots: +6 % measured)."""
+    per handle, each on its own HIP stream (two slices in flight per GPU fill each other's idle issue slots: +6 % measured).
+    `smooth_scale` (device stitch only) also applies the post step of segment_tomogram_core (inference_core.py:68-74, scale 0.05):
+    fast_3d_gaussian_smoothing on the stitched labels without leaving the device; the result is then the uint8 volume it returns."""
     import torch.distributed as dist
     Z, H, W = volume.shape
     dist_on = dist.is_available() and dist.is_initialized()
@@ -122,6 +124,9 @@ def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area:
             parts.append(full[r * chunk: r * chunk + (b - a)])
         planes_dev = parts[0] if world == 1 and parts[0].shape[0] == Z else torch.cat(parts, 0)
         labels, _ = engine.separate_masks(planes_dev.contiguous(), min_mask_area=min_mask_area)
+        if smooth_scale is not None:
+            smoothed, _ = engine.smooth_labels(labels, smooth_scale)
+            return smoothed.cpu().numpy()
         return labels.cpu().numpy().view(np.uint32)
     planes = np.empty((Z, H, W), dtype=np.uint16)
     full_np = full.cpu().numpy().view(np.uint16)
@@ -130,4 +135,6 @@ def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area:
         planes[a:b] = full_np[r * chunk: r * chunk + (b - a)]
     if not stitch:
         return planes
+    if smooth_scale is not None:
+        raise RuntimeError("smooth_scale needs the device stitch (pass engine=... and device planes): there is no CPU smoothing path")
     return utils.separate_masks(planes, min_mask_area=min_mask_area)

@@ -59,3 +59,15 @@ def test_slice_loop_device_equals_reference_shaped_loop(segmenter):
     assert ref.dtype == np.uint32 and dev.dtype == np.uint32 and ref.shape == vol.shape
     assert ref.max() > 0, "no component survived: the test volume / thresholds no longer exercise the path"
     assert np.array_equal(ref, dev)
+
+
+def test_slice_loop_with_device_smoothing(segmenter):
+    """slice loop + stitch + the post step of segment_tomogram_core (inference_core.py:68-74) without leaving the device ==
+    the same label volume pushed through the oracle's fast_3d_gaussian_smoothing (threshold band as in test_gpu_smooth3d)"""
+    from oracle import saber_ref
+    vol = _volume()
+    labels = segmenter.slice_by_slice_device(vol)
+    sm = segmenter.slice_by_slice_device(vol, smooth_scale=0.05)
+    assert sm.dtype == np.uint8 and sm.shape == vol.shape
+    ref, near = saber_ref.fast_3d_gaussian_smoothing(labels, 0.05, band=1e-5)
+    assert not ((sm != ref) & ~near).any()

@@ -64,6 +64,23 @@ def test_oracle_separate_masks_matches_reference():
     assert np.array_equal(saber_ref.separate_masks(np.zeros((3, 8, 8), np.uint16)), G["sep_out_empty"])
 
 
+def test_oracle_smoothing_matches_reference():
+    """oracle restatement of fast_3d_gaussian_smoothing / gaussian_smoothing_3d against the reference's own outputs
+    (tests/golden/saber_smooth.npz, oracle/make_golden_smooth.py)"""
+    from oracle import saber_ref
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "saber_smooth.npz"), allow_pickle=False)
+    for name, inp, scale in (("a_out_s075", "a_in", 0.075), ("a_out_s05", "a_in", 0.05), ("b_out_s05", "b_in", 0.05), ("c_out_s075", "c_in", 0.075)):
+        out = saber_ref.fast_3d_gaussian_smoothing(S[inp], scale)
+        assert out.dtype == np.uint8 and np.array_equal(out, S[name]), name
+    assert set(np.unique(S["b_out_s05"])) == {0, 3, 300 & 255, 70, 200}      # uint8 result array: 300 and 515 wrap, 515 lands on 3
+    assert np.array_equal(saber_ref.fast_3d_gaussian_smoothing(np.zeros((4, 8, 8), np.uint32)), S["empty_out"])
+    for n, m in (("a3", S["a_in"] == 3), ("c1", S["c_in"] == 1)):
+        assert np.abs(saber_ref.gaussian_smoothing_3d(m, float(S[f"field_{n}_sigma"])) - S[f"field_{n}"]).max() < 1e-6
+    est = [saber_ref.estimate_feature_size_3d(S["a_in"] == k, 0.05) for k in range(1, 12)]
+    assert np.array_equal(np.array(est), S["sigma_est"])
+    assert len(saber_ref.gaussian_taps_3d(0.09)) == 1 and len(saber_ref.gaussian_taps_3d(1.5)) == 11
+
+
 def utils_sep5():
     from saber_amd.segmenters import utils
     return utils.separate_masks(G["sep_in"], min_mask_area=5)
