@@ -85,7 +85,9 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel class from the latest committed rocprofv3 PMC summary
     (profiles/*_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])      # r01_v10 after r01_v9
     if not files:
         return None
     try:
