@@ -99,4 +99,6 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    if os.environ.get("SABER_AMD_DEBUG"):      # development A/B switches of individual kernels (tools/ab_flag.sh); 0 in production
+        lib.saber_k_set_debug(int(os.environ["SABER_AMD_DEBUG"], 0))
     return lib

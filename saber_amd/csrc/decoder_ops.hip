@@ -630,18 +630,146 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
     }
 }
 
+// W <= 1024 (every SABER slice): the row loop with NO scalar work per 64-pixel chunk.  The previous form spent ~15 SALU instructions
+// per chunk (three popcounts, ffs / clz for the box, the bit-deposit bookkeeping) beside ~14 VALU; here
+//   * lane k keeps chunk k of the row's bits (v_writelane of the v_cmp result), so area / box come from ONE popcount / ffs / clz per
+//     lane and row instead of per chunk, and the row is stored as is;
+//   * the two stability counts are per-lane adds of the compare results, reduced across the wave once per 16 rows;
+//   * pixels outside the crop read a -3e38 sentinel (taps precomputed per block), the chunk loop skips chunks the crop does not touch;
+//   * vrow[256] repeats vrow[255], so the right tap is always x0 + 1 (one ds_read2).
+// Same arithmetic per pixel as mask_post_kernel: bit-identical masks and counts.
+__global__ __launch_bounds__(256) void mask_post_w1k_kernel(const float* __restrict__ lowres, const int* __restrict__ idx, int crop_x0,
+                                                            int crop_y0, int crop_w, int crop_h, int H, int W, float thr, float offset,
+                                                            uint32_t* __restrict__ bits, MaskStats* __restrict__ stats) {
+    __shared__ float vrow[4][260];
+    __shared__ int red[4][8];
+    const int mi = blockIdx.y;
+    const float* src = lowres + (int64_t)(idx ? idx[mi] : mi) * 65536;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W32 = (W + 31) >> 5;
+    const float sy_scale = 256.0f / (float)crop_h, sx_scale = 256.0f / (float)crop_w;
+    const int c_lo = max(crop_x0, 0) >> 6, c_hi = min(crop_x0 + crop_w - 1, W - 1) >> 6;
+    int x0a[16];
+    float lxa[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int x = 64 * c + lane, cx = x - crop_x0;
+        float sx = ((float)cx + 0.5f) * sx_scale - 0.5f;
+        sx = fmaxf(sx, 0.f);
+        const int x0i = min((int)sx, 255);
+        const bool valid = x < W && cx >= 0 && cx < crop_w;
+        x0a[c] = valid ? x0i : 257;
+        lxa[c] = valid ? sx - (float)x0i : 0.0f;
+    }
+    if (lane < 2) vrow[wave][257 + lane] = -3.0e38f;
+    auto fetch = [&](int y, float4* a, float4* b, float* ly) -> bool {
+        const int cy = y - crop_y0;
+        if (y >= H || cy < 0 || cy >= crop_h) return false;       // wave-uniform
+        float sy = ((float)cy + 0.5f) * sy_scale - 0.5f;
+        sy = fmaxf(sy, 0.f);
+        const int y0i = min((int)sy, 255), y1i = min(y0i + 1, 255);
+        *ly = sy - (float)y0i;
+        *a = *reinterpret_cast<const float4*>(src + y0i * 256 + lane * 4);
+        *b = *reinterpret_cast<const float4*>(src + y1i * 256 + lane * 4);
+        return true;
+    };
+    int area = 0, inter = 0, uni = 0, xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;     // per lane; y extents wave-uniform
+    const int ybase = blockIdx.x * MP_ROWS + wave * (MP_ROWS / 4);
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+    float nly = 0.f;
+    bool nin = fetch(ybase, &na, &nb, &nly);
+    for (int r = 0; r < MP_ROWS / 4; ++r) {
+        const int y = ybase + r;
+        if (y >= H) break;  // wave-uniform
+        uint32_t* brow = bits + ((int64_t)mi * H + y) * W32;
+        const float4 a = na, b = nb;
+        const float ly = nly;
+        const bool in_crop = nin;
+        nin = (r + 1 < MP_ROWS / 4) ? fetch(y + 1, &na, &nb, &nly) : false;
+        if (!in_crop) {  // wave-uniform: rows outside the crop are all zero
+            for (int wd = lane; wd < W32; wd += 64) brow[wd] = 0u;
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            float* vw = vrow[wave] + lane * 4;
+            vw[0] = (1.0f - ly) * a.x + ly * b.x; vw[1] = (1.0f - ly) * a.y + ly * b.y;
+            vw[2] = (1.0f - ly) * a.z + ly * b.z; vw[3] = (1.0f - ly) * a.w + ly * b.w;
+            if (lane == 63) vw[4] = vw[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* vr = vrow[wave];
+        uint32_t blo = 0u, bhi = 0u;        // lane k: bits of pixels 64k .. 64k+63 of this row
+        // all taps of the row first (16 ds_read2 in flight, one wait; chunks outside the crop read the sentinel), then the chunks
+        float ta[16], tb[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) { ta[cc] = vr[x0a[cc]]; tb[cc] = vr[x0a[cc] + 1]; }
+        // one 64-pixel chunk; the lane select of v_writelane_b32 must be an inline constant (one SGPR per VALU instruction)
+#define MP_CHUNK(cc)                                                                                              \
+        if ((cc) >= c_lo && (cc) <= c_hi) {                                                                       \
+            const float lx = lxa[cc];                                                                             \
+            const float v = (1.0f - lx) * ta[cc] + lx * tb[cc];                                                   \
+            const unsigned long long bm = __ballot(v > thr);                                                      \
+            asm("s_nop 1\n\tv_writelane_b32 %0, %1, " #cc : "+v"(blo) : "s"((uint32_t)bm));    /* VALU-written SGPR read by a VALU op: 2 wait states on gfx940+, and the hazard recogniser does not look inside asm */ \
+            asm("v_writelane_b32 %0, %1, " #cc : "+v"(bhi) : "s"((uint32_t)(bm >> 32)));                          \
+            inter += (v > thr + offset) ? 1 : 0;                                                                  \
+            uni += (v > thr - offset) ? 1 : 0;                                                                    \
+        }
+        MP_CHUNK(0) MP_CHUNK(1) MP_CHUNK(2) MP_CHUNK(3) MP_CHUNK(4) MP_CHUNK(5) MP_CHUNK(6) MP_CHUNK(7)
+        MP_CHUNK(8) MP_CHUNK(9) MP_CHUNK(10) MP_CHUNK(11) MP_CHUNK(12) MP_CHUNK(13) MP_CHUNK(14) MP_CHUNK(15)
+#undef MP_CHUNK
+        const int pc = __popc(blo) + __popc(bhi);
+        area += pc;
+        if (pc) {
+            xmin = min(xmin, lane * 64 + (blo ? __ffs((int)blo) - 1 : 31 + __ffs((int)bhi)));
+            xmax = max(xmax, lane * 64 + (bhi ? 63 - __clz((int)bhi) : 31 - __clz((int)blo)));
+        }
+        if (__ballot(pc != 0)) { ymin = min(ymin, y); ymax = max(ymax, y); }
+        const int wd = lane * 2;
+        if (wd < W32) brow[wd] = blo;
+        if (wd + 1 < W32) brow[wd + 1] = bhi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        area += __shfl_xor(area, o, 64); inter += __shfl_xor(inter, o, 64); uni += __shfl_xor(uni, o, 64);
+        xmin = min(xmin, __shfl_xor(xmin, o, 64)); xmax = max(xmax, __shfl_xor(xmax, o, 64));
+    }
+    if (lane == 0) {
+        red[wave][0] = area; red[wave][1] = inter; red[wave][2] = uni; red[wave][3] = xmin;
+        red[wave][4] = xmax; red[wave][5] = ymin; red[wave][6] = ymax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, in_ = 0, u = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+        for (int w = 0; w < 4; ++w) {
+            a += red[w][0]; in_ += red[w][1]; u += red[w][2];
+            x0 = min(x0, red[w][3]); x1 = max(x1, red[w][4]); y0 = min(y0, red[w][5]); y1 = max(y1, red[w][6]);
+        }
+        MaskStats* st = stats + mi;
+        if (a) {
+            atomicAdd(&st->area, a);
+            atomicMin(&st->x0, x0); atomicMax(&st->x1, x1);
+            atomicMin(&st->y0, y0); atomicMax(&st->y1, y1);
+        }
+        if (in_) atomicAdd(&st->inter, in_);
+        if (u) atomicAdd(&st->uni, u);
+    }
+}
+
 __global__ void mask_stats_init_kernel(MaskStats* stats, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { MaskStats s; s.area = 0; s.inter = 0; s.uni = 0; s.x0 = 1 << 30; s.y0 = 1 << 30; s.x1 = -1; s.y1 = -1; s.pad = 0; stats[i] = s; }
 }
 
+extern int g_saber_debug_flags;
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
                              int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s) {
     if (n <= 0) return nullptr;
     if (crop_w <= 0 || crop_h <= 0) return "mask_post: empty crop";
     hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, n);
     const dim3 grid((H + MP_ROWS - 1) / MP_ROWS, n);
-    if (W <= 1024) hipLaunchKernelGGL(mask_post_kernel<true>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
+    if (W <= 1024 && !(g_saber_debug_flags & 8)) hipLaunchKernelGGL(mask_post_w1k_kernel, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
+    else if (W <= 1024) hipLaunchKernelGGL(mask_post_kernel<true>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
     else hipLaunchKernelGGL(mask_post_kernel<false>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
     return nullptr;
 }

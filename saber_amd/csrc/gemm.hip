@@ -443,7 +443,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // waves 0-3 own the left 64 columns, waves 4-7 the right 64: one wave of each column half per SIMD, so that in an N-edge tile
+    // whose right half lies beyond N (N = 576, 288, 144: a tenth to a quarter of all tiles' columns) EVERY SIMD loses half of this
+    // workgroup's MFMA + fragment-read work to the co-resident workgroup, not two SIMDs all of it
+    const int wm = wave & 3, wn = wave >> 2;
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
     if (!tile_map(blockIdx.x, tiles_m, tiles_n, &tm, &tn)) return;
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bf16_t* __restrict__ W = p.W + z * p.strideW;
     const int fi = lane & 15, fg = lane >> 4;
     const int nk = (p.K + BK2 - 1) / BK2;
+    const bool cols_live = (n0 + wn * 64 < p.N) || (p.dbg & 2);   // wave-uniform: this wave's 64 columns hold at least one real one
 
     // one wave-instruction = 16 rows x 64 B; per K-tile: A 16 instructions (2 per wave), W 8 (1 per wave)
     const int lrow = lane >> 2, lslot = lane & 3;
@@ -491,17 +495,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (kt + 2 < nk) issue(kt + 2);
         const char* sa = smem + (kt % 3) * G2_STAGE;
         const char* sw = sa + A_BYTES;
-        bf16x8 af[4], wf[4];
+        if (cols_live) {
+            bf16x8 af[4], wf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 64 + i * 16 + fi, fg));
-            wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + i * 16 + fi, fg));
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 64 + i * 16 + fi, fg));
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + i * 16 + fi, fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         // K-tile kt+1 must have landed (this wave's pieces); the youngest one may stay in flight
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
