@@ -2,18 +2,22 @@
 // Replaces nn.LayerNorm / LayerNorm2d calls of the sam2 image model.
 // fp32 statistics (two-pass in registers), outputs: optional fp32, optional bf16,
 // optional bf16 of (y + addvec[row % add_mod]) used for "keys + image_pe".
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
 #define LN_MAX_CHUNKS 5  // 5 * 64 lanes * 4 floats = 1280 channels
 
-// One wave per row, LN_RPW consecutive rows per wave: gamma / beta (and the row's x) live in registers, so a row costs one load and
-// one store instruction per 1-KB chunk instead of three loads (gamma and beta were re-fetched for every row).
-#define LN_RPW 8
+// One wave per row; a wave walks rows wave_id, wave_id + n_waves, ... of a grid sized to ONE resident set of workgroups (<= 8 per CU):
+// gamma / beta (and the row's x) live in registers, so a row costs one load and one store instruction per 1-KB chunk instead of three
+// loads, and there is no second, partly filled round of workgroups (86 016 rows in chunks of 8 per wave were 2 688 workgroups on 2 048
+// slots: a 31 %-full tail round, 70 us where the bytes need 47).
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row0 >= p.rows) return;
     const int nvec = p.C >> 2;
     float4 g[NCH], b[NCH];
@@ -34,10 +38,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
         }
     };
     load_row(row0, v);
-    for (int rr = 0; rr < LN_RPW; ++rr) {
-        const int64_t row = row0 + rr;
-        if (row >= p.rows) break;
-        if (rr + 1 < LN_RPW && row + 1 < p.rows) load_row(row + 1, vn);      // next row in flight while this one is reduced
+    for (int64_t row = row0; row < p.rows; row += n_waves) {
+        if (row + n_waves < p.rows) load_row(row + n_waves, vn);             // next row in flight while this one is reduced
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -86,11 +88,20 @@ const char* launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if ((p.ldx & 3) || (p.ldo & 3)) return "layernorm: strides must be multiples of 4";
     if (p.out_bf_add && (!p.addvec || p.add_mod <= 0)) return "layernorm: addvec missing";
     if (p.row_valid && p.valid_mod <= 0) return "layernorm: valid_mod";
-    const dim3 grid((unsigned)((p.rows + 4 * LN_RPW - 1) / (4 * LN_RPW)));
     const int nch = (p.C / 4 + 63) / 64;
-    if (nch <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, p);
-    else if (nch == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, p);
-    else if (nch == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, p);
+    const int slot = nch <= 1 ? 0 : nch == 2 ? 1 : nch == 3 ? 2 : 3;
+    static int resident[4] = {0, 0, 0, 0};             // workgroups of each instantiation that fit one CU (register budget)
+    if (!resident[slot]) {
+        int nb = 0;
+        const void* fn = slot == 0 ? (const void*)layernorm_kernel<1> : slot == 1 ? (const void*)layernorm_kernel<2>
+                       : slot == 2 ? (const void*)layernorm_kernel<3> : (const void*)layernorm_kernel<LN_MAX_CHUNKS>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 4;
+        resident[slot] = std::min(nb, 8);
+    }
+    const dim3 grid((unsigned)std::min<int64_t>((p.rows + 3) / 4, (int64_t)256 * resident[slot]));
+    if (slot == 0) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, p);
+    else if (slot == 1) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, p);
+    else if (slot == 2) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(layernorm_kernel<LN_MAX_CHUNKS>, grid, dim3(256), 0, s, p);
     return nullptr;
 }
