@@ -564,36 +564,72 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     } else if (fast_f32) {
         float* Cf = p.Cf + z * p.strideCf;
-        // bias and residual: unconditional loads from clamped addresses (clamped lanes are never stored), the residual rows of group
-        // i + 1 in flight while group i is stored - not one waited-for load per accumulator tile
-        const float* bp = p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W);
+        // bias and residual: unconditional loads from clamped addresses (clamped lanes are never stored).  The bias goes into the
+        // accumulators first (its registers die), then the residual rows of group i + 1 are in flight while group i is added and
+        // stored: one exposed HBM latency per tile instead of four (the kernel lives on 128 VGPRs: 64 accumulators + 2 x 16 residual)
+        // residual through a buffer descriptor over this tile's rows: ONE 32-bit per-lane offset for all 16 loads (row group in the
+        // scalar offset, column group in the immediate), rows beyond M read as zero (never stored), no clamps
         const float* rp = p.res ? p.res + z * p.strideRes : p.Cf + z * p.strideCf;     // no residual: any readable fp32 (discarded)
         const int64_t ldr = p.res ? p.ldres : p.ldcf;
-        int ncol[4];
-        float4 bias4[4];
+        const float* rtile = rp + (int64_t)m0 * ldr;
+        const uint32_t rbytes = (uint32_t)(min(256, p.M - m0) * ldr * 4);
+        // (every input is a kernel argument or blockIdx-derived: the descriptor is built in SGPRs without readfirstlane)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rtile, 0, (int)rbytes, 0x00020000);
+        int lane_e = lane;                            // opaque copy: keeps the epilogue's address arithmetic from being hoisted above the
+        asm volatile("" : "+v"(lane_e));              // main loop, where every live register costs a spill (128-register budget)
+        const uint32_t voff = (uint32_t)(((wm * 64 + (lane_e & 15)) * ldr + n0 + wn * 64 + (lane_e >> 4) * 4) * 4);
+        const uint32_t sstep = (uint32_t)(16 * ldr * 4);
+        u32x4 ra[4], rb[4];
+        auto load_group = [&](int i, u32x4 (&rr)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ncol[j] = min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4);
-            bias4[j] = *reinterpret_cast<const float4*>(bp + ncol[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (!p.bias) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // per 16-row group: its 4 residual vectors back to back, one wait, 4 stores (16 registers: the kernel lives on 128 VGPRs)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + fi;
-            const float* rrow = rp + (int64_t)min(m, p.M - 1) * ldr;
-            float4 rr[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(rrow + ncol[j]);
+            for (int j = 0; j < 4; ++j) rr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + j * 64, i * sstep, 0);
+        };
+        load_group(0, ra);
+        {   // unconditional (a branch around the accumulator update doubles their live ranges): no bias = any readable fp32, zeroed
+            const float* bp = p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W);
+            const bool has_bias = p.bias != nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fg * 4;
-                float4 v = make_float4(acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w);
-                if (p.res) { v.x += rr[j].x; v.y += rr[j].y; v.z += rr[j].z; v.w += rr[j].w; }
-                if (m < p.M && n + 3 < p.N) *reinterpret_cast<float4*>(Cf + (int64_t)m * p.ldcf + n) = v;
+                float4 b4 = *reinterpret_cast<const float4*>(bp + min(n0 + wn * 64 + j * 16 + fg * 4, p.N - 4));
+                if (!has_bias) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
             }
         }
+        // output through a descriptor over the same rows of C (rows beyond M are dropped by the range check; columns by the predicate)
+        float* ctile = Cf + (int64_t)m0 * p.ldcf;
+        const __amdgpu_buffer_rsrc_t csrc = __builtin_amdgcn_make_buffer_rsrc((void*)ctile, 0, (int)(uint32_t)(min(256, p.M - m0) * p.ldcf * 4), 0x00020000);
+        const int ncol0 = n0 + wn * 64 + (lane_e >> 4) * 4;
+        const uint32_t coff = (uint32_t)(((wm * 64 + (lane_e & 15)) * p.ldcf + ncol0) * 4);
+        const uint32_t cstep = (uint32_t)(16 * p.ldcf * 4);
+        auto store_group = [&](int i, const u32x4 (&rr)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 v;
+                if (p.res) {
+                    v[0] = __float_as_uint(acc[i][j][0] + __uint_as_float(rr[j][0])); v[1] = __float_as_uint(acc[i][j][1] + __uint_as_float(rr[j][1]));
+                    v[2] = __float_as_uint(acc[i][j][2] + __uint_as_float(rr[j][2])); v[3] = __float_as_uint(acc[i][j][3] + __uint_as_float(rr[j][3]));
+                } else {
+                    v[0] = __float_as_uint(acc[i][j][0]); v[1] = __float_as_uint(acc[i][j][1]); v[2] = __float_as_uint(acc[i][j][2]); v[3] = __float_as_uint(acc[i][j][3]);
+                }
+                if (ncol0 + j * 16 + 3 < p.N) __builtin_amdgcn_raw_buffer_store_b128(v, csrc, coff + j * 64, i * cstep, 0);
+            }
+        };
+        // sched_barrier: without it the scheduler hoists all four load groups to the top (64 more registers: spills)
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(1, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        store_group(0, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(2, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        store_group(1, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(3, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        store_group(2, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        store_group(3, rb);
     } else {
         gemm_epilogue<4>(p, acc, m0, n0, wm, wn, fi, fg, z);
     }
