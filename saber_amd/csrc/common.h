@@ -90,24 +90,36 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return x * r;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-    v = xor16_sum(xor32_sum(v));
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Lane exchanges inside a 16-lane row as DPP modifiers of ordinary VALU instructions (no LDS round trip: ds_bpermute_b32, which
+// __shfl / __shfl_xor compile to, costs ~100 cycles of latency per exchange and shares the LDS pipe with everything else).
+//   quad_perm [1,0,3,2] = lane ^ 1, [2,3,0,1] = lane ^ 2, [q,q,q,q] = broadcast of lane q of the quad;
+//   row_half_mirror (lane i <-> 7 - i of each 8) and row_mirror (i <-> 15 - i) pair the quads / the two halves of a row, which is
+//   all a reduction needs once every lane of a quad (of an 8-group) already holds the same partial result.
+#define DPP_XOR1 0xB1
+#define DPP_XOR2 0x4E
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, true));
+}
+template <int Q> __device__ __forceinline__ float quad_bcast(float x) { return dpp_mov<Q * 0x55>(x); }   // value of lane Q of this lane's quad
+__device__ __forceinline__ float quad_sum(float v) { v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); return v; }
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-    v = xor16_max(xor32_max(v));
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v)); v = fmaxf(v, dpp_mov<DPP_XOR2>(v)); v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
     return v;
 }
-__device__ __forceinline__ float wave_min(float v) {
-    v = xor16_min(xor32_min(v));
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, dpp_mov<DPP_XOR1>(v)); v = fminf(v, dpp_mov<DPP_XOR2>(v)); v = fminf(v, dpp_mov<DPP_HALF_MIRROR>(v)); v = fminf(v, dpp_mov<DPP_MIRROR>(v));
     return v;
 }
+// whole-wave all-reduce: 4 DPP steps inside the rows, then the two permlane swaps across rows
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
+__device__ __forceinline__ float wave_min(float v) { return xor32_min(xor16_min(row16_min(v))); }
 
 // Hiera token order used throughout the engine (DESIGN.md "token order"): for the
 // 256x256 stage-0 grid, index bits are [y7 y6 x7 x6][y5 y4 y3 x5 x4 x3][y2 x2][y1 x1][y0 x0].

@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) mine[c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) h1[qq][c] = __shfl(mine[c], (tid & ~3) | qq, 64);
+        for (int c = 0; c < 4; ++c) {     // the quad's four h1 vectors: DPP quad broadcasts (were 16 ds_bpermute round trips per token)
+            h1[0][c] = quad_bcast<0>(mine[c]); h1[1][c] = quad_bcast<1>(mine[c]); h1[2][c] = quad_bcast<2>(mine[c]); h1[3][c] = quad_bcast<3>(mine[c]);
+        }
         float h2[4];
         mu = 0.f;
 #pragma unroll
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
             h2[cc] = a;
             mu += a;
         }
-        mu += __shfl_xor(mu, 1, 64); mu += __shfl_xor(mu, 2, 64);
+        mu = quad_sum(mu);
         mu *= (1.0f / 16.0f);
         var = 0.f;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) var += (h2[cc] - mu) * (h2[cc] - mu);
-        var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64);
+        var = quad_sum(var);
         rstd = __builtin_amdgcn_rsqf(var * (1.0f / 16.0f) + 1e-6f);
         float4 o;
         o.x = gelu_erf((h2[0] - mu) * rstd * w.g2[4 * q + 0] + w.be2[4 * q + 0]);

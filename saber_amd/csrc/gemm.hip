@@ -73,8 +73,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = (m < p.M) ? v[r] : -3.0e38f;
-                    x = fmaxf(x, __shfl_xor(x, 1, 64));
-                    x = fmaxf(x, __shfl_xor(x, 2, 64));
+                    x = fmaxf(x, dpp_mov<DPP_XOR1>(x));
+                    x = fmaxf(x, dpp_mov<DPP_XOR2>(x));
                     v[r] = x;
                 }
                 writer = writer && ((fi & 3) == 0);
