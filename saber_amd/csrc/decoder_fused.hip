@@ -128,7 +128,7 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <int NW>
+template <int NW, bool STAMPS>
 __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
                                                       const bf16_t* __restrict__ pek, const bf16_t* __restrict__ Qt,
                                                       const float* __restrict__ tq, float qscale,
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     constexpr int T2I_KB = T2ICfg<NW>::KB, T2I_STAGE = T2ICfg<NW>::STAGE, NST = T2ICfg<NW>::NST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // development only (stamps != nullptr), see tools/dec_stamps.py
-#define T2I_STAMP(k) do { if (stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
+#define T2I_STAMP(k) do { if (STAMPS) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qt = wave & 3, kh = wave >> 2;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     if (NST == 3 && nkb > 1) { issue(1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (stamps) tprev = __builtin_amdgcn_s_memtime();
+    if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
     int stage = 0;
     for (int kb = 0; kb < nkb; ++kb) {
         {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
         T2I_STAMP(5);
         stage = stage + 1 == NST ? 0 : stage + 1;
     }
-    if (stamps && lane == 0)
+    if (STAMPS && stamps && lane == 0)
         for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * NW + wave) * 6 + k] = ts[k];
     // merge the two key halves of each q tile: waves 4..7 park (m, l, O) in LDS, waves 0..3 combine and store
     float* mo = reinterpret_cast<float*>(smem) + (size_t)qt * 16 * 260;      // [16 q][256 + 4] floats per q tile
@@ -377,10 +377,14 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
     if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
     extern int g_saber_debug_flags;
-    if (!(g_saber_debug_flags & 4))   // 4-wave workgroups (two per CU, no key-half merge) measure the same as one 8-wave workgroup: kept as an option
-        hipLaunchKernelGGL(dec_t2i_kernel<8>, dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+    if (!(g_saber_debug_flags & 4)) {  // 4-wave workgroups (two per CU, no key-half merge) measure the same as one 8-wave workgroup: kept as an option
+        if (g_saber_stamp_buf)
+            hipLaunchKernelGGL((dec_t2i_kernel<8, true>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+        else
+            hipLaunchKernelGGL((dec_t2i_kernel<8, false>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+    }
     else
-        hipLaunchKernelGGL(dec_t2i_kernel<4>, dim3(P * split), dim3(256), T2ICfg<4>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+        hipLaunchKernelGGL((dec_t2i_kernel<4, false>), dim3(P * split), dim3(256), T2ICfg<4>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
     if (split > 1) hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
@@ -411,7 +415,7 @@ template <int RT> struct I2TCfg {
     static constexpr int LDS = I2T_NSTAGE * STAGE + 2 * PBUF_B + 2 * STAT_B + OSCR_B;
 };
 
-template <int RT>
+template <int RT, bool STAMPS>
 __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
                                                       const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
                                                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // development only (stamps != nullptr): per-wave cycle sums of the phases of the tile loop, see tools/dec_stamps.py
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define I2T_STAMP(k) do { if (stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
+#define I2T_STAMP(k) do { if (STAMPS) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
     char* pbuf = smem + I2T_NSTAGE * I2T_STAGE;                         // [2 rt][16 rows][144 B]
     float* stat = reinterpret_cast<float*>(pbuf + 2 * I2T_PBUF_B);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     issue(0); issue(1); issue(2);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (stamps) tprev = __builtin_amdgcn_s_memtime();
+    if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < NT; ++t) {
         const char* xs = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
         const char* ps = xs + I2T_ROWS * ROW_B;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     finish_tile(NT - 1);
-    if (stamps && lane == 0)
+    if (STAMPS && stamps && lane == 0)
         for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * (4 * RT) + wave) * 6 + k] = ts[k];
 }
 
@@ -632,9 +636,12 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
     if (g_saber_debug_flags & 1)
-        hipLaunchKernelGGL(dec_i2t_kernel<2>, dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+        hipLaunchKernelGGL((dec_i2t_kernel<2, false>), dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
     else
-        hipLaunchKernelGGL(dec_i2t_kernel<1>, dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+        if (g_saber_stamp_buf)
+            hipLaunchKernelGGL((dec_i2t_kernel<1, true>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+        else
+            hipLaunchKernelGGL((dec_i2t_kernel<1, false>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
     return nullptr;
 }
 
@@ -843,10 +850,12 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
 }
 
 const char* decoder_fused_init_device() {
-    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<4>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
+    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<4>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
