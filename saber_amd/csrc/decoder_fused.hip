@@ -55,33 +55,61 @@ __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__
     const int p = blockIdx.x, d = threadIdx.x;
     reinterpret_cast<float4*>(as)[d] = reinterpret_cast<const float4*>(a + (int64_t)p * 1024)[d];
     __syncthreads();
-    for (int h = 0; h < 8; ++h) {
-        float w[16];
-        if (mode == 0) {
+    if (mode == 0) {
+        // thread = (head h, 8 consecutive output columns): 16 coalesced 16-byte loads of W and 8 16-byte stores per thread (one thread
+        // per column did 128 two-byte loads and 64 two-byte stores: the kernel was bound by their issue, 25-40 us per launch)
+        const int h = d >> 5, c0 = (d & 31) * 8;
+        float acc[8][8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) w[j] = bf2f(W[(16 * h + j) * 256 + d]);
-        } else {        // thread d owns row d of W: 32 contiguous bytes per head
-            const uint4 w0 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h), w1 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h + 8);
-            const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { w[2 * j] = __uint_as_float(ww[j] << 16); w[2 * j + 1] = __uint_as_float(ww[j] & 0xffff0000u); }
-        }
-        float r[8];
+            for (int c = 0; c < 8; ++c) acc[t][c] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            float acc = 0.f;
+        for (int j4 = 0; j4 < 4; ++j4) {
+            float w[4][8];
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {       // broadcast reads, 16 bytes at a time
-                const float4 av = *reinterpret_cast<const float4*>(as + t * 128 + 16 * h + 4 * j4);
-                acc += av.x * w[4 * j4] + av.y * w[4 * j4 + 1] + av.z * w[4 * j4 + 2] + av.w * w[4 * j4 + 3];
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint4 u = *reinterpret_cast<const uint4*>(W + (16 * h + 4 * j4 + jj) * 256 + c0);
+                const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { w[jj][2 * k] = __uint_as_float(uu[k] << 16); w[jj][2 * k + 1] = __uint_as_float(uu[k] & 0xffff0000u); }
             }
-            r[t] = acc * scale;
-            if (mode == 0) out[((int64_t)p * 64 + 8 * h + t) * 256 + d] = f2bf(r[t]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float4 av = *reinterpret_cast<const float4*>(as + t * 128 + 16 * h + 4 * j4);      // broadcast read
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[t][c] += av.x * w[0][c] + av.y * w[1][c] + av.z * w[2][c] + av.w * w[3][c];
+            }
         }
-        // Vt^T: rows = channel d, 64 folded columns -> the 8 tokens of head h are 16 contiguous bytes of row d
-        if (mode != 0)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            *reinterpret_cast<uint4*>(out + ((int64_t)p * 64 + 8 * h + t) * 256 + c0) =
+                make_uint4(pack_bf16(acc[t][0] * scale, acc[t][1] * scale), pack_bf16(acc[t][2] * scale, acc[t][3] * scale),
+                           pack_bf16(acc[t][4] * scale, acc[t][5] * scale), pack_bf16(acc[t][6] * scale, acc[t][7] * scale));
+    } else {
+        for (int h = 0; h < 8; ++h) {
+            float w[16];
+            {           // thread d owns row d of W: 32 contiguous bytes per head
+                const uint4 w0 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h), w1 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h + 8);
+                const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { w[2 * j] = __uint_as_float(ww[j] << 16); w[2 * j + 1] = __uint_as_float(ww[j] & 0xffff0000u); }
+            }
+            float r[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {       // broadcast reads, 16 bytes at a time
+                    const float4 av = *reinterpret_cast<const float4*>(as + t * 128 + 16 * h + 4 * j4);
+                    acc += av.x * w[4 * j4] + av.y * w[4 * j4 + 1] + av.z * w[4 * j4 + 2] + av.w * w[4 * j4 + 3];
+                }
+                r[t] = acc * scale;
+            }
+            // Vt^T: rows = channel d, 64 folded columns -> the 8 tokens of head h are 16 contiguous bytes of row d
             *reinterpret_cast<uint4*>(out + ((int64_t)p * 256 + d) * 64 + 8 * h) =
                 make_uint4(pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]), pack_bf16(r[4], r[5]), pack_bf16(r[6], r[7]));
+        }
     }
     if (cb && d < 64) {
         const int h = d >> 3, t = d & 7;
