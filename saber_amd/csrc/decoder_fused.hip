@@ -716,11 +716,12 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         const int row = idx >> 3, ch = idx & 7;
         *reinterpret_cast<u32x4*>(w2s + swz128(row, ch)) = *reinterpret_cast<const u32x4*>(W2p + row * 64 + ch * 8);
     }
-    // per-lane constants of this tile: feat_s1 + b1 (fp32), feat_s0 + b2 (packed bf16), LN parameters
+    // per-lane constants of this tile: feat_s1 + b1 and feat_s0 + b2 (fp32: they are the C operands of the first MFMA of their
+    // accumulator, so adding them costs nothing), LN parameters
     const int tl = mw * 16 + fi;                        // token within the tile: bits [X3 X2 X1][Y0][X0]
     const int tok = tile * UP_TOK + tl;
     float4 f1[4], gg[4], be[4];
-    uint2 f0[4][2];
+    f32x4 f0[4][2];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         gg[ni] = *reinterpret_cast<const float4*>(ln_g + ni * 16 + 4 * fg);
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             for (int hh = 0; hh < 2; ++hh) {
                 const float4 r = *reinterpret_cast<const float4*>(s0 + (((int64_t)tok * 4 + pos) * 4 + pos2) * 32 + hh * 16 + 4 * fg);
                 const float4 b = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
-                f0[pos2][hh] = make_uint2(pack_bf16(r.x + b.x, r.y + b.y), pack_bf16(r.z + b.z, r.w + b.w));
+                f0[pos2][hh] = (f32x4){r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w};
             }
     };
     const int dy1 = pos >> 1, dx1 = pos & 1;
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256
         f32x4 acc[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){f1[ni].x, f1[ni].y, f1[ni].z, f1[ni].w};       // bias + feat_s1 enter as the C operand
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -799,8 +800,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             float v[4][4], sum = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                v[ni][0] = acc[ni][0] + f1[ni].x; v[ni][1] = acc[ni][1] + f1[ni].y;
-                v[ni][2] = acc[ni][2] + f1[ni].z; v[ni][3] = acc[ni][3] + f1[ni].w;
+                v[ni][0] = acc[ni][0]; v[ni][1] = acc[ni][1]; v[ni][2] = acc[ni][2]; v[ni][3] = acc[ni][3];
                 sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
             }
             sum = xor32_sum(xor16_sum(sum));
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         for (int hb = 0; hb < 2; ++hb) {
             f32x4 c2[4];
 #pragma unroll
-            for (int nl = 0; nl < 4; ++nl) c2[nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nl = 0; nl < 4; ++nl) c2[nl] = f0[2 * hb + (nl >> 1)][nl & 1];                       // bias + feat_s0 enter as the C operand
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -846,9 +846,8 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int nl = 2 * pp + hh;
-                    const uint2 fb = f0[pos2][hh];
-                    const f32x2 ua = gelu_erf2((f32x2){c2[nl][0], c2[nl][1]} + (f32x2){__uint_as_float(fb.x << 16), __uint_as_float(fb.x & 0xffff0000u)});
-                    const f32x2 ub = gelu_erf2((f32x2){c2[nl][2], c2[nl][3]} + (f32x2){__uint_as_float(fb.y << 16), __uint_as_float(fb.y & 0xffff0000u)});
+                    const f32x2 ua = gelu_erf2((f32x2){c2[nl][0], c2[nl][1]});
+                    const f32x2 ub = gelu_erf2((f32x2){c2[nl][2], c2[nl][3]});
                     const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
