@@ -47,7 +47,7 @@ def parse():
 
 def cpu_baseline(cfg, weights, image01, crop_n_layers):
     """Oracle ("port") timed on the host cores on a bounded sample: 1 Hiera-L encoder pass + one 64-prompt
-    first-pass decoder batch + its 192 m2m refinements + their full-res post-processing; extrapolated to one slice
+    first-pass decoder batch + its 192 m2m refinements + their stability scores (about 10 s of CPU work); extrapolated to one slice
     by the reference's work counts (21 crops / 3072 + 9216 prompts for crop_n_layers=2)."""
     from oracle import sam2_ref
     from oracle.amg_ref import calculate_stability_score
@@ -68,17 +68,18 @@ def cpu_baseline(cfg, weights, image01, crop_n_layers):
     t0 = time.perf_counter()
     pts3 = pts.repeat_interleave(3, 0)
     lowf = low.flatten(0, 1)
-    m2, i2, _ = P._predict(pts3[:64, None], torch.ones(64, 1, dtype=torch.int64), lowf[:64, None], False)
-    calculate_stability_score(m2.squeeze(1), 0.0, 0.7)
-    t_m2m = 3.0 * (time.perf_counter() - t0)  # one of the three 64-prompt m2m batches is timed
+    for b in range(3):      # the three 64-prompt m2m batches of these 64 grid prompts (SABER's points_per_batch = 64)
+        m2, i2, _ = P._predict(pts3[64 * b:64 * b + 64, None], torch.ones(64, 1, dtype=torch.int64), lowf[64 * b:64 * b + 64, None], False)
+        calculate_stability_score(m2.squeeze(1), 0.0, 0.7)
+    t_m2m = time.perf_counter() - t0
     n_side = [2 ** (i + 1) for i in range(crop_n_layers)]
     n_crops = 1 + sum(n * n for n in n_side)
     n_first = sum((32 // (2 ** l)) ** 2 * (1 if l == 0 else (2 ** l) ** 2) for l in range(crop_n_layers + 1))
     per_slice = n_crops * t_enc + n_first / 64.0 * (t_first + t_m2m)
     return {"value": 1.0 / per_slice, "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 torch CPU, {cores} threads: 1 encoder pass ({t_enc:.2f}s) + 64 grid prompts ({t_first:.2f}s) + 64 of their 192 "
-                      f"m2m refinements incl. stability score (x3 = {t_m2m:.2f}s); extrapolated to {n_crops} crops / {n_first} grid prompts per slice",
-            "seconds_sampled": t_enc + t_first + t_m2m / 3.0}
+            "sample": f"oracle fp32 torch CPU, {cores} threads: 1 encoder pass ({t_enc:.2f}s) + 64 grid prompts ({t_first:.2f}s) + their 192 "
+                      f"m2m refinements incl. stability score ({t_m2m:.2f}s); extrapolated to {n_crops} crops / {n_first} grid prompts per slice",
+            "seconds_sampled": t_enc + t_first + t_m2m}
 
 
 def pmc_traffic():
@@ -89,14 +90,14 @@ def pmc_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")),
                    key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])      # r01_v10 after r01_v9
     if not files:
-        return None
+        return None, None
     try:
         k = json.load(open(files[-1]))["kernels"]
         tot = sum(v["hbm_bytes_total"] for n, v in k.items() if "gemm_bf16" in n)
         cnt = sum(v["launches"] for n, v in k.items() if "gemm_bf16" in n)
-        return {"hbm_bytes_per_launch": tot / max(1, cnt), "source": os.path.basename(files[-1])}
+        return tot / max(1, cnt), os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -225,7 +226,9 @@ def main():
         g = prof["gemm_bf16"]
         total_ms = sum(v["ms"] for v in prof.values())
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(),
+        traffic, traffic_src = pmc_traffic()
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                           "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                            "kernel": "gemm_bf16 (gemm_bf16_glds2_kernel + gemm_bf16_p256s_kernel + gemm_bf16_glds_kernel<4> + gemm_bf16_kernel<T>)", "launches_per_slice": g["launches"],
                            "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
                            "algorithmic_gflop_per_launch": g["flops"] / max(1, g["launches"]) / 1e9,
