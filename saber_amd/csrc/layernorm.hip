@@ -82,12 +82,97 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
     }
 }
 
+// Narrow rows (C <= 192: the 144-channel stage-0 tokens of Hiera-L, 1.4 M rows per slice): FOUR rows per wave, one per 16-lane DPP
+// row, 3 float4 per lane.  With one wave per row only 36 of 64 lanes held data and every 576-byte row paid two whole-wave
+// reductions (2.9 TB/s); here a row's statistics never leave its DPP row (row16_sum: four DPP adds, no permlane swap).
+__global__ __launch_bounds__(256) void layernorm_rows4_kernel(LayerNormParams p) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int64_t n_groups = (int64_t)gridDim.x * 4;                       // wave-sized groups of 4 rows in flight
+    const int64_t g0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nvec = p.C >> 2;
+    float4 g[3], b[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = li + 16 * i;
+        if (c < nvec) { g[i] = *reinterpret_cast<const float4*>(p.gamma + 4 * c); b[i] = *reinterpret_cast<const float4*>(p.beta + 4 * c); }
+        else { g[i] = make_float4(0.f, 0.f, 0.f, 0.f); b[i] = g[i]; }
+    }
+    const float invC = 1.0f / (float)p.C;
+    const int64_t n_row_groups = (p.rows + 3) >> 2;
+    float4 v[3], vn[3];
+    auto load_row = [&](int64_t grp, float4 (&dst)[3]) {
+        const int64_t row = grp * 4 + sub;
+        const float* x = p.x + (row < p.rows ? row : (int64_t)p.rows - 1) * p.ldx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = li + 16 * i;
+            dst[i] = c < nvec ? *reinterpret_cast<const float4*>(x + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (g0 >= n_row_groups) return;
+    load_row(g0, v);
+    for (int64_t grp = g0; grp < n_row_groups; grp += n_groups) {
+        if (grp + n_groups < n_row_groups) load_row(grp + n_groups, vn);
+        const int64_t row = grp * 4 + sub;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = row16_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (li + 16 * i < nvec) {
+                const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + bb * bb) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(row16_sum(q) * invC + p.eps);
+        if (row < p.rows) {
+            const float* addv = p.addvec ? p.addvec + (int64_t)(row % p.add_mod) * p.C : nullptr;
+            const bool zero_row = p.row_valid && !p.row_valid[row % p.valid_mod];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = li + 16 * i;
+                if (c < nvec) {
+                    float y0 = (v[i].x - mean) * rstd * g[i].x + b[i].x;
+                    float y1 = (v[i].y - mean) * rstd * g[i].y + b[i].y;
+                    float y2 = (v[i].z - mean) * rstd * g[i].z + b[i].z;
+                    float y3 = (v[i].w - mean) * rstd * g[i].w + b[i].w;
+                    if (p.act == ACT_GELU) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+                    if (zero_row) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
+                    if (p.out_f) *reinterpret_cast<float4*>(p.out_f + row * p.ldo + 4 * c) = make_float4(y0, y1, y2, y3);
+                    if (p.out_bf)
+                        *reinterpret_cast<uint2*>(p.out_bf + row * p.ldo + 4 * c) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+                    if (p.out_bf_add) {
+                        const float4 a = *reinterpret_cast<const float4*>(addv + 4 * c);
+                        *reinterpret_cast<uint2*>(p.out_bf_add + row * p.ldo + 4 * c) =
+                            make_uint2(pack_bf16(y0 + a.x, y1 + a.y), pack_bf16(y2 + a.z, y3 + a.w));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = vn[i];
+    }
+}
+
 const char* launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if (p.rows <= 0) return nullptr;
     if ((p.C & 3) || p.C > LN_MAX_CHUNKS * 256) return "layernorm: C must be a multiple of 4 and <= 1280";
     if ((p.ldx & 3) || (p.ldo & 3)) return "layernorm: strides must be multiples of 4";
     if (p.out_bf_add && (!p.addvec || p.add_mod <= 0)) return "layernorm: addvec missing";
     if (p.row_valid && p.valid_mod <= 0) return "layernorm: valid_mod";
+    if (p.C <= 192 && p.rows >= 4096) {        // narrow rows: four per wave
+        static int resident4 = 0;
+        if (!resident4) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)layernorm_rows4_kernel, 256, 0) != hipSuccess || nb < 1) nb = 4;
+            resident4 = std::min(nb, 8);
+        }
+        const int64_t groups = (p.rows + 3) / 4;
+        hipLaunchKernelGGL(layernorm_rows4_kernel, dim3((unsigned)std::min<int64_t>((groups + 3) / 4, (int64_t)256 * resident4)), dim3(256), 0, s, p);
+        return nullptr;
+    }
     const int nch = (p.C / 4 + 63) / 64;
     const int slot = nch <= 1 ? 0 : nch == 2 ? 1 : nch == 3 ? 2 : 3;
     static int resident[4] = {0, 0, 0, 0};             // workgroups of each instantiation that fit one CU (register budget)

@@ -104,7 +104,7 @@ def test_gemm_act_last_and_res_mod(gpu_lib):
     assert (out_f.cpu().double() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("rows,C,act", [(1000, 144, 0), (333, 576, 0), (64, 1152, 0), (4096, 64, 1), (17, 256, 0)])
+@pytest.mark.parametrize("rows,C,act", [(1000, 144, 0), (333, 576, 0), (64, 1152, 0), (4096, 64, 1), (17, 256, 0), (5001, 144, 0), (4099, 192, 1), (70003, 144, 0)])
 def test_layernorm(gpu_lib, rows, C, act):
     g = torch.Generator().manual_seed(C)
     x = torch.randn(rows, C, generator=g) * 3 + 1
