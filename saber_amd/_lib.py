@@ -90,6 +90,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if os.environ.get("SABER_AMD_LIB"):         # development: A/B a differently built library (tools/ab_lib.sh)
+        globals()["LIB_PATH"] = os.environ["SABER_AMD_LIB"]
     if not os.path.exists(LIB_PATH):
         raise SaberAmdError(f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
                             f"(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
