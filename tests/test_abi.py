@@ -59,6 +59,23 @@ def test_engine_wrapper_fails_loudly_without_device(monkeypatch):
         Engine("huge")
 
 
+def test_filters_fail_loudly_without_device():
+    """the volume filters have no CPU path either: numpy in, but the arithmetic only exists in the HIP library"""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("has a GPU")
+    from saber_amd.filters import fast_3d_gaussian_smoothing, gaussian_smoothing_3d
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fast_3d_gaussian_smoothing(np.ones((4, 8, 8), np.uint16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gaussian_smoothing_3d(np.ones((4, 8, 8), bool), 1.0)
+    with pytest.raises(ValueError):                     # argument checks come first, as in the reference
+        fast_3d_gaussian_smoothing(np.ones((8, 8), np.uint16))
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        gaussian_smoothing_3d(np.ones((4, 8, 8), bool), 1.0, device="cpu")
+
+
 def test_token_order_tiles_every_hiera_l_window(lib):
     """every Hiera-L attention window is a contiguous aligned run of rows; 2x2 pooling groups are 4 consecutive rows"""
     for stage, win in ((0, 8), (1, 4), (2, 16), (3, 8)):
