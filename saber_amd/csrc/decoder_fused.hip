@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+typedef unsigned int u32x2_d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x4 tr_read_d(const char* p) {
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
     return __builtin_bit_cast(bf16x4, v);
@@ -278,12 +279,29 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
         l += sum;
         const bf16x8 pf = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
         T2I_STAMP(2);
+        // V^T fragments through inline asm, four output tiles per wait: a compiler-visible ds_read_b64_tr_b16 is ordered behind the
+        // direct-to-LDS loads of the NEXT key block with s_waitcnt vmcnt(0) (the prefetch then ended between the softmax and
+        // the PV products instead of at the end of the iteration; measured effect small: the block is bound by the issue of its two
+        // waves per SIMD, ~1 500 cycles each per 64-key block, not by the wait)
+        {
+            const uint32_t va = (uint32_t)(uintptr_t)(lptr_d)(xs + vrow * ROW_B + vlow);
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt) {
-            const int sw = ((2 * dt + vsel) ^ (vrow & 15)) << 4;       // rows vrow and vrow+16 share (row & 15)
-            const char* base = xs + vrow * ROW_B + sw + vlow;
-            const bf16x8 vf = cat4_d(tr_read_d(base), tr_read_d(base + 16 * ROW_B));
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            for (int d4 = 0; d4 < 16; d4 += 4) {
+                u32x2_d lo[4], hi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sw = ((2 * (d4 + j) + vsel) ^ (vrow & 15)) << 4;       // rows vrow and vrow+16 share (row & 15)
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[j]) : "v"(va + sw) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(hi[j]) : "v"(va + sw) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8 vf = cat4_d(__builtin_bit_cast(bf16x4, lo[j]), __builtin_bit_cast(bf16x4, hi[j]));
+                    o[d4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d4 + j], 0, 0, 0);
+                }
+            }
         }
         T2I_STAMP(3);
         // next block landed (this wave's part); with 3 stages the one after it stays in flight
