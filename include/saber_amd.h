@@ -81,7 +81,8 @@ typedef struct saber_mask_meta {
     float crop_box_xywh[4];
 } saber_mask_meta;
 
-/* trunk: "large" (Hiera-L).  max_images: crops encoded per batched pass / feature slots kept resident.
+/* trunk: "tiny" | "small" | "base" | "large" (the four sam2.1 Hiera trunks SABER can name, saber/adapters/base.py:28-33;
+ * anything else is SABER_ERR_INVALID).  max_images: crops encoded per batched pass / feature slots kept resident.
  * max_prompts: prompts decoded per batched pass. */
 int saber_engine_create(int device_id, const char* trunk, int max_images, int max_prompts, saber_engine** out);
 void saber_engine_destroy(saber_engine* e);
@@ -95,6 +96,11 @@ int saber_engine_finalize(saber_engine* e);
 
 /* K0.  img_dev: (H,W) uint16 or float32.  out_dev: (H,W) float32 in [0,1]. */
 int saber_prepare(saber_engine* e, const void* img_dev, int dtype, int H, int W, float* out_dev, void* stream);
+/* K0 for an (H,W,3) float32 array, as the reference's segment_image_2d treats RGB input (saber/adapters/sam2/predictor.py:58-59 ->
+ * saber/utils/preprocessing.py:67-80): uniform_filter(size=500, reflect) over all three axes of the array (channel axis included),
+ * clip +-3 sigma, ONE global min/max.  img_dev, out_dev: (H,W,3) interleaved float32.  Like saber_prepare it needs a created
+ * handle only (no weights). */
+int saber_prepare_rgb(saber_engine* e, const float* img_dev, int H, int W, float* out_dev, void* stream);
 
 /* Encode n crops of one image.  img_dev: (H,W) [channels==1] or (H,W,3) float32 in [0,1];
  * crop_boxes_host: n x [x0,y0,x1,y1].  Features stay resident in slots slot0..slot0+n-1. */
@@ -111,7 +117,10 @@ int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const i
                         const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream);
 
 /* Automatic mask generation for one image.  out_bits_dev: (max_masks, H, ceil(W/32)) uint32, bit b of word w of row y
- * = pixel (y, 32w+b).  out_meta_host: max_masks records.  Synchronises the stream before returning (a count is returned). */
+ * = pixel (y, 32w+b).  out_meta_host: max_masks records.  Synchronises the stream before returning (a count is returned).
+ * More than max_masks results: SABER_ERR_CAPACITY with *out_count = the capacity needed (nothing is written).
+ * params->points_per_batch is accepted for cfgAMG parity and does NOT change any result: prompts are independent of each other in
+ * SAM2's decoder, so the engine decodes them in batches of its own max_prompts (upstream batches only to bound memory). */
 int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* params,
                        uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta_host, int* out_count, void* stream);
 

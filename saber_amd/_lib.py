@@ -14,6 +14,10 @@ class SaberAmdError(RuntimeError):
     pass
 
 
+# status codes of include/saber_amd.h
+SABER_OK, SABER_ERR_INVALID, SABER_ERR_STATE, SABER_ERR_HIP, SABER_ERR_CAPACITY = 0, -1, -2, -3, -4
+
+
 def build(verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into saber_amd/libsaber_amd.so (in-tree)."""
     r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
@@ -52,6 +56,7 @@ SIGNATURES = {
     "saber_engine_set_weight": (_i, [_vp, C.c_char_p, _vp, _i64p, _i]),
     "saber_engine_finalize": (_i, [_vp]),
     "saber_prepare": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "saber_prepare_rgb": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "saber_encode": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _i, _i, _vp]),
     "saber_get_features": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "saber_decode_points": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -27,8 +27,18 @@ def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_imag
     src = pretrained_weights.resolve_weights(sam2_cfg, checkpoint)
     key = (idx, sam2_cfg, tuple(sorted(src.items())), replica)
     if key not in _ENGINES:
-        _ENGINES[key] = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, **src)
+        eng = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, **src)
+        eng._build = (sam2_cfg, checkpoint)       # what get_replica() needs to build an identical handle
+        _ENGINES[key] = eng
     return _ENGINES[key]
+
+
+def get_replica(engine, replica: int):
+    """A further handle of the SAME model (trunk and weights) as `engine` on the same device.  The z-loop keeps several slices in
+    flight per GPU; every handle must segment with the model slice 0 was segmented with, whatever the adapter's `cfg` field says
+    (the AMG model is chosen by amg_cfg.sam2_cfg, reference automask.py:61)."""
+    sam2_cfg, checkpoint = getattr(engine, "_build", (engine.cfg.name, None))
+    return get_engine(sam2_cfg, engine.device, checkpoint, max_images=engine.max_images, max_prompts=engine.max_prompts, replica=replica)
 
 
 def get_default() -> Dict[str, Any]:

@@ -47,12 +47,11 @@ class SAM2Adapter(BaseAdapter):
     def segment_image_2d(self, image: np.ndarray, text_prompt: str = None, threshold: float = None) -> List[Dict[str, Any]]:
         """(H,W) gray or (H,W,3) image of any float range -> SAM-AMG dict list (caller owns the arrays)."""
         gen = self._generator()
-        if image.ndim == 2:
-            img = prep.prepare(image, gen.base_generator.engine, to_rgb=True)
-        else:
-            # the reference normalises an RGB array with one global min/max after the per-pixel contrast step; the
-            # uniform_filter then runs over the channel axis too - a path no SABER caller uses (images are gray).
-            raise NotImplementedError("segment_image_2d: only (H,W) grayscale slices are supported on the device path")
+        if image.ndim not in (2, 3) or (image.ndim == 3 and image.shape[2] != 3):
+            raise ValueError(f"segment_image_2d: expected (H,W) or (H,W,3), got {image.shape}")
+        # (H,W): gray slice, the reference repeats it to 3 channels (to_rgb=True).  (H,W,3): the reference passes the array
+        # through prepare(to_rgb=False): box filter over all three axes, one global min/max (predictor.py:58-59)
+        img = prep.prepare(image, to_rgb=image.ndim == 2, engine=gen.base_generator.engine)
         return gen.generate(img)
 
     # ------------------------------------------------------------------ video path: next row

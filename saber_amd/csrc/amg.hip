@@ -83,7 +83,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     if (prm->points_per_side <= 0 || prm->points_per_batch <= 0 || prm->crop_n_layers < 0 || prm->crop_n_layers > 4 ||
         prm->crop_n_points_downscale_factor <= 0)
         return eng_fail(e, SABER_ERR_INVALID, "amg_generate: bad cfgAMG value");
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     *out_count = 0;
     const int W32 = (W + 31) >> 5;
@@ -115,17 +115,17 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     }
     const size_t max_prompts = max_pts * M;
     if (e->amg_prompts_cap < max_prompts) {
-        TRY(eng_alloc(e, &e->amg_pts, max_pts * 2));
-        TRY(eng_alloc(e, &e->amg_pts2, max_prompts * 2));
-        TRY(eng_alloc(e, &e->amg_low1, max_prompts * 65536));
-        TRY(eng_alloc(e, &e->amg_iou1, max_prompts));
-        TRY(eng_alloc(e, &e->amg_low2, max_prompts * 65536));
-        TRY(eng_alloc(e, &e->amg_iou2, max_prompts));
+        TRY(eng_regrow(e, &e->amg_pts, max_pts * 2, s));
+        TRY(eng_regrow(e, &e->amg_pts2, max_prompts * 2, s));
+        TRY(eng_regrow(e, &e->amg_low1, max_prompts * 65536, s));
+        TRY(eng_regrow(e, &e->amg_iou1, max_prompts, s));
+        TRY(eng_regrow(e, &e->amg_low2, max_prompts * 65536, s));
+        TRY(eng_regrow(e, &e->amg_iou2, max_prompts, s));
         e->amg_prompts_cap = max_prompts;
     }
     if (e->amg_stats_cap < max_prompts) {
-        TRY(eng_alloc(e, &e->amg_stats, max_prompts));
-        TRY(eng_alloc(e, &e->amg_idx, max_prompts));
+        TRY(eng_regrow(e, &e->amg_stats, max_prompts, s));
+        TRY(eng_regrow(e, &e->amg_idx, max_prompts, s));
         e->amg_stats_cap = max_prompts;
     }
 

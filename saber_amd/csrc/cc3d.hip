@@ -152,7 +152,7 @@ extern "C" int saber_separate_masks(saber_engine* e, const uint16_t* planes_dev,
     hipStream_t s = (hipStream_t)stream;
     uint32_t *lab = nullptr, *list = nullptr, *counter = nullptr;
     auto cleanup = [&]() { (void)hipFree(lab); (void)hipFree(list); (void)hipFree(counter); };
-    CC_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     const uint32_t min_vol = min_mask_area > 0 ? (uint32_t)std::min<int64_t>((int64_t)min_mask_area * 10, 0x7fffffff) : 0u;   // utils.py:113
     // a kept component has >= max(min_vol, 1) voxels; isolated voxels of a 26-connected labelling are >= 2 apart in every axis
     const int64_t cap64 = min_vol > 1 ? n / min_vol + 1 : (int64_t)((Z + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) + 1;

@@ -121,6 +121,20 @@ void prof_end(saber_engine* e, hipStream_t s);
     } while (0)
 
 int eng_fail(saber_engine* e, int code, const std::string& msg);
+// Binds the calling thread to the engine's device for the duration of one C-ABI call and restores the caller's current device on
+// return (a caller whose torch current device is M must not find it switched to the engine's device N afterwards).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t st = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) st = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ENG_DEVICE(e)                                                                                  \
+    DeviceGuard _dev_guard((e)->device);                                                               \
+    if (_dev_guard.st != hipSuccess) return eng_fail((e), SABER_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.st))
 #define ENG_HIP(e, call)                                                                              \
     do {                                                                                              \
         hipError_t _st = (call);                                                                      \
@@ -142,3 +156,13 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
 template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count);
 int eng_alloc_bytes(saber_engine* e, void** p, size_t bytes);
 void eng_free(saber_engine* e, void* p);
+// grow-on-demand workspaces: waits for the stream, releases the previous allocation (if any) and allocates `count` elements
+template <typename T> int eng_regrow(saber_engine* e, T** p, size_t count, hipStream_t s) {
+    if (*p) {
+        hipError_t st = hipStreamSynchronize(s);
+        if (st != hipSuccess) return eng_fail(e, SABER_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(st));
+        eng_free(e, *p);
+        *p = nullptr;
+    }
+    return eng_alloc(e, p, count);
+}

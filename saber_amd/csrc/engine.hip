@@ -255,7 +255,7 @@ static double bicubic_sample(const float* plane, int h, int w, int oy, int ox, i
 extern "C" int saber_engine_finalize(saber_engine* e) {
     if (!e) return SABER_ERR_INVALID;
     if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "finalize called twice");
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     Finalizer F{e};
     const int C0 = e->embed_dim;
     const std::string t = "image_encoder.trunk.";
@@ -530,7 +530,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->counts_ws, 2 * P));
     TRY(eng_alloc(e, &e->dec_out_masks, P * 3 * 65536));
     TRY(eng_alloc(e, &e->dec_out_iou, P * 3));
-    TRY(eng_alloc(e, &e->prep_minmax, 4));
+    if (!e->prep_minmax) TRY(eng_alloc(e, &e->prep_minmax, 4));
     // dense positional encoding projected by the image-side weight of every cross attention (model constants for dec_t2i / dec_i2t)
     {
         auto project = [&](AttnW& a, const LinW& w) -> int {
@@ -573,7 +573,7 @@ extern "C" int saber_profile_begin(saber_engine* e) {
 }
 extern "C" int saber_profile_end(saber_engine* e, saber_profile_class* out, int n_classes) {
     if (!e || !out || n_classes < PC_N) return e ? eng_fail(e, SABER_ERR_INVALID, "profile_end: need room for all classes") : SABER_ERR_INVALID;
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     ENG_HIP(e, hipDeviceSynchronize());
     e->prof_on = false;
     for (int i = 0; i < n_classes; ++i) { out[i].launches = 0; out[i].ms = 0.0; out[i].flops = 0.0; out[i].bytes = 0.0; }
@@ -603,22 +603,33 @@ static const char* ln_run(const float* x, const LnW& w, float eps, int rows, int
 }
 
 // ------------------------------------------------------------------------------------------------ K0
-extern "C" int saber_prepare(saber_engine* e, const void* img_dev, int dtype, int H, int W, float* out_dev, void* stream) {
-    if (!e) return SABER_ERR_INVALID;
-    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+static int prepare_common(saber_engine* e, const void* img_dev, int dtype, int H, int W, int channels, float* out_dev, hipStream_t s) {
+    // K0 needs the device binding and scratch only: it also runs on a handle without weights (saber_amd.utils.preprocessing.prepare)
     if (!img_dev || !out_dev || H <= 0 || W <= 0) return eng_fail(e, SABER_ERR_INVALID, "prepare: bad argument");
-    ENG_HIP(e, hipSetDevice(e->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t need = (size_t)4 * H * W;
+    if (!e->prep_minmax) TRY(eng_alloc(e, &e->prep_minmax, 4));
+    const size_t need = (size_t)4 * H * W * channels;
     if (e->prep_ws_elems < need) {
-        TRY(eng_alloc(e, &e->prep_ws, need));
+        TRY(eng_regrow(e, &e->prep_ws, need, s));
         e->prep_ws_elems = need;
     }
-    if (dtype == SABER_U16) ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_prepare_u16((const uint16_t*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
+    if (channels == 3) {
+        if (dtype != SABER_F32) return eng_fail(e, SABER_ERR_INVALID, "prepare: (H,W,3) input must be float32");
+        ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_prepare_rgb_f32((const float*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
+    } else if (dtype == SABER_U16) ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_prepare_u16((const uint16_t*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
     else if (dtype == SABER_F32) ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_prepare_f32((const float*)img_dev, H, W, out_dev, e->prep_ws, e->prep_minmax, s));
     else return eng_fail(e, SABER_ERR_INVALID, "prepare: dtype must be SABER_U16 or SABER_F32");
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;
+}
+extern "C" int saber_prepare(saber_engine* e, const void* img_dev, int dtype, int H, int W, float* out_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    ENG_DEVICE(e);
+    return prepare_common(e, img_dev, dtype, H, W, 1, out_dev, (hipStream_t)stream);
+}
+extern "C" int saber_prepare_rgb(saber_engine* e, const float* img_dev, int H, int W, float* out_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    ENG_DEVICE(e);
+    return prepare_common(e, img_dev, SABER_F32, H, W, 3, out_dev, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
@@ -720,7 +731,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
 extern "C" int saber_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crop_boxes_host, int n,
                             int slot0, void* stream) {
     if (!e) return SABER_ERR_INVALID;
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     return eng_encode(e, img_dev, H, W, channels, crop_boxes_host, n, slot0, (hipStream_t)stream);
 }
 
@@ -728,7 +739,7 @@ extern "C" int saber_get_features(saber_engine* e, int slot, float* image_embed,
     if (!e) return SABER_ERR_INVALID;
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
     if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot]) return eng_fail(e, SABER_ERR_STATE, "get_features: slot holds no encoded image; call saber_encode first");
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     if (image_embed) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_unpermute_nchw(e->emb + (size_t)slot * 4096 * 256, 256, 2, image_embed, s));
     if (feat_s1) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_unpermute_nchw(e->fs1 + (size_t)slot * 16384 * 64, 64, 1, feat_s1, s));
@@ -879,7 +890,7 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
 extern "C" int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                                    const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream) {
     if (!e) return SABER_ERR_INVALID;
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     return eng_decode(e, slot, 0, pts_dev, labels_dev, n, multimask, mask_in_dev, 0.f, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
 }
 
@@ -889,11 +900,11 @@ extern "C" int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, cons
     if (!e) return SABER_ERR_INVALID;
     if (!plane_dev || H <= 0 || W <= 0 || n < 0 || (n > 0 && !bits_dev)) return eng_fail(e, SABER_ERR_INVALID, "label_plane: bad argument");
     if (n > 65535) return eng_fail(e, SABER_ERR_INVALID, "label_plane: more than 65535 masks do not fit a uint16 plane");
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     int* od = nullptr;
     if (order_host && n > 0) {
-        if (e->order_cap < (size_t)n) { TRY(eng_alloc(e, &e->order_dev, (size_t)n)); e->order_cap = n; }
+        if (e->order_cap < (size_t)n) { TRY(eng_regrow(e, &e->order_dev, (size_t)n, s)); e->order_cap = n; }
         ENG_HIP(e, hipMemcpyAsync(e->order_dev, order_host, sizeof(int) * n, hipMemcpyHostToDevice, s));
         od = e->order_dev;
     }
@@ -906,7 +917,7 @@ extern "C" int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, cons
 extern "C" int saber_mask_pair_intersections(saber_engine* e, const uint32_t* bits_dev, int n, int H, int W, int32_t* out_inter_dev, void* stream) {
     if (!e) return SABER_ERR_INVALID;
     if (n < 0 || H <= 0 || W <= 0 || (n > 0 && (!bits_dev || !out_inter_dev))) return eng_fail(e, SABER_ERR_INVALID, "mask_pair_intersections: bad argument");
-    ENG_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     ENG_KP(e, PC_MASK_POST, 0.0, (double)n * n * 0.5 * H * ((W + 31) / 32) * 8.0, launch_pair_intersections(bits_dev, n, (int64_t)H * ((W + 31) >> 5), out_inter_dev, s));
     ENG_HIP(e, hipGetLastError());

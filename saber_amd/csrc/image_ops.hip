@@ -136,6 +136,43 @@ static const char* prepare_impl(const TIN* img, int H, int W, float* out, float*
     return nullptr;
 }
 
+// (H,W,3) input (reference: prep.prepare on an RGB array, saber/utils/preprocessing.py:67-80 via adapters/sam2/predictor.py:58-59):
+// scipy's uniform_filter(size=500) runs over ALL three axes of the array, the channel axis included (axis order 0, 1, 2, each pass
+// rounded to the array's dtype).  Along the 3-long channel axis the reflect-extended line has period 6 (a b c c b a), so a 500-wide
+// window holds 83 periods plus two more samples: out[0] = (166 S + 2c) / 500, out[1] = (166 S + c + b) / 500, out[2] = (166 S + b + a) / 500
+// with S = a + b + c (window = [i - 250, i + 249]).
+__global__ __launch_bounds__(256) void channel_box3_kernel(float* __restrict__ m, float* __restrict__ q, int64_t npix) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* p = (t ? q : m) + 3 * i;
+            const double a = p[0], b = p[1], c = p[2], S = 166.0 * (a + b + c);
+            p[0] = (float)((S + c + c) / 500.0);
+            p[1] = (float)((S + c + b) / 500.0);
+            p[2] = (float)((S + b + a) / 500.0);
+        }
+    }
+}
+
+const char* launch_prepare_rgb_f32(const float* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s) {
+    // ws: 4 planes of 3*H*W floats
+    const int size = 500;
+    const int64_t n = (int64_t)H * W * 3;
+    float *t1 = ws, *t2 = ws + n, *mean = ws + 2 * n, *sq = ws + 3 * n;
+    auto lds_bytes = [&](int L) { const int npad = ((L + size - 1 + 255) / 256) * 256; return (size_t)2 * (npad + 1) * sizeof(double); };
+    if (lds_bytes(H) > 152 * 1024 || lds_bytes(W) > 152 * 1024) return "prepare: image side too large for the LDS line buffer";
+    hipLaunchKernelGGL((box_filter_lines_kernel<float, true>), dim3(3 * W), dim3(256), lds_bytes(H), s, img, (const float*)nullptr, t1, t2, H,
+                       (int64_t)1, (int64_t)3 * W, size);
+    for (int c = 0; c < 3; ++c)
+        hipLaunchKernelGGL((box_filter_lines_kernel<float, false>), dim3(H), dim3(256), lds_bytes(W), s, (const float*)(t1 + c), (const float*)(t2 + c),
+                           mean + c, sq + c, W, (int64_t)3 * W, (int64_t)3, size);
+    hipLaunchKernelGGL(channel_box3_kernel, dim3(1024), dim3(256), 0, s, mean, sq, (int64_t)H * W);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, minmax);
+    hipLaunchKernelGGL((contrast_kernel<float>), dim3(1024), dim3(256), 0, s, img, (const float*)mean, (const float*)sq, t1, n, 3.0f, minmax);
+    hipLaunchKernelGGL(minmax_normalize_kernel, dim3(1024), dim3(256), 0, s, (const float*)t1, out, n, (const unsigned int*)minmax);
+    return nullptr;
+}
+
 const char* launch_prepare_u16(const uint16_t* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s) {
     return prepare_impl<uint16_t>(img, H, W, out, ws, minmax, s);
 }

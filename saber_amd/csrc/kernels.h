@@ -57,6 +57,7 @@ const char* hiera_attention_init_device();
 // ------------------------------------------------------------------ image_ops.hip
 const char* launch_prepare_u16(const uint16_t* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s);
 const char* launch_prepare_f32(const float* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s);
+const char* launch_prepare_rgb_f32(const float* img, int H, int W, float* out, float* ws, unsigned int* minmax, hipStream_t s);   // (H,W,3) interleaved
 const char* launch_resize_normalize(const float* img, int H, int W, int channels, const int* crops_dev, int n, float* out, int res,
                                     hipStream_t s);
 const char* launch_patch_embed(const float* pix, const float* wt, const float* bias, const float* pos, float* out, int n_images,

@@ -249,7 +249,7 @@ static int sm_run(saber_engine* e, const void* vol_dev, int elem_bytes, int Z, i
     const int64_t n = (int64_t)Z * H * W;
     SmScratch S;
     auto cleanup = [&]() { S.release(); };
-    SM_HIP(e, hipSetDevice(e->device));
+    ENG_DEVICE(e);
     if (out_n_labels) *out_n_labels = 0;
     SM_HIP(e, hipMalloc(&S.maxv, 4));
     SM_HIP(e, hipMemsetAsync(S.maxv, 0, 4, s));

@@ -89,8 +89,16 @@ class Engine:
 
     # ------------------------------------------------------------------ K0
     def prepare(self, img: torch.Tensor) -> torch.Tensor:
-        """prep.prepare on device.  img: (H,W) uint16 or float32 device tensor -> (H,W) float32 in [0,1]."""
-        assert img.is_cuda and img.dim() == 2 and img.is_contiguous()
+        """prep.prepare on device.  img: (H,W) uint16 or float32 device tensor -> (H,W) float32 in [0,1];
+        (H,W,3) float32 -> (H,W,3) float32 (the reference's treatment of an RGB array: box filter over all three axes, one min/max)."""
+        assert img.is_cuda and img.is_contiguous()
+        if img.dim() == 3:
+            if img.shape[2] != 3 or img.dtype != torch.float32:
+                raise ValueError(f"prepare: a 3-D input must be (H,W,3) float32, got {tuple(img.shape)} {img.dtype}")
+            out = torch.empty(img.shape, dtype=torch.float32, device=img.device)
+            self._check(self.lib.saber_prepare_rgb(self.h, _ptr(img), img.shape[0], img.shape[1], _ptr(out), _stream()))
+            return out
+        assert img.dim() == 2
         if img.dtype == torch.uint16:
             dt = SABER_U16
         elif img.dtype == torch.float32:
@@ -147,7 +155,11 @@ class Engine:
         bits = torch.empty((max_masks, H, W32), dtype=torch.int32, device=self.device)
         meta = (_lib.MaskMeta * max_masks)()
         cnt = C.c_int(0)
-        self._check(self.lib.saber_amg_generate(self.h, _ptr(img), H, W, ch, C.byref(params), _ptr(bits), max_masks, meta, C.byref(cnt), _stream()))
+        st = self.lib.saber_amg_generate(self.h, _ptr(img), H, W, ch, C.byref(params), _ptr(bits), max_masks, meta, C.byref(cnt), _stream())
+        if st == _lib.SABER_ERR_CAPACITY and cnt.value > max_masks:
+            # the engine reports the count it needed: retry once with that capacity instead of failing the slice
+            return self.amg_generate(img, params, max_masks=cnt.value)
+        self._check(st)
         n = cnt.value
         return bits[:n], [meta[i] for i in range(n)]
 

@@ -83,10 +83,9 @@ class propagationSegmenter(saber3D):
         eng, params = gen.base_generator.engine, gen.base_generator.params
         engines = [eng]
         if handles_per_gpu > 1:
-            from saber_amd.adapters.sam2.automask import get_engine
-            cfg = self.adapter_cfg
-            engines += [get_engine(cfg.cfg, eng.device, getattr(cfg, "checkpoint", None), max_images=eng.max_images,
-                                   max_prompts=eng.max_prompts, replica=r) for r in range(1, handles_per_gpu)]
+            # replicas of the PRIMARY engine's model (the adapter's own `cfg` field may name another trunk)
+            from saber_amd.adapters.sam2.automask import get_replica
+            engines += [get_replica(eng, r) for r in range(1, handles_per_gpu)]
 
         def make(engine):
             def one(z):
@@ -94,7 +93,7 @@ class propagationSegmenter(saber3D):
                 if isinstance(sl, np.ndarray):
                     sl = torch.from_numpy(np.ascontiguousarray(sl if sl.dtype == np.uint16 else sl.astype(np.float32))).to(engine.device)
                 plane, _ = segment_slice_to_plane(engine, sl, params, min_mask_area=self.min_mask_area,
-                                                  remove_repeating_masks=self.remove_repeating_masks)
+                                                  remove_repeating_masks=self.remove_repeating_masks, max_masks=gen.base_generator.max_masks)
                 return plane
             return one
 

@@ -34,8 +34,10 @@ def select_and_order(meta, inter: np.ndarray, min_mask_area: int, remove_repeati
 
 
 def segment_slice_to_plane(engine, raw_slice: torch.Tensor, params, min_mask_area: int = 50,
-                           remove_repeating_masks: bool = True, max_masks: int = 1024) -> Tuple[torch.Tensor, int]:
-    """raw_slice: (H,W) uint16/float32 device tensor.  Returns ((H,W) uint16 label plane on device, n masks)."""
+                           remove_repeating_masks: bool = True, max_masks: int = 2048) -> Tuple[torch.Tensor, int]:
+    """raw_slice: (H,W) uint16/float32 device tensor.  Returns ((H,W) uint16 label plane on device, n masks).
+    max_masks is the same capacity the adapter path uses (EngineMaskGenerator.max_masks); a denser slice is retried once with the
+    count the engine reports instead of failing the volume."""
     H, W = raw_slice.shape
     img = engine.prepare(raw_slice)
     bits, meta = engine.amg_generate(img, params, max_masks=max_masks)

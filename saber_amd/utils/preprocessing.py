@@ -28,16 +28,38 @@ def project_tomogram(vol, zSlice: Optional[int] = None, deltaZ: Optional[int] = 
     return np.mean(vol[z0:z1, ], axis=0)
 
 
-def prepare(image, engine, to_rgb: bool = False) -> torch.Tensor:
-    """image: (H,W) numpy or device tensor (uint16 / float).  Returns the (H,W) float32 device tensor in [0,1];
-    `to_rgb` is accepted for signature parity: the 3x channel repeat of the reference is folded into the
-    encoder's pixel kernel (a gray plane is broadcast to the three ImageNet-normalised channels)."""
+_K0_HANDLES = {}
+
+
+def _k0_engine(device):
+    """a weight-less handle per device: K0 needs the device binding and scratch only"""
+    from saber_amd.engine import Engine
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _K0_HANDLES:
+        _K0_HANDLES[idx] = Engine.bare(idx)
+    return _K0_HANDLES[idx]
+
+
+def prepare(image, to_rgb: bool = False, engine=None) -> torch.Tensor:
+    """Reference signature `prepare(image, to_rgb)` (preprocessing.py:67); `engine` optionally names the handle (and device) to run on,
+    default: a weight-less handle on torch's current device.
+    image: (H,W) numpy or device tensor (uint16 / float) -> (H,W) float32 device tensor in [0,1]; `to_rgb` is accepted for
+    signature parity: the 3x channel repeat of the reference is folded into the encoder's pixel kernel (a gray plane is broadcast
+    to the three ImageNet-normalised channels).  (H,W,3) -> (H,W,3) float32 device tensor, filtered over all three axes with ONE
+    global min/max exactly as the reference does for RGB arrays.
+    K0 computes in float32: prepare(x) == prepare(x.astype(float32)) (the reference's loaders cast to float32, utils/io.py:34; for
+    integer arrays the reference's own `image**2` wraps in the integer dtype, a behaviour nobody relies on and not reproduced -
+    uint16 slices are widened exactly)."""
+    if engine is None:
+        dev = image.device if isinstance(image, torch.Tensor) and image.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        engine = _k0_engine(dev)
     if isinstance(image, np.ndarray):
-        if image.dtype == np.uint16:
+        if image.dtype == np.uint16 and image.ndim == 2:
             t = torch.from_numpy(np.ascontiguousarray(image))
         else:
             t = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
         image = t.to(engine.device)
-    elif image.dtype not in (torch.uint16, torch.float32):
+    elif image.dtype not in (torch.uint16, torch.float32) or image.dim() == 3:
         image = image.float()
     return engine.prepare(image.contiguous())

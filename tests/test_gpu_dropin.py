@@ -18,7 +18,9 @@ def segmenter():
     from saber_amd.segmenters.propagation import propagationSegmenter
     # thresholds low enough that the seeded (untrained) decoder's masks survive the AMG filters; the reference's default trunk
     amg = cfgAMG(npoints=8, crop_n_layers=1, pred_iou_thresh=0.2, stability_score_thresh=0.3, sam2_cfg="small")
-    cfg = SAM2AdapterConfig(cfg="small", amg_cfg=amg, min_mask_area=50)
+    # the adapter's own `cfg` (the video model of the reference) deliberately names ANOTHER trunk than the AMG model: every engine
+    # handle of the z-loop must still be the AMG model (amg_cfg.sam2_cfg, reference automask.py:61)
+    cfg = SAM2AdapterConfig(cfg="tiny", amg_cfg=amg, min_mask_area=50)
     return propagationSegmenter(deviceID=0, cfg=cfg, min_mask_area=50)
 
 
@@ -59,6 +61,20 @@ def test_slice_loop_device_equals_reference_shaped_loop(segmenter):
     assert ref.dtype == np.uint32 and dev.dtype == np.uint32 and ref.shape == vol.shape
     assert ref.max() > 0, "no component survived: the test volume / thresholds no longer exercise the path"
     assert np.array_equal(ref, dev)
+    # the second in-flight handle is a replica of the AMG model, not of cfg.cfg
+    from saber_amd.adapters.sam2.automask import get_replica
+    eng = segmenter.adapter.engine
+    assert eng.cfg.name == "small" and get_replica(eng, 1).cfg.name == "small" and get_replica(eng, 1) is not eng
+
+
+def test_segment_image_2d_accepts_rgb(segmenter):
+    """(H,W,3) input takes the reference's RGB route (prepare over all three axes, no channel repeat) and returns the dict schema"""
+    vol = _volume()
+    rgb = np.stack([vol[0], vol[1], vol[2]], axis=-1)
+    masks = segmenter.adapter.segment_image_2d(rgb)
+    assert isinstance(masks, list) and len(masks) > 0 and masks[0]["segmentation"].shape == (384, 384)
+    with pytest.raises(ValueError):
+        segmenter.adapter.segment_image_2d(np.zeros((8, 8, 2), np.float32))
 
 
 def test_slice_loop_with_device_smoothing(segmenter):

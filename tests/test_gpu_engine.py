@@ -2,10 +2,12 @@
 weights and inputs.
 
 Tolerances.  The engine runs GEMM operands in bf16 with fp32 accumulation, fp32 residual stream,
-fp32 LayerNorm/softmax statistics.  Against the fp32 oracle this gives a relative RMS error of a few 1e-3
+fp32 LayerNorm/softmax statistics.  Against the FP32 oracle this gives a relative RMS error of a few 1e-3
 per block output that accumulates over 48 blocks; the bounds below are stated per tensor as relative RMS
-(||a-b|| / ||b||) and are ~3x the measured values recorded in DESIGN.md.  Mask-level parity is stated
-as IoU of thresholded masks.
+(||a-b|| / ||b||) and are <= 2x the values measured on an MI355X, so a regression of 2x
+fails.  That this residual IS the sanctioned bf16 operand rounding and not a kernel defect is shown separately:
+tests/test_gpu_parity_bf16.py compares the engine with an oracle that rounds where the engine rounds and
+asserts the north star's 1e-3 there.  Mask-level parity is stated as IoU of thresholded masks.
 """
 import numpy as np
 import pytest
@@ -50,7 +52,7 @@ def test_encode_parity(engine, image, oracle_feats):
     torch.cuda.synchronize()
     errs = {k: rel_rms(got[k].cpu(), feats[k][0]) for k in ("image_embed", "feat_s0", "feat_s1")}
     print("encoder rel-rms:", errs)
-    assert errs["feat_s0"] < 0.02 and errs["feat_s1"] < 0.03 and errs["image_embed"] < 0.05, errs
+    assert errs["feat_s0"] < 5.6e-3 and errs["feat_s1"] < 8.4e-3 and errs["image_embed"] < 1.2e-2, errs   # measured 2.8e-3 / 4.2e-3 / 6.0e-3
 
 
 def test_encode_crops_and_rgb(engine, image, oracle_large):
@@ -66,7 +68,7 @@ def test_encode_crops_and_rgb(engine, image, oracle_large):
     got = engine.get_features(1)
     err = rel_rms(got["image_embed"].cpu(), feats["image_embed"][0])
     print("crop/rgb image_embed rel-rms:", err)
-    assert err < 0.05
+    assert err < 1.3e-2
 
 
 def test_decode_parity(engine, image, oracle_large, oracle_feats):
@@ -86,14 +88,14 @@ def test_decode_parity(engine, image, oracle_large, oracle_feats):
         r_low, r_iou, r_obj, _, _ = sam2_ref.mask_decoder(W, gf, sp, de, True)
     e_low, e_iou, e_obj = rel_rms(low.cpu(), r_low), (iou.cpu() - r_iou).abs().max().item(), (obj.cpu() - r_obj[:, 0]).abs().max().item()
     print("decoder-only: low-res rel-rms", e_low, "iou abs", e_iou, "obj abs", e_obj)
-    assert e_low < 0.03 and e_iou < 0.02 and e_obj < 0.2
+    assert e_low < 1.1e-2 and e_iou < 1.2e-2 and e_obj < 4e-2            # measured 5.5e-3 / 5.6e-3 / ~1e-2
     agree = ((low.cpu() > 0) == (r_low > 0)).float().mean().item()
-    assert agree > 0.995, agree
+    assert agree > 0.997, agree
     # (b) end to end against the oracle's own features
     with torch.no_grad():
         o_low, o_iou, _, _, _ = sam2_ref.mask_decoder(W, feats, sp, de, True)
     print("end-to-end: low-res rel-rms", rel_rms(low.cpu(), o_low), "iou abs", (iou.cpu() - o_iou).abs().max().item())
-    assert rel_rms(low.cpu(), o_low) < 0.1
+    assert rel_rms(low.cpu(), o_low) < 1.6e-2                            # measured 7.8e-3
     # (c) m2m pass: mask prompt + dynamic single-mask selection
     mi = torch.clamp(low[:, 0], -32, 32).contiguous()
     low2, iou2, _ = engine.decode_points(pts.cuda(), slot=0, multimask=False, mask_input=mi)
@@ -102,7 +104,7 @@ def test_decode_parity(engine, image, oracle_large, oracle_feats):
         r_low2, r_iou2, _, _, _ = sam2_ref.mask_decoder(W, gf, sp, de, False)
     e2 = rel_rms(low2.cpu(), r_low2)
     print("m2m decoder-only: low-res rel-rms", e2, "iou abs", (iou2.cpu() - r_iou2).abs().max().item())
-    assert e2 < 0.03
+    assert e2 < 1.2e-2
 
 
 def _match_masks(a, b):
@@ -131,12 +133,13 @@ def test_amg_parity(engine, image, oracle_large, large_weights, layers, nms):
     got = unpack_bits(bits, 1024)
     print(f"AMG layers={layers}: oracle {len(ref)} masks, engine {len(meta)} masks")
     assert len(ref) > 0
-    # bf16 vs fp32 logits can flip a borderline filter decision; require the sets to agree up to 15 % and matched masks to coincide
-    assert abs(len(ref) - len(meta)) <= max(2, int(0.15 * len(ref)))
+    # bf16 vs fp32 logits can flip a borderline filter decision (the emulating-oracle test is the tight one): the sets must agree
+    # up to 5 % (measured: same count) and matched masks must coincide (measured median IoU 0.994)
+    assert abs(len(ref) - len(meta)) <= max(2, int(0.05 * len(ref)))
     ious = _match_masks(list(got), [r["segmentation"] for r in ref])
     good = np.mean(np.array(ious) > 0.97)
     print("matched IoU: median", float(np.median(ious)), "fraction>0.97", float(good))
-    assert good >= 0.8
+    assert good >= 0.9 and np.median(ious) >= 0.988
     for m, g in zip(meta, got):
         assert m.area == int(g.sum())
         ys, xs = np.where(g)
@@ -163,9 +166,10 @@ def test_amg_parity_non_square_image(engine, large_weights):
     got = unpack_bits(bits, W)
     print(f"non-square AMG: oracle {len(ref)} masks, engine {len(meta)} masks")
     assert len(ref) >= 5 and got.shape[1:] == (H, W)
-    assert abs(len(ref) - len(meta)) <= max(2, int(0.15 * len(ref)))
+    assert abs(len(ref) - len(meta)) <= max(2, int(0.05 * len(ref)))
     ious = _match_masks(list(got), [r["segmentation"] for r in ref])
-    assert np.mean(np.array(ious) > 0.97) >= 0.8
+    print("non-square matched IoU: median", float(np.median(ious)), "fraction>0.97", float(np.mean(np.array(ious) > 0.97)))
+    assert np.mean(np.array(ious) > 0.97) >= 0.9
     for m, g in zip(meta, got):
         assert m.area == int(g.sum())
 
@@ -220,7 +224,7 @@ def test_encode_decode_parity_other_trunks(trunk_case, image):
     torch.cuda.synchronize()
     errs = {k: rel_rms(got[k].cpu(), feats[k][0]) for k in ("image_embed", "feat_s0", "feat_s1")}
     print(name, "encoder rel-rms:", errs)
-    assert errs["feat_s0"] < 0.02 and errs["feat_s1"] < 0.03 and errs["image_embed"] < 0.05, errs
+    assert errs["feat_s0"] < 5.0e-3 and errs["feat_s1"] < 8.0e-3 and errs["image_embed"] < 1.2e-2, errs   # measured 2.5e-3 / 4.0e-3 / 5.0-5.8e-3
     pts = torch.tensor([[300.0, 420.0], [800.0, 128.0], [512.0, 512.0]])
     lab = torch.ones(3, 1, dtype=torch.int64)
     low, iou, obj = eng.decode_points(pts.cuda(), slot=1, multimask=True)
@@ -229,7 +233,7 @@ def test_encode_decode_parity_other_trunks(trunk_case, image):
         o_low, o_iou, _, _, _ = sam2_ref.mask_decoder(W, feats, sp, de, True)
     e = rel_rms(low.cpu(), o_low)
     print(name, "end-to-end low-res rel-rms", e, "iou abs", (iou.cpu() - o_iou).abs().max().item())
-    assert e < 0.1 and (iou.cpu() - o_iou).abs().max().item() < 0.03
+    assert e < 2e-2 and (iou.cpu() - o_iou).abs().max().item() < 2e-2       # measured 8e-3 - 1e-2
 
 
 def test_config1_tiny_against_hf_validated_golden():
@@ -253,8 +257,8 @@ def test_config1_tiny_against_hf_validated_golden():
         e_low = rel_rms(low[0, :, ::4, ::4].cpu(), torch.from_numpy(M["low_res_sub"]))
         e_iou = float(np.abs(iou.cpu().numpy() - M["iou"]).max())
         print("config 1 (tiny) vs golden:", errs, "low-res", e_low, "iou", e_iou)
-        assert errs["feat_s0"] < 0.02 and errs["feat_s1"] < 0.03 and errs["image_embed"] < 0.05, errs
-        assert e_low < 0.05 and e_iou < 0.02
+        assert errs["feat_s0"] < 6e-3 and errs["feat_s1"] < 8e-3 and errs["image_embed"] < 1.1e-2, errs     # measured 2.9e-3 - 5.3e-3
+        assert e_low < 1.7e-2 and e_iou < 7e-3                                                            # measured 8.2e-3 / 3.3e-3
         sign = ((low[0, :, ::4, ::4].cpu().numpy() > 0) == (M["low_res_sub"] > 0)).mean()
         assert sign > 0.99, sign
         # m2m refinement of the first mask (mask prompt = clamped low-res logits), single-mask output
@@ -262,6 +266,6 @@ def test_config1_tiny_against_hf_validated_golden():
         low2, iou2, _ = eng.decode_points(pts.cuda(), slot=0, multimask=False, mask_input=mi)
         e2 = rel_rms(low2[0, :, ::4, ::4].cpu(), torch.from_numpy(M["m2m_low_res_sub"]))
         print("config 1 m2m low-res", e2)
-        assert e2 < 0.08
+        assert e2 < 3.6e-2                                                                                # measured 1.8e-2
     finally:
         eng.close()

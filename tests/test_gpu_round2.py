@@ -1,0 +1,121 @@
+"""GPU: direct tests of shipped kernels / entry points that round 1 only reached indirectly:
+saber_mask_pair_intersections against flat @ flat.T, the W > 1024 form of K8, K0 on (H,W,3) input against the reference's own
+output, the RCCL branch of the sharded volume driver at world size 1, the caller's current device after a C-ABI call."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ptr(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr())
+
+
+def test_pair_intersections_against_matmul(engine):
+    """reference: remove_duplicate_masks builds IoU from flat @ flat.T counts (saber/segmenters/utils.py:21-29)"""
+    rng = np.random.default_rng(5)
+    for (n, H, W) in ((1, 64, 64), (7, 96, 160), (33, 130, 75), (40, 1024, 1024)):
+        masks = rng.uniform(size=(n, H, W)) > rng.uniform(0.3, 0.9, size=(n, 1, 1))
+        masks[0] = False                                   # an empty mask
+        W32 = (W + 31) // 32
+        pad = np.zeros((n, H, W32 * 32), bool)
+        pad[..., :W] = masks
+        packed = np.packbits(pad, axis=-1, bitorder="little").view(np.int32)
+        got = engine.pair_intersections(torch.from_numpy(np.ascontiguousarray(packed)).cuda(), H, W).cpu().numpy()
+        flat = masks.reshape(n, -1).astype(np.float64)
+        ref = (flat @ flat.T).astype(np.int64)
+        assert np.array_equal(got.astype(np.int64), ref), (n, H, W)
+
+
+@pytest.mark.parametrize("size,crop", [((1536, 2048), (0, 0, 2048, 1536)), ((1536, 2048), (600, 300, 1200, 900)), ((2048, 2048), (1000, 900, 1048, 1148))])
+def test_mask_post_wide_images(gpu_lib, size, crop):
+    """K8 for W > 1024 (mask_post_kernel<false>): 2048^2 micrographs are ordinary inputs (the reference warns above 1280 px only)"""
+    from saber_amd.engine import unpack_bits
+    H, W = size
+    x0, y0, cw, ch = crop
+    g = torch.Generator().manual_seed(cw + H)
+    n = 4
+    low = F.interpolate(torch.randn(n, 1, 16, 16, generator=g) * 4, size=(256, 256), mode="bicubic")[:, 0].contiguous()
+    low[3] = -5.0
+    full = F.interpolate(low[:, None], size=(ch, cw), mode="bilinear", align_corners=False)[:, 0]
+    thr, off = 0.0, 0.7
+    ref_mask = torch.zeros(n, H, W, dtype=torch.bool)
+    ref_mask[:, y0:y0 + ch, x0:x0 + cw] = full > thr
+    bits = torch.zeros(n, H, W // 32, dtype=torch.int32, device="cuda")
+    stats = torch.zeros(n, 8, dtype=torch.int32, device="cuda")
+    st_ = gpu_lib.saber_k_mask_post(ptr(low.cuda()), n, x0, y0, cw, ch, H, W, thr, off, ptr(bits), ptr(stats), None)
+    assert st_ == 0, gpu_lib.saber_k_last_error()
+    torch.cuda.synchronize()
+    got = unpack_bits(bits, W)
+    st = stats.cpu().numpy()
+    for i in range(n):
+        assert np.logical_xor(got[i], ref_mask[i].numpy()).sum() <= 4, i
+        assert abs(int(st[i, 1]) - int((full[i] > thr + off).sum())) <= 4 and abs(int(st[i, 2]) - int((full[i] > thr - off).sum())) <= 4
+        assert int(st[i, 0]) == int(got[i].sum())
+        if got[i].any():
+            ys, xs = np.where(got[i])
+            assert (st[i, 3], st[i, 4], st[i, 5], st[i, 6]) == (xs.min(), ys.min(), xs.max(), ys.max())
+
+
+def test_prepare_rgb_against_reference_fixture():
+    """(H,W,3) input: the reference's prepare filters over all three axes (tests/golden/saber_rgb_prepare.npz was written by the
+    imported reference, oracle/make_golden_rgb.py)"""
+    from saber_amd.utils import preprocessing as prep
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "saber_rgb_prepare.npz"))
+    out = prep.prepare(g["rgb_in"], to_rgb=False)            # reference signature, weight-less K0 handle
+    assert out.shape == g["rgb_in"].shape and out.dtype == torch.float32
+    err = np.abs(out.cpu().numpy() - g["rgb_out"]).max()
+    print("K0 rgb max abs diff", err)
+    assert err < 2e-4
+    gray = prep.prepare(g["rgb_in"][..., 0].copy(), to_rgb=True)
+    from oracle import saber_ref
+    assert np.abs(gray.cpu().numpy() - saber_ref.prepare(g["rgb_in"][..., 0])).max() < 2e-4
+
+
+def test_sharded_driver_over_rccl_world_size_one(engine):
+    """The NCCL (= RCCL) branch of segment_volume_sharded on real hardware: init_process_group('nccl'), uneven Z, device stitch.
+    World size 1 on the one-GPU box; the collective call path (all_gather_into_tensor on a byte view) is the one N > 1 takes."""
+    import torch.distributed as dist
+    from saber_amd.segmenters.slice_driver import segment_volume_sharded
+    from saber_amd.segmenters import utils
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl"
+        rng = np.random.default_rng(2)
+        Z, H, W = 5, 96, 128
+        vol = np.zeros((Z, H, W), np.uint16)
+        zz, yy, xx = np.mgrid[:Z, :H, :W]
+        for k in range(5):
+            cz, cy, cx, r = rng.integers(0, Z), rng.integers(10, H - 10), rng.integers(10, W - 10), rng.integers(6, 14)
+            vol[(zz - cz) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = k + 1
+        dev_planes = torch.from_numpy(vol.view(np.int16)).cuda()
+        out = segment_volume_sharded(vol, lambda z: dev_planes[z], stitch=True, min_mask_area=1, engine=engine)
+        assert np.array_equal(out, utils.separate_masks(vol, min_mask_area=1))
+        # and the collective itself, as the N > 1 branch issues it (byte view of int16 planes)
+        full = torch.empty_like(dev_planes)
+        dist.all_gather_into_tensor(full.view(torch.uint8), dev_planes.view(torch.uint8))
+        torch.cuda.synchronize()
+        assert torch.equal(full, dev_planes)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_c_abi_call_leaves_callers_device_alone(engine):
+    """entry points bind to the engine's device for the call only"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    cur = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(cur)) == 0
+    before = cur.value
+    engine.prepare(torch.zeros(64, 64, device="cuda"))
+    assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == before

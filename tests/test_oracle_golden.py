@@ -173,3 +173,11 @@ def test_oracle_model_reproduces_hf_validated_outputs():
     assert np.allclose(low2[0, :, ::4, ::4].numpy(), M["m2m_low_res_sub"], rtol=0, atol=1e-3)
     assert masks.shape == (1, 3, 512, 512)
     assert np.abs((masks[0] > 0).sum((-1, -2)).numpy() - M["mask_area"]).max() <= 2
+
+
+def test_prepare_rgb_restatement_matches_reference_fixture():
+    """(H,W,3) input through prepare(): captured from the imported reference by oracle/make_golden_rgb.py"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "saber_rgb_prepare.npz"))
+    from oracle import saber_ref
+    out = saber_ref.prepare(g["rgb_in"], to_rgb=False)
+    assert out.shape == g["rgb_in"].shape and np.array_equal(out.astype(np.float32), g["rgb_out"])
