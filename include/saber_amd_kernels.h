@@ -28,6 +28,14 @@ int saber_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, const 
 int saber_k_gemm_ld(const uint16_t* A, int lda, const uint16_t* W, int ldw, int w_kpad, const float* bias, const float* res, float* out_f32,
                     uint16_t* out_bf16, int M, int N, int K, int act, void* stream);
 
+/* Residual step + the LayerNorm that follows it in one kernel (Hiera MultiScaleBlock: attn.proj + shortcut -> norm2, mlp.layers.1 +
+ * residual -> norm1 of the next block):  y = A.W^T + bias + res -> out_f32 (and out_bf16 = bf16(y) if not NULL);
+ * ln_out = bf16(LayerNorm(y) * ln_gamma + ln_beta).  N must be 144, 288 or 576 (the workgroup owns whole rows); W rows zero-padded
+ * to a multiple of 64 in K (ldw >= padded K); res may alias out_f32 (in-place residual stream). */
+int saber_k_gemm_rowln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* res, float* out_f32,
+                       uint16_t* out_bf16, const float* ln_gamma, const float* ln_beta, float ln_eps, uint16_t* ln_out, int M, int N, int K,
+                       void* stream);
+
 /* nn.LayerNorm over the last dim; fp32 in, fp32 and/or bf16 out. */
 int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,
                       int rows, int C, int act, void* stream);

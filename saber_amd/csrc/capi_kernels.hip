@@ -19,6 +19,7 @@ extern "C" const char* saber_k_last_error(void) { return g_kerr.c_str(); }
 extern "C" int saber_k_init(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return kfail("hipSetDevice failed");
     const char* m = gemm_init_device();
+    if (!m) m = gemm_rowln_init_device();
     if (!m) m = hiera_attention_init_device();
     if (!m) m = image_ops_init_device();
     if (!m) m = decoder_fused_init_device();
@@ -42,6 +43,15 @@ extern "C" int saber_k_gemm_ld(const uint16_t* A, int lda, const uint16_t* W, in
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
     p.M = M; p.N = N; p.K = K; p.act = act; p.w_kpad = w_kpad;
     return kcheck(launch_gemm(p, (hipStream_t)stream));
+}
+
+extern "C" int saber_k_gemm_rowln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* res, float* out_f32,
+                                  uint16_t* out_bf16, const float* ln_gamma, const float* ln_beta, float ln_eps, uint16_t* ln_out, int M, int N, int K,
+                                  void* stream) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.w_kpad = 1; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
+    p.M = M; p.N = N; p.K = K; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_out = ln_out; p.ldln = N;
+    return kcheck(launch_gemm_rowln(p, (hipStream_t)stream));
 }
 
 extern "C" int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,

@@ -109,6 +109,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     if (const char* m = hiera_spec(e, *spec)) { delete e; return eng_fail(nullptr, SABER_ERR_INVALID, m); }
     {
         const char* m = gemm_init_device();
+        if (!m) m = gemm_rowln_init_device();
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();
         if (!m) m = decoder_fused_init_device();
@@ -648,12 +649,19 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
     float* xalt = e->xb;
     int tokens = 65536;  // per image, current stage
     int stage = 0;
-    for (size_t i = 0; i < e->blocks.size(); ++i) {
+    // The LayerNorm that follows each residual step (norm2 after attn.proj, norm1 of the NEXT block after mlp.layers.1) is computed in
+    // the epilogue of the GEMM that produces the row (gemm_rowln.hip) wherever the residual width allows (144 / 288 / 576: stages 0-2 of
+    // Hiera-L); the padded-window trunks keep the separate pass (their norm1 also zeroes the window-padding rows).
+    static const bool no_rowln = getenv("SABER_AMD_NO_ROWLN") != nullptr;      // development A/B switch
+    const bool fuse = !e->padded && !no_rowln;
+    const size_t nblocks = e->blocks.size();
+    // window-padding rows (padded layout): the reference pads the normalised tokens with zeros before qkv
+    ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, e->bw[0].n1, 1e-6f, n * tokens, e->blocks[0].din, nullptr, e->xn, ACT_NONE, s, nullptr, nullptr, 0, e->valid[0], tokens));
+    for (size_t i = 0; i < nblocks; ++i) {
         const BlockSpec& bs = e->blocks[i];
         const BlockW& w = e->bw[i];
         const int N = n * tokens;
-        // window-padding rows (padded layout): the reference pads the normalised tokens with zeros before qkv
-        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, w.n1, 1e-6f, N, bs.din, nullptr, e->xn, ACT_NONE, s, nullptr, nullptr, 0, e->valid[stage], tokens));
+        // e->xn holds norm1(x) of this block
         float* xres = x;
         int Nq = N;
         if (bs.din != bs.dout) {
@@ -676,27 +684,42 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         {
             GemmParams g = mk_gemm(e->att, bs.dout, Nq, w.proj);
             g.Cf = xres; g.ldcf = bs.dout; g.res = xres; g.ldres = bs.dout;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+            g.ln_gamma = w.n2.g; g.ln_beta = w.n2.b; g.ln_eps = 1e-6f; g.ln_out = e->xn; g.ldln = bs.dout;
+            if (fuse && gemm_rowln_supported(g)) {
+                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm_rowln(g, s));
+            } else {
+                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+                ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(xres, w.n2, 1e-6f, Nq, bs.dout, nullptr, e->xn, ACT_NONE, s));
+            }
         }
         if (bs.din != bs.dout) { std::swap(x, xalt); tokens /= 4; ++stage; }
-        ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, w.n2, 1e-6f, Nq, bs.dout, nullptr, e->xn, ACT_NONE, s));
         {
             GemmParams g = mk_gemm(e->xn, bs.dout, Nq, w.fc1);
             g.Cb = e->hid; g.ldcb = 4 * bs.dout; g.act = ACT_GELU;
             ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
         }
+        const bool to_padded = e->padded && bs.din != bs.dout && stage == 2;
+        const bool has_next = i + 1 < nblocks;
         {
             GemmParams g = mk_gemm(e->hid, 4 * bs.dout, Nq, w.fc2);
             g.Cf = x; g.ldcf = bs.dout; g.res = x; g.ldres = bs.dout;
             if ((int)i == e->stage_ends[stage]) { g.Cb = e->sb[stage]; g.ldcb = bs.dout; }
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
-        }
-        if (e->padded && bs.din != bs.dout && stage == 2) {
-            // the 64^2 grid leaves the stage-transition block in the bit-interleaved order; the 14x14 windows of the blocks that
-            // follow need the window-major padded layout (padding rows start as zeros and are re-zeroed by every norm1)
-            ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(x, 4096, xalt, e->tok_rows[2], e->pack_idx, bs.dout, n, s));
-            std::swap(x, xalt);
-            tokens = e->tok_rows[2];
+            bool fused = false;
+            if (fuse && has_next) {
+                g.ln_gamma = e->bw[i + 1].n1.g; g.ln_beta = e->bw[i + 1].n1.b; g.ln_eps = 1e-6f; g.ln_out = e->xn; g.ldln = bs.dout;
+                fused = gemm_rowln_supported(g);
+            }
+            if (fused) ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm_rowln(g, s));
+            else ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+            if (to_padded) {
+                // the 64^2 grid leaves the stage-transition block in the bit-interleaved order; the 14x14 windows of the blocks that
+                // follow need the window-major padded layout (padding rows start as zeros and are re-zeroed by every norm1)
+                ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(x, 4096, xalt, e->tok_rows[2], e->pack_idx, bs.dout, n, s));
+                std::swap(x, xalt);
+                tokens = e->tok_rows[2];
+            }
+            if (has_next && !fused)   // norm1 of the next block (its width is this block's dout)
+                ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, e->bw[i + 1].n1, 1e-6f, n * tokens, bs.dout, nullptr, e->xn, ACT_NONE, s, nullptr, nullptr, 0, e->valid[stage], tokens));
         }
     }
     // neck

@@ -27,9 +27,16 @@ struct GemmParams {
     int dbg = 0;         // development flags (saber_k_set_debug), 0 in production
     unsigned long long* stamps = nullptr;   // development: in-kernel cycle stamps (tools/gemm_stamps.py)
     int w_kpad = 0;      // W rows are zero-padded to a multiple of 64 in K (ldw >= padded K): enables the direct-to-LDS kernel
+    // row-owner GEMM + LayerNorm (gemm_rowln.hip): ln_out = bf16(LayerNorm(Cf row) * ln_gamma + ln_beta)
+    const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-6f;
+    bf16_t* ln_out = nullptr; int64_t ldln = 0;
 };
 const char* launch_gemm(const GemmParams& p, hipStream_t stream);
 const char* gemm_init_device();
+// y = A.W^T + bias + res (fp32 -> Cf, optional bf16 copy -> Cb) and ln_out = bf16(LayerNorm(y)) in one kernel; N in {144, 288, 576}
+bool gemm_rowln_supported(const GemmParams& p);
+const char* launch_gemm_rowln(const GemmParams& p, hipStream_t stream);
+const char* gemm_rowln_init_device();
 
 // ------------------------------------------------------------------ layernorm.hip
 struct LayerNormParams {

@@ -404,3 +404,41 @@ def test_hand_synchronised_kernels_are_run_to_run_identical(gpu_lib):
         kcall(gpu_lib, gpu_lib.saber_k_dec_t2i(ptr(X), 4096 * 256, ptr(peq), ptr(Kt), ptr(tk), 0.3, ptr(part), ptr(ml), P, 1, ptr(Wv), ptr(bv), ptr(b), None))
         o1.append(a); o2.append(b)
     assert all(torch.equal(o1[0], o) for o in o1[1:]) and all(torch.equal(o2[0], o) for o in o2[1:])
+
+
+@pytest.mark.parametrize("M,N,K,with_res,with_bf", [(4096, 576, 576, True, False), (4096 + 70, 576, 2304, True, True), (16384, 288, 1152, True, False),
+                                                    (2048 + 300, 288, 288, False, True), (65536, 144, 144, True, False), (4096 + 33, 144, 576, True, True)])
+def test_gemm_rowln(gpu_lib, M, N, K, with_res, with_bf):
+    """residual GEMM + the LayerNorm that follows it in one kernel (gemm_rowln.hip): y against fp64 on the same bf16 operands,
+    the normalised bf16 rows against LayerNorm of the kernel's own y (<= 1 bf16 ulp, almost all exact) and of the fp64 y"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16)
+    Kp = (K + 63) // 64 * 64
+    Wf = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    Wp = torch.zeros(N, Kp, dtype=torch.bfloat16)
+    Wp[:, :K] = Wf
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) * 2 + 0.5 if with_res else None
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    Ad, Wd = A.view(torch.uint16).cuda(), Wp.view(torch.uint16).cuda()
+    out = (res.clone() if with_res else torch.zeros(M, N)).cuda()        # in place: res aliases out_f32, as the engine's residual stream does
+    out_bf = torch.zeros(M, N, dtype=torch.uint16, device="cuda") if with_bf else None
+    ln_out = torch.zeros(M, N, dtype=torch.uint16, device="cuda")
+    bd, gd, bed = bias.cuda(), gamma.cuda(), beta.cuda()
+    kcall(gpu_lib, gpu_lib.saber_k_gemm_rowln(ptr(Ad), K, ptr(Wd), Kp, ptr(bd), ptr(out) if with_res else None, ptr(out), ptr(out_bf) if with_bf else None,
+                                              ptr(gd), ptr(bed), 1e-6, ptr(ln_out), M, N, K, None))
+    torch.cuda.synchronize()
+    ref = A.double() @ Wf.double().T + bias.double() + (res.double() if with_res else 0.0)
+    y = out.cpu()
+    err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err
+    if with_bf:
+        assert torch.equal(from_bf(out_bf), y.to(torch.bfloat16).float())
+    ln_self = torch.nn.functional.layer_norm(y, (N,), gamma, beta, 1e-6)
+    got = from_bf(ln_out)
+    d = (got - ln_self.to(torch.bfloat16).float()).abs()
+    ulp = ln_self.abs().clamp(min=1e-3) * 2.0 ** -7
+    assert (d <= ulp).all(), float((d / ulp).max())
+    assert (d > 0).float().mean().item() < 2e-3         # rounding flips only
+    ln_ref = torch.nn.functional.layer_norm(ref, (N,), gamma.double(), beta.double(), 1e-6)
+    assert (got.double() - ln_ref).abs().max().item() < 0.05
