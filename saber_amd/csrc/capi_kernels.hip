@@ -48,9 +48,19 @@ extern "C" int saber_k_gemm_ld(const uint16_t* A, int lda, const uint16_t* W, in
 extern "C" int saber_k_gemm_rowln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* res, float* out_f32,
                                   uint16_t* out_bf16, const float* ln_gamma, const float* ln_beta, float ln_eps, uint16_t* ln_out, int M, int N, int K,
                                   void* stream) {
+    // the kernel reads W packed per K-step (the engine packs its weights once at finalize); here: into a scratch kept per thread
+    static thread_local bf16_t* scratch = nullptr;
+    static thread_local size_t scratch_elems = 0;
+    const size_t need = gemm_rowln_packed_elems(N, K);
+    if (need > scratch_elems) {
+        if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); scratch = nullptr; scratch_elems = 0; }
+        if (hipMalloc(reinterpret_cast<void**>(&scratch), need * sizeof(bf16_t)) != hipSuccess) return kfail("gemm_rowln: scratch allocation failed");
+        scratch_elems = need;
+    }
+    if (const char* m = launch_pack_w_kstep(W, ldw, N, K, scratch, (hipStream_t)stream)) return kfail(m);
     GemmParams p;
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.w_kpad = 1; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
-    p.M = M; p.N = N; p.K = K; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_out = ln_out; p.ldln = N;
+    p.M = M; p.N = N; p.K = K; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_out = ln_out; p.ldln = N; p.Wpk = scratch;
     return kcheck(launch_gemm_rowln(p, (hipStream_t)stream));
 }
 

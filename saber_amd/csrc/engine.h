@@ -12,7 +12,7 @@ struct BlockSpec { int din, dout, heads, window, q_stride; };
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
-struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; };  // rows zero-padded to ldw = ceil(in/64)*64
+struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; };   // wpk: K-step-packed copy (gemm_rowln.hip)  // rows zero-padded to ldw = ceil(in/64)*64
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
 
 struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };

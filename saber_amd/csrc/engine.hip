@@ -297,6 +297,15 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         w.fc2 = F.lin(b + "mlp.layers.1", bs.dout, 4 * bs.dout);
         if (bs.din != bs.dout) w.sc = F.lin(b + "proj", bs.dout, bs.din);
         if (F.status != SABER_OK) return F.status;
+        // residual widths the row-owner GEMM + LayerNorm kernel covers: a K-step-packed copy of the two weights it replaces
+        if (!e->padded && (bs.dout == 144 || bs.dout == 288 || bs.dout == 576)) {
+            for (LinW* l : {&w.proj, &w.fc2}) {
+                bf16_t* d = nullptr;
+                TRY(eng_alloc(e, &d, gemm_rowln_packed_elems(l->out, l->in)));
+                if (const char* m = launch_pack_w_kstep(l->w, l->ldw, l->out, l->in, d, nullptr)) return eng_fail(e, SABER_ERR_INVALID, m);
+                l->wpk = d;
+            }
+        }
     }
     // ---- neck (+ conv_s0 / conv_s1 composed with their lateral convs; no_mem_embed folded into the 64^2 bias)
     {
@@ -590,7 +599,7 @@ extern "C" int saber_profile_end(saber_engine* e, saber_profile_class* out, int 
 // ------------------------------------------------------------------------------------------------ helpers
 static GemmParams mk_gemm(const bf16_t* A, int64_t lda, int M, const LinW& w) {
     GemmParams p;
-    p.A = A; p.lda = lda; p.W = w.w; p.ldw = w.ldw; p.w_kpad = 1; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in;
+    p.A = A; p.lda = lda; p.W = w.w; p.ldw = w.ldw; p.w_kpad = 1; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in; p.Wpk = w.wpk;
     return p;
 }
 static const char* ln_run(const float* x, const LnW& w, float eps, int rows, int C, float* out_f, bf16_t* out_bf, int act, hipStream_t s,

@@ -14,6 +14,10 @@
 // (144, 288, 576) and of tiny/small stage 1-2 (192?  no: only multiples of 144, other trunks keep the unfused pair).
 //
 //   * A is streamed ONCE (no N tiling), W is re-read per tile from L2: (R + N) x 64 B per 32-deep K-step.
+//   * W comes PRE-PACKED per K-step (pack_w_kstep_kernel, once per weight at engine finalize): Wpk[ks][n][32] with the LDS chunk
+//     permutation already applied, so the W tile of a K-step is ONE contiguous 64 N-byte block and every direct-to-LDS instruction
+//     copies 1 KB = 8 whole 128-B lines.  Row-major W costs 16 half-used lines per instruction (16 rows x 64 B), and the CU's
+//     texture-address path works per line: the operand feed of the round-1 GEMMs sits at ~13 B/clk/CU for that reason.
 //   * operands go global -> LDS directly (global_load_lds_dwordx4) into a 3-stage ring, K-steps of 32, 64-B LDS rows with the
 //     chunk permutation of gemm_bf16_glds2_kernel (conflict-free ds_read_b128), counted vmcnt, one raw barrier per K-step;
 //     13 fragment reads per 36 MFMAs per wave.
@@ -72,11 +76,11 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             ldsoff[q] = (wave + 8 * q) * 1024;
         } else {
             const int wp = min(wave + 8 * q - RA, RW - 1);      // wave-uniform
-            voff[q] = (uint32_t)((wp * 16 + lrow) * (int)p.ldw * 2 + lchunk * 16);
+            voff[q] = (uint32_t)(wp * 1024 + lane * 16);        // packed W: the K-step's tile is a straight copy
             ldsoff[q] = (RA + wp) * 1024;
         }
     }
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((uint32_t)p.N * (uint32_t)p.ldw * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wpk, 0, (int)((uint32_t)nk * (uint32_t)CF::N * 64u), 0x00020000);
     // (the voffset argument is cast explicitly: voff[] has a template-dependent bound, which makes voff[q] type-dependent, and a
     // type-dependent argument of this builtin makes the HOST instantiation of the kernel template fail silently - no host stub)
     auto issue = [&](const __amdgpu_buffer_rsrc_t& wrs, int tile, int kt) {
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (q * 8 < RA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], kt * (RL_BK * 2), 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], kt * (RL_BK * 2), 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], (int)(kt * (CF::N * 64)), 0, 0);
         }
     };
     static_assert(NQ == 6 || NQ == 5, "piece counts handled: 5 or 6 per wave");
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj)
-                        acc[i][jg * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
             }
             // K-step kt + 1 has landed (this wave's pieces); the youngest (kt + 2) may stay in flight
             if (kt + 2 < nk) { if (NQ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
@@ -148,12 +152,13 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         const uint32_t roff = (uint32_t)((trow * (int)ldr + ncol) * 4), coff = (uint32_t)((trow * (int)p.ldcf + ncol) * 4);
         const uint32_t rstep = (uint32_t)(16 * (int)ldr * 4), cstep = (uint32_t)(16 * (int)p.ldcf * 4);
         const bool has_res = p.res != nullptr;
+        const bool dbg_nores = p.dbg & 1024, dbg_nof32 = p.dbg & 2048, dbg_nobf = p.dbg & 4096;   // development: timing-only switches (tools/rowln_bench.py)
         // No direct-to-LDS load is in flight here (the last K-step ended with vmcnt(0)), so hipcc counts these loads instead of draining
         // the queue at every use; the residual rows of group i + 1 are requested before group i is added and stored.
         u32x4 ra[9], rb[9];
         auto load_group = [&](const __amdgpu_buffer_rsrc_t& rsr, int i, u32x4 (&rr)[9]) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) rr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsr, roff + j * 64, i * rstep, 0);
+            for (int j = 0; j < 9; ++j) rr[j] = dbg_nores ? (u32x4){0u, 0u, 0u, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rsr, roff + j * 64, i * rstep, 0);
         };
         float rs[4];
         auto finish_group = [&](const __amdgpu_buffer_rsrc_t& csr, int i, const u32x4 (&rr)[9]) {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             for (int j = 0; j < 9; ++j) {
                 u32x4 v;
                 v[0] = __float_as_uint(acc[i][j][0]); v[1] = __float_as_uint(acc[i][j][1]); v[2] = __float_as_uint(acc[i][j][2]); v[3] = __float_as_uint(acc[i][j][3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, csr, coff + j * 64, i * cstep, 0);
+                if (!dbg_nof32) __builtin_amdgcn_raw_buffer_store_b128(v, csr, coff + j * 64, i * cstep, 0);
             }
             rs[i] = xor32_sum(xor16_sum(s));
         };
@@ -268,10 +273,32 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
                 const float v2 = fmaf(acc[i][j][2] * rstd[i], g4.z, be4.z), v3 = fmaf(acc[i][j][3] * rstd[i], g4.w, be4.w);
                 u32x2 v;
                 v[0] = pack_bf16(v0, v1); v[1] = pack_bf16(v2, v3);
-                __builtin_amdgcn_raw_buffer_store_b64(v, lrsrc, loff + j * 32, i * lstep, 0);
+                if (!dbg_nobf) __builtin_amdgcn_raw_buffer_store_b64(v, lrsrc, loff + j * 32, i * lstep, 0);
             }
         }
     }
+}
+
+// Wpk[ks][n][physical chunk][8] <- W[n][32 ks + 8 chunk + e], physical chunk = chunk ^ rl_perm(n); k beyond ldw reads as zero
+__global__ __launch_bounds__(256) void pack_w_kstep_kernel(const bf16_t* __restrict__ W, int ldw, int N, int nk, bf16_t* __restrict__ out) {
+    const int64_t total = (int64_t)nk * N * 4;           // 16-B chunks
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx & 3);
+        const int64_t rn = idx >> 2;
+        const int n = (int)(rn % N), ks = (int)(rn / N);
+        const int k = ks * 32 + c * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k + 8 <= ldw) v = *reinterpret_cast<const uint4*>(W + (int64_t)n * ldw + k);
+        *reinterpret_cast<uint4*>(out + ((rn * 4) + (c ^ rl_perm(n))) * 8) = v;
+    }
+}
+size_t gemm_rowln_packed_elems(int N, int K) { return (size_t)((K + 31) / 32) * N * 32; }
+const char* launch_pack_w_kstep(const bf16_t* W, int ldw, int N, int K, bf16_t* out, hipStream_t s) {
+    if ((ldw & 7) || ldw < K) return "pack_w_kstep: ldw must be a multiple of 8 and >= K";
+    const int nk = (K + 31) / 32;
+    const int64_t total = (int64_t)nk * N * 4;
+    hipLaunchKernelGGL(pack_w_kstep_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, W, ldw, N, nk, out);
+    return nullptr;
 }
 
 const char* gemm_rowln_init_device() {
@@ -282,15 +309,18 @@ const char* gemm_rowln_init_device() {
 }
 
 bool gemm_rowln_supported(const GemmParams& p) {
-    return (p.N == 144 || p.N == 288 || p.N == 576) && p.w_kpad && p.Cf && p.ln_out && p.ln_gamma && p.ln_beta && p.batch <= 1 && !p.pool4 &&
+    return (p.N == 144 || p.N == 288 || p.N == 576) && p.Wpk && p.Cf && p.ln_out && p.ln_gamma && p.ln_beta && p.batch <= 1 && !p.pool4 &&
            p.act == ACT_NONE && p.res_shift == 0 && p.res_mod == 0;
 }
 
-const char* launch_gemm_rowln(const GemmParams& p, hipStream_t stream) {
+extern int g_saber_debug_flags;
+const char* launch_gemm_rowln(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.dbg = g_saber_debug_flags;
     if (!gemm_rowln_supported(p)) return "gemm_rowln: unsupported problem (N must be 144, 288 or 576; fp32 + LayerNorm outputs required)";
     if (p.M <= 0 || p.K <= 0) return "gemm_rowln: empty problem";
-    if ((p.K & 7) || (p.lda & 7) || (p.ldw & 7) || (p.ldw < ((p.K + 63) / 64) * 64)) return "gemm_rowln: K, lda, ldw must be multiples of 8 and W rows padded to 64";
-    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.Cf & 15) || (p.ldcf & 3) || ((uintptr_t)p.ln_out & 7) || (p.ldln & 3) ||
+    if ((p.K & 7) || (p.lda & 7)) return "gemm_rowln: K and lda must be multiples of 8";
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.Wpk & 15) || ((uintptr_t)p.Cf & 15) || (p.ldcf & 3) || ((uintptr_t)p.ln_out & 7) || (p.ldln & 3) ||
         (p.res && (((uintptr_t)p.res & 15) || (p.ldres & 3))) || (p.bias && ((uintptr_t)p.bias & 15)) || (p.Cb && (((uintptr_t)p.Cb & 7) || (p.ldcb & 3))) ||
         ((uintptr_t)p.ln_gamma & 15) || ((uintptr_t)p.ln_beta & 15))
         return "gemm_rowln: operand alignment";

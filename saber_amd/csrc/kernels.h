@@ -30,6 +30,7 @@ struct GemmParams {
     // row-owner GEMM + LayerNorm (gemm_rowln.hip): ln_out = bf16(LayerNorm(Cf row) * ln_gamma + ln_beta)
     const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-6f;
     bf16_t* ln_out = nullptr; int64_t ldln = 0;
+    const bf16_t* Wpk = nullptr;     // W packed per K-step for the row-owner kernel (launch_pack_w_kstep)
 };
 const char* launch_gemm(const GemmParams& p, hipStream_t stream);
 const char* gemm_init_device();
@@ -37,6 +38,9 @@ const char* gemm_init_device();
 bool gemm_rowln_supported(const GemmParams& p);
 const char* launch_gemm_rowln(const GemmParams& p, hipStream_t stream);
 const char* gemm_rowln_init_device();
+// W [N][ldw] (rows zero-padded) -> Wpk[ceil(K/32)][N][32] with the LDS chunk permutation of the row-owner kernel applied
+size_t gemm_rowln_packed_elems(int N, int K);
+const char* launch_pack_w_kstep(const bf16_t* W, int ldw, int N, int K, bf16_t* out, hipStream_t s);
 
 // ------------------------------------------------------------------ layernorm.hip
 struct LayerNormParams {
