@@ -124,6 +124,10 @@ int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const i
 int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* params,
                        uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta_host, int* out_count, void* stream);
 
+/* Host synchronisations (hipStreamSynchronize) the last saber_amg_generate call on this handle needed: 2 per group of crops decoded
+ * together + 1 at the end (7 for cfgAMG's default 1 + 4 + 16 crop pyramid), more only when a scratch buffer had to grow. */
+int saber_amg_last_syncs(const saber_engine* e);
+
 /* plane[y][x] = (position in order_host)+1 of the LAST mask covering the pixel, 0 if none. */
 int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, const int* order_host, int n, int H, int W,
                       uint16_t* plane_dev, void* stream);

@@ -74,6 +74,8 @@ static void gen_crop_boxes(int H, int W, int n_layers, float overlap_ratio, std:
     }
 }
 
+extern "C" int saber_amg_last_syncs(const saber_engine* e) { return e ? e->amg_last_syncs : -1; }
+
 extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* prm,
                                   uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta, int* out_count, void* stream) {
     if (!e) return SABER_ERR_INVALID;
@@ -86,6 +88,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     ENG_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     *out_count = 0;
+    e->amg_last_syncs = 0;
     const int W32 = (W + 31) >> 5;
     const size_t mask_words = (size_t)H * W32;
     const int M = prm->multimask_output ? 3 : 1;
@@ -137,14 +140,14 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         uint32_t* nb = nullptr;
         TRY(eng_alloc(e, &nb, ncap * mask_words));
         if (acc_used) ENG_HIP(e, hipMemcpyAsync(nb, e->amg_bits, acc_used * mask_words * 4, hipMemcpyDeviceToDevice, s));
-        ENG_HIP(e, hipStreamSynchronize(s));
+        { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
         eng_free(e, e->amg_bits);
         e->amg_bits = nb; e->amg_bits_words = ncap * mask_words;
         return SABER_OK;
     };
     auto crop_reserve = [&](size_t need) -> int {  // scratch for one crop's pred_iou survivors
         if (need * mask_words <= e->amg_crop_words) return SABER_OK;
-        ENG_HIP(e, hipStreamSynchronize(s));
+        { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
         eng_free(e, e->amg_crop_bits);
         e->amg_crop_bits = nullptr; e->amg_crop_words = 0;
         TRY(eng_alloc(e, &e->amg_crop_bits, need * mask_words));
@@ -198,30 +201,44 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             }
             std::vector<float> h_iou_all((size_t)G * nm);
             ENG_HIP(e, hipMemcpyAsync(h_iou_all.data(), ious, sizeof(float) * G * nm, hipMemcpyDeviceToHost, s));
-            ENG_HIP(e, hipStreamSynchronize(s));
+            { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }                                   // sync 1 of 2 per decoded group
+            // pred_iou filter of every crop of the group on the host, then K8 for ALL of them (one launch per crop, no host round trip in
+            // between) into one scratch, ONE copy of the per-mask scalars back: 2 host synchronisations per group of crops instead of
+            // 1 + one per crop (24 -> 7 per slice with the default 21-crop pyramid)
+            std::vector<int> g_first(G + 1, 0);                                    // survivors of crop g: [g_first[g], g_first[g+1]) of the group list
+            h_idx.clear();
+            for (int g = 0; g < G; ++g) {
+                const int kbase = g * nm;
+                for (int k = 0; k < nm; ++k)
+                    if (!(prm->pred_iou_thresh > 0.0f) || h_iou_all[kbase + k] > prm->pred_iou_thresh) h_idx.push_back(kbase + k);
+                g_first[g + 1] = (int)h_idx.size();
+            }
+            const int ns_all = (int)h_idx.size();
+            if (ns_all == 0) continue;
+            TRY(crop_reserve((size_t)ns_all));
+            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_idx.data(), sizeof(int) * ns_all, hipMemcpyHostToDevice, s));
+            for (int g = 0; g < G; ++g) {
+                const int ns = g_first[g + 1] - g_first[g];
+                if (ns == 0) continue;
+                const auto& box = crops[c0 + ci + g];
+                ENG_KP(e, PC_MASK_POST, 0.0, (double)ns * (65536.0 * 4 + (double)mask_words * 4),
+                       launch_mask_post(masks, e->amg_idx + g_first[g], ns, box[0], box[1], box[2] - box[0], box[3] - box[1], H, W, prm->mask_threshold,
+                                        prm->stability_score_offset, e->amg_crop_bits + (size_t)g_first[g] * mask_words, e->amg_stats + g_first[g], s));
+            }
+            h_stats.resize(ns_all);
+            ENG_HIP(e, hipMemcpyAsync(h_stats.data(), e->amg_stats, sizeof(MaskStats) * ns_all, hipMemcpyDeviceToHost, s));
+            { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }                                   // sync 2 of 2
           for (int g = 0; g < G; ++g) {            // per-crop filtering and NMS, exactly as for unbatched crops
             const auto& box = crops[c0 + ci + g];
-            const int cw = box[2] - box[0], chh = box[3] - box[1];
             const float* crop_pts = crop_pts_all.data() + (size_t)g * np * 2;
             const int kbase = g * nm;              // first mask of this crop in the group buffers
-            h_iou.assign(h_iou_all.begin() + kbase, h_iou_all.begin() + kbase + nm);
-            h_idx.clear();
-            for (int k = 0; k < nm; ++k)
-                if (!(prm->pred_iou_thresh > 0.0f) || h_iou[k] > prm->pred_iou_thresh) h_idx.push_back(kbase + k);
-            const int ns = (int)h_idx.size();
+            const int ns = g_first[g + 1] - g_first[g];
             if (ns == 0) continue;
-            TRY(crop_reserve((size_t)ns));
-            uint32_t* crop_bits = e->amg_crop_bits;
-            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
-            ENG_KP(e, PC_MASK_POST, 0.0, (double)ns * (65536.0 * 4 + (double)mask_words * 4), launch_mask_post(masks, e->amg_idx, ns, box[0], box[1], cw, chh, H, W, prm->mask_threshold, prm->stability_score_offset,
-                                      crop_bits, e->amg_stats, s));
-            h_stats.resize(ns);
-            ENG_HIP(e, hipMemcpyAsync(h_stats.data(), e->amg_stats, sizeof(MaskStats) * ns, hipMemcpyDeviceToHost, s));
-            ENG_HIP(e, hipStreamSynchronize(s));
+            const uint32_t* crop_bits = e->amg_crop_bits + (size_t)g_first[g] * mask_words;
             std::vector<Cand> cand;
             std::vector<int> cand_src;  // index into crop_bits
             for (int k = 0; k < ns; ++k) {
-                const MaskStats& st = h_stats[k];
+                const MaskStats& st = h_stats[g_first[g] + k];
                 const float stab = (float)st.inter / (float)st.uni;  // 0/0 -> nan fails the filter like upstream
                 if (prm->stability_score_thresh > 0.0f && !(stab >= prm->stability_score_thresh)) continue;
                 Cand cd;
@@ -236,8 +253,8 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                     near = near || (nc_ && !ni);
                 }
                 if (near) continue;
-                const int src = h_idx[k] - kbase;
-                cd.iou = h_iou[src];
+                const int src = h_idx[g_first[g] + k] - kbase;
+                cd.iou = h_iou_all[kbase + src];
                 cd.stab = stab;
                 const int pk = src / M;
                 cd.pt[0] = crop_pts[2 * pk] + (float)box[0];
@@ -290,7 +307,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         m.crop_box_xywh[0] = (float)cd.crop[0]; m.crop_box_xywh[1] = (float)cd.crop[1];
         m.crop_box_xywh[2] = (float)(cd.crop[2] - cd.crop[0]); m.crop_box_xywh[3] = (float)(cd.crop[3] - cd.crop[1]);
     }
-    ENG_HIP(e, hipStreamSynchronize(s));
+    { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
     *out_count = nf;
     return SABER_OK;
 }

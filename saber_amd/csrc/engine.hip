@@ -602,6 +602,16 @@ static GemmParams mk_gemm(const bf16_t* A, int64_t lda, int M, const LinW& w) {
     p.A = A; p.lda = lda; p.W = w.w; p.ldw = w.ldw; p.w_kpad = 1; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in; p.Wpk = w.wpk;
     return p;
 }
+// algorithmic HBM bytes of one GEMM launch: every operand once (A, W, bias-free), every output once, the residual read once
+static double gemm_bytes(const GemmParams& g, bool rowln = false) {
+    const double M = g.M, N = g.N, K = g.K, Mo = g.pool4 ? M / 4 : M, b = g.batch > 0 ? g.batch : 1;
+    double by = M * K * 2 + N * K * 2;
+    if (g.Cf) by += Mo * N * 4;
+    if (g.Cb) by += Mo * N * 2;
+    if (g.res) by += (g.res_shift || g.res_mod ? 0.0 : Mo * N * 4);
+    if (rowln) by += Mo * N * 2;
+    return by * b;
+}
 static const char* ln_run(const float* x, const LnW& w, float eps, int rows, int C, float* out_f, bf16_t* out_bf, int act, hipStream_t s,
                           bf16_t* out_bf_add = nullptr, const float* addvec = nullptr, int add_mod = 0, const uint8_t* row_valid = nullptr,
                           int valid_mod = 0) {
@@ -676,14 +686,14 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         if (bs.din != bs.dout) {
             GemmParams g = mk_gemm(e->xn, bs.din, N, w.sc);
             g.Cf = xalt; g.ldcf = bs.dout; g.pool4 = 1;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
             xres = xalt;
             Nq = N / 4;
         }
         {
             GemmParams g = mk_gemm(e->xn, bs.din, N, w.qkv);
             g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
         }
         const int nk = bs.window > 0 ? bs.window * bs.window : tokens;
         // global blocks of the padded layout: one "window" per image whose padding rows are masked out as keys
@@ -695,9 +705,9 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             g.Cf = xres; g.ldcf = bs.dout; g.res = xres; g.ldres = bs.dout;
             g.ln_gamma = w.n2.g; g.ln_beta = w.n2.b; g.ln_eps = 1e-6f; g.ln_out = e->xn; g.ldln = bs.dout;
             if (fuse && gemm_rowln_supported(g)) {
-                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm_rowln(g, s));
+                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g, true), launch_gemm_rowln(g, s));
             } else {
-                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
                 ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(xres, w.n2, 1e-6f, Nq, bs.dout, nullptr, e->xn, ACT_NONE, s));
             }
         }
@@ -705,7 +715,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         {
             GemmParams g = mk_gemm(e->xn, bs.dout, Nq, w.fc1);
             g.Cb = e->hid; g.ldcb = 4 * bs.dout; g.act = ACT_GELU;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
         }
         const bool to_padded = e->padded && bs.din != bs.dout && stage == 2;
         const bool has_next = i + 1 < nblocks;
@@ -718,8 +728,8 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
                 g.ln_gamma = e->bw[i + 1].n1.g; g.ln_beta = e->bw[i + 1].n1.b; g.ln_eps = 1e-6f; g.ln_out = e->xn; g.ldln = bs.dout;
                 fused = gemm_rowln_supported(g);
             }
-            if (fused) ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm_rowln(g, s));
-            else ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+            if (fused) ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g, true), launch_gemm_rowln(g, s));
+            else ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
             if (to_padded) {
                 // the 64^2 grid leaves the stage-transition block in the bit-interleaved order; the 14x14 windows of the blocks that
                 // follow need the window-major padded layout (padding rows start as zeros and are re-zeroed by every norm1)
@@ -735,25 +745,25 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
     {
         GemmParams g = mk_gemm(e->sb[3], e->stage_dims[3], n * e->tok_rows[3], e->neck3);
         g.Cf = e->lat3; g.ldcf = 256;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[2], e->stage_dims[2], n * e->tok_rows[2], e->neck2);
         float* emb_slot = e->emb + (size_t)slot0 * 4096 * 256;
         g.Cf = e->padded ? e->xa : emb_slot; g.ldcf = 256; g.res = e->lat3; g.ldres = 256; g.res_shift = 2;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
         // padded layout -> the decoder's bit-interleaved order of the 64^2 grid (the residual stream buffers are free by now)
         if (e->padded) ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(e->xa, e->tok_rows[2], emb_slot, 4096, e->unpack_idx, 256, n, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[1], e->stage_dims[1], n * 16384, e->s1);
         g.Cf = e->fs1 + (size_t)slot0 * 16384 * 64; g.ldcf = 64;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
     }
     {
         GemmParams g = mk_gemm(e->sb[0], e->stage_dims[0], n * 65536, e->s0);
         g.Cf = e->fs0 + (size_t)slot0 * 65536 * 32; g.ldcf = 32;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
     }
     for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
     ENG_HIP(e, hipGetLastError());
@@ -821,12 +831,12 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         GemmParams g = mk_gemm(e->t_bf0, 256, PT, a.q);
         g.Cf = e->tq; g.ldcf = 128;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tq, a.k.w, nullptr, 0, kScale, e->fold_q, nullptr, P, s));
         ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, a.pe_proj, e->fold_q, e->tq, kScale, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
         g = mk_gemm(e->t_att, 128, PT, a.o);
         g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, ln, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         return SABER_OK;
     };
@@ -837,27 +847,27 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, l == 0 ? nullptr : e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         const bf16_t* vin = e->t_bf0;
         if (l > 0) { ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s)); vin = e->t_bf1; }
-        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        GemmParams g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.q); g.Cf = e->tq; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.self_attn.k); g.Cf = e->tk; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
+        g = mk_gemm(vin, 256, PT, w.self_attn.v); g.Cf = e->tv; g.ldcf = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_DEC_ATTN, 0.0, 0.0, launch_dec_attention(e->tq, e->tk, e->tv, e->t_att, P, T, T, 8, 32, T * 256, T * 256, T * 256, T * 256, s));
         g = mk_gemm(e->t_att, 256, PT, w.self_attn.o);
         g.Cf = e->queries; g.ldcf = 256;
         if (l > 0) { g.res = e->queries; g.ldres = 256; }
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, w.n1, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         // (2) tokens -> image
         TRY(t2i(w.t2i, w.n2));
         // (3) MLP
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.mlp1); g.Cb = e->t_hid; g.ldcb = 2048; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
+        g = mk_gemm(e->t_hid, 2048, PT, w.mlp2); g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(e->queries, w.n3, 1e-5f, PT, 256, e->queries, nullptr, ACT_NONE, s));
         // (4) image -> tokens, fused with the residual and norm4: X <- LN(X + attn)
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf1, nullptr, PT, 256, s));
-        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        g = mk_gemm(e->t_bf0, 256, PT, w.i2t.k); g.Cf = e->tk; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
+        g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tk, w.i2t.q.w, w.i2t.q.b, 0, kScale, e->fold_k, e->fold_cb, P, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tv, w.i2t.o.w, nullptr, 1, 1.0f, e->fold_v, nullptr, P, s));
         ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, w.i2t.pe_proj, e->fold_k, e->tk, kScale, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
@@ -868,9 +878,9 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     // heads
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, nullptr, 1, e->t_bf0, nullptr, PT, 256, s));
     auto mlp3 = [&](const LinW* L, const bf16_t* A, int last_act, float* outf, int ldo) -> int {
-        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
-        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0, launch_gemm(g, s));
+        GemmParams g = mk_gemm(A, T * 256, P, L[0]); g.Cb = e->head_bf0; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
+        g = mk_gemm(e->head_bf0, 256, P, L[1]); g.Cb = e->head_bf1; g.ldcb = 256; g.act = ACT_RELU; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
+        g = mk_gemm(e->head_bf1, 256, P, L[2]); g.Cf = outf; g.ldcf = ldo; g.act = last_act; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         return SABER_OK;
     };
     TRY(mlp3(e->iou_head, e->t_bf0 + 1 * 256, ACT_SIGMOID, e->iou4, 4));
@@ -879,15 +889,15 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         GemmParams g = mk_gemm(e->t_bf0 + 2 * 256, T * 256, P, e->hyper[0]);
         g.batch = 4; g.strideA = 256; g.strideW = 256 * 256; g.strideBias = 256;
         g.Cb = e->head_bf0; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, gemm_bytes(g), launch_gemm(g, s));
         g = mk_gemm(e->head_bf0, 256, P, e->hyper[1]);
         g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 256 * 256; g.strideBias = 256;
         g.Cb = e->head_bf1; g.ldcb = 256; g.strideCb = (int64_t)P * 256; g.act = ACT_RELU;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, gemm_bytes(g), launch_gemm(g, s));
         g = mk_gemm(e->head_bf1, 256, P, e->hyper[2]);
         g.batch = 4; g.strideA = (int64_t)P * 256; g.strideW = 32 * 256; g.strideBias = 32;
         g.Cf = e->hyper_out; g.ldcf = 128; g.strideCf = 32;
-        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, 0.0, launch_gemm(g, s));
+        ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, gemm_bytes(g), launch_gemm(g, s));
     }
     // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),

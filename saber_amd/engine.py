@@ -232,9 +232,10 @@ def make_amg_params(amg: Optional[dict] = None) -> "_lib.AmgParams":
     """cfgAMG dict (saber/adapters/sam2/amg.py:7-17) -> C struct, with the upstream defaults SABER does not pass."""
     a = dict(npoints=32, points_per_batch=64, pred_iou_thresh=0.7, stability_score_thresh=0.92, stability_score_offset=0.7,
              crop_n_layers=2, box_nms_thresh=0.7, crop_n_points_downscale_factor=2, use_m2m=True, multimask_output=True)
+    a["crop_nms_thresh"] = 0.7          # upstream default; not a cfgAMG field (bench.py's tail mode and tests may override it)
     a.update({k: v for k, v in (amg or {}).items() if k in a})
     return _lib.AmgParams(points_per_side=a["npoints"], points_per_batch=a["points_per_batch"], pred_iou_thresh=a["pred_iou_thresh"],
                           stability_score_thresh=a["stability_score_thresh"], stability_score_offset=a["stability_score_offset"],
-                          mask_threshold=0.0, box_nms_thresh=a["box_nms_thresh"], crop_n_layers=a["crop_n_layers"], crop_nms_thresh=0.7,
+                          mask_threshold=0.0, box_nms_thresh=a["box_nms_thresh"], crop_n_layers=a["crop_n_layers"], crop_nms_thresh=a["crop_nms_thresh"],
                           crop_overlap_ratio=512 / 1500, crop_n_points_downscale_factor=a["crop_n_points_downscale_factor"],
                           use_m2m=int(a["use_m2m"]), multimask_output=int(a["multimask_output"]))
