@@ -1,0 +1,52 @@
+"""Generates tests/golden/amg_default_grid_seed0.npz: the fp32 oracle's AMG result for BASELINE configs[1]'s slice
+(oracle.saber_ref.synthetic_slice(seed=0) -> prepare) at SABER's default point grid and crop pyramid (npoints=32, crop_n_layers=2:
+21 crops, 3 072 grid prompts + 9 216 m2m refinements) with the seeded Hiera-L weights.
+
+cfgAMG's default score thresholds (0.7 / 0.92) leave 0-1 masks with untrained weights, and the seeded model's masks are image-sized
+blobs that suppress each other in both box NMS stages, so the filters are set to leave a few hundred masks: pred_iou_thresh = 0.8055
+(the value that keeps ~250 of the 3 072 full-image masks), stability filter and both NMS off.  Every other step of
+SAM2AutomaticMaskGenerator.generate runs as configured by the reference (saber/adapters/sam2/automask.py:66-78).
+
+About 15-25 minutes of CPU time in the authoring container:   python -m oracle.make_golden_amg
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "amg_default_grid_seed0.npz")
+AMG = dict(points_per_side=32, points_per_batch=64, pred_iou_thresh=0.8055, stability_score_thresh=0.0, stability_score_offset=0.7,
+           box_nms_thresh=1.0, crop_n_layers=2, crop_nms_thresh=1.0, crop_n_points_downscale_factor=2, use_m2m=True, multimask_output=True)
+
+
+def main():
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    from oracle import saber_ref
+    from oracle.sam2_ref import ImagePredictorRef
+    from oracle.amg_ref import AutomaticMaskGeneratorRef
+    torch.set_num_threads(int(os.environ.get("THREADS", "6")))
+    cfg = get_config("large")
+    W = seeded_weights(cfg, 0)
+    img = saber_ref.prepare(saber_ref.synthetic_slice(seed=0).astype(np.float32), to_rgb=True)
+    t0 = time.time()
+    anns = AutomaticMaskGeneratorRef(ImagePredictorRef(W, cfg), **AMG).generate(img)
+    print(f"{len(anns)} masks in {time.time() - t0:.0f} s", flush=True)
+    n = len(anns)
+    q = np.zeros((n, 256, 256), dtype=bool)
+    for i, a in enumerate(anns):
+        q[i] = a["segmentation"][2::4, 2::4]                  # quarter-resolution sample of the full-resolution mask
+    np.savez_compressed(OUT, count=np.array(n), area=np.array([a["area"] for a in anns], dtype=np.int64),
+                        bbox=np.array([a["bbox"] for a in anns], dtype=np.float32).reshape(n, 4),
+                        predicted_iou=np.array([a["predicted_iou"] for a in anns], dtype=np.float32),
+                        stability_score=np.array([a["stability_score"] for a in anns], dtype=np.float32),
+                        point=np.array([a["point_coords"][0] for a in anns], dtype=np.float32).reshape(n, 2),
+                        crop_box=np.array([a["crop_box"] for a in anns], dtype=np.float32).reshape(n, 4),
+                        quarter_bits=np.packbits(q, axis=-1), amg=np.array(repr(AMG)))
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
