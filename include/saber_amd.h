@@ -110,6 +110,15 @@ int saber_encode(saber_engine* e, const float* img_dev, int H, int W, int channe
  * Any pointer may be NULL. */
 int saber_get_features(saber_engine* e, int slot, float* image_embed_dev, float* feat_s0_dev, float* feat_s1_dev, void* stream);
 
+/* Video (memory) path, SURVEY.md 8f-1 (reference: saber/adapters/sam2/predictor.py:232-348 driving upstream SAM2Base.track_step): a tracked
+ * frame's image embedding is replaced by its memory-conditioned version before the mask decoder runs.  Tokens cross this boundary as
+ * (4096, 256) fp32 in row-major (y * 64 + x) order.  get: the slot's image_embed (with no_mem_embed, as saber_encode leaves it).
+ * set: overwrite it (the slot keeps its high-resolution features).  saber_get_decoder_tokens: the (n, 8, 256) output tokens of the last
+ * saber_decode_points call ([obj, iou, mask0..3, point, pad]); upstream projects one mask token to the object pointer. */
+int saber_get_embed_tokens(saber_engine* e, int slot, float* out_tokens_dev, void* stream);
+int saber_set_embed_tokens(saber_engine* e, int slot, const float* tokens_dev, void* stream);
+int saber_get_decoder_tokens(saber_engine* e, int n, float* out_dev, void* stream);
+
 /* Decode n point prompts against a slot.  pts_dev: (n,2) in model pixels (0..1024); labels_dev: (n) or NULL (=1).
  * mask_in_dev: (n,256,256) low-res logits or NULL.  multimask: 3 masks per prompt, else 1 (dynamic selection).
  * Outputs: lowres (n,M,256,256), iou (n,M), obj (n) - any may be NULL. */

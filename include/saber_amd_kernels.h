@@ -61,6 +61,32 @@ int saber_k_prepare(const void* img, int dtype, int H, int W, float* out, float*
 int saber_k_mask_post(const float* lowres, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H, int W, float thr,
                       float offset, uint32_t* bits, int32_t* stats, void* stream);
 
+/* ---- SAM2 video (memory) path: the per-frame arithmetic the reference's segment_volume (saber/adapters/sam2/predictor.py:232-348) makes the
+ * third-party video predictor run besides encoder and mask decoder (upstream sam2/modeling/{memory_attention,memory_encoder,sam2_base}.py).
+ * Channels-last fp32 tensors [pixels][C], pixels in row-major (y, x) order. */
+/* axial rotary encoding of q / k (RoPEAttention): rows < n_rot are rotated (token = row % side^2 on a side x side grid, theta 10000), the
+ * rest (object-pointer tokens) copied; fp32 and/or bf16 out */
+int saber_k_rope(const float* x, int64_t rows, int n_rot, int C, int side, float theta, float* out_f32, uint16_t* out_bf16, void* stream);
+/* P[row][0..n) = softmax(scale * S[row][0..n)) as bf16; columns n..ld_p zeroed */
+int saber_k_softmax_rows(const float* S, int64_t ld_s, int64_t rows, int n, float scale, uint16_t* P, int64_t ld_p, void* stream);
+/* Conv2d(k3, s2, p1) of the memory encoder's mask down-sampler; w (Cout,Cin,3,3) */
+int saber_k_conv3x3s2(const float* in, int H, int W, int Cin, const float* w, const float* b, int Cout, float* out, void* stream);
+/* depth-wise Conv2d(k7, p3) of the memory fuser's ConvNeXt blocks; w (C,1,7,7) */
+int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream);
+/* the video predictor's mask_downsample: Conv2d(1, 1, k4, s4) */
+int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=False, antialias) of n planes, fused post transform: 0 none, 1 a*sigmoid(v)+c, 2 a*(v>0)+c, 3 a*v+c, 4 (v>=a) */
+int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream);
+/* out = x + alpha * g[c] * y  (x, g may be NULL) */
+int saber_k_axpy(const float* x, const float* y, const float* g, float alpha, int64_t rows, int C, float* out, void* stream);
+/* out = x + y[row % y_rows] as bf16 and/or fp32 (y may be NULL) */
+int saber_k_add_to_bf16(const float* x, const float* y, int y_rows, uint16_t* out_bf16, float* out_f32, int64_t rows, int C, void* stream);
+/* widen stored bf16 (the memory bank keeps spatial memories in bf16, as upstream does) to fp32 */
+int saber_k_bf16_to_f32(const uint16_t* x, int64_t n, float* out, void* stream);
+/* batched bf16 GEMM C[b] = A[b] . W[b]^T + bias with explicit leading dimensions and batch strides */
+int saber_k_gemm_batched(const uint16_t* A, int lda, int64_t strideA, const uint16_t* W, int ldw, int64_t strideW, const float* bias, float* out_f32,
+                         int ldcf, int64_t strideCf, uint16_t* out_bf16, int ldcb, int64_t strideCb, int M, int N, int K, int batch, void* stream);
+
 /* engine token order helpers (DESIGN.md "token order") */
 /* Folded image->token attention of the two-way transformer (reference: sam2 TwoWayAttentionBlock.cross_attn_image_to_token +
  * norm4, called from sam2/modeling/sam/transformer.py via saber/adapters/sam2/automask.py's predictor):

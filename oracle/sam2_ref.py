@@ -269,9 +269,10 @@ def _stability(logits, delta):
     return torch.where(au > 0, ai / au, torch.ones_like(au))
 
 
-def mask_decoder(W, feats, sparse, dense, multimask_output: bool, pos: Optional[torch.Tensor] = None):
+def mask_decoder(W, feats, sparse, dense, multimask_output: bool, pos: Optional[torch.Tensor] = None, return_tokens: bool = False):
     """feats: encode_image() dict for ONE image (B=1). sparse (P,T,256), dense (P|1,256,64,64).
-    Returns low_res (P,M,256,256), iou (P,M), obj (P,1), all_masks (P,4,256,256), all_iou (P,4)."""
+    Returns low_res (P,M,256,256), iou (P,M), obj (P,1), all_masks (P,4,256,256), all_iou (P,4)
+    [+ the 4 mask tokens after the transformer (P,4,256) with return_tokens: the video path projects one of them to the object pointer]."""
     d = "sam_mask_decoder."
     P = sparse.shape[0]
     out_tok = torch.cat([W[d + "obj_score_token.weight"], W[d + "iou_token.weight"], W[d + "mask_tokens.weight"]], 0)
@@ -306,6 +307,8 @@ def mask_decoder(W, feats, sparse, dense, multimask_output: bool, pos: Optional[
         stable = _stability(single, DYN_MULTIMASK_DELTA) >= DYN_MULTIMASK_THRESH
         masks = torch.where(stable[..., None, None], single, best_masks)
         iou = torch.where(stable, single_iou, best_iou)
+    if return_tokens:
+        return masks, iou, obj, all_masks, all_iou, mask_toks
     return masks, iou, obj, all_masks, all_iou
 
 

@@ -14,11 +14,13 @@ Weights are addressed by their upstream checkpoint keys (`memory_attention.layer
 oracle/sam2_ref.py.  Parity unpinned (the reference pins nothing here and `sam2` is absent); cross-checked in this container
 against the independent restatement in `transformers` (`Sam2VideoMemoryAttention`, `Sam2VideoMemoryEncoder`) with shared random
 weights: oracle/hf_crosscheck_video.py, tests/test_oracle_video.py.  The tracking loop around them (memory bank, object pointers,
-temporal encodings, occlusion logic) is not restated yet.
+temporal encodings, occlusion logic, the adapter's bidirectional pass with its presence-score filter) follows further down:
+VideoPredictorRef and segment_volume_ref.
 """
 import math
-from typing import Dict
+from typing import Dict, Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -174,3 +176,307 @@ def from_hf_memory_encoder(sd: Dict[str, T], prefix: str = "memory_encoder") -> 
             name = {"depthwise_conv": "dwconv", "layer_norm": "norm", "pointwise_conv1": "pwconv1", "pointwise_conv2": "pwconv2", "scale": "gamma"}[name]
             out[f"{prefix}.fuser.layers.{i}.{name}" + ("" if name == "gamma" else "." + parts[4])] = v
     return out
+
+
+# ------------------------------------------------------------------------------------------------ tracking loop
+# Restated from the published SAM 2.1 video predictor (upstream sam2/sam2_video_predictor.py and sam2/modeling/sam2_base.py as the
+# reference drives them: saber/adapters/sam2/predictor.py:24-34 builds it with vos_optimized=False and truncates maskmem_tpos_enc to
+# num_maskmem rows; :163-202 add_new_mask / propagate_in_video; :232-348 segment_volume).  Settings of the sam2.1 configs + the video
+# predictor's overrides: per-object tracking (batch 1), use_obj_ptrs_in_encoder, max_obj_ptrs_in_encoder 16, signed + projected temporal
+# encoding of pointers, only_obj_ptrs_in_the_past_for_eval, pred_obj_scores (+ MLP), fixed_no_obj_ptr, no_obj_embed_spatial,
+# use_mlp_for_obj_ptr_proj, multimask_output_for_tracking with 0..1 points, use_multimask_token_for_obj_ptr, directly_add_no_mem_embed,
+# sigmoid scale / bias 20 / -10, binarize_mask_from_pts_for_mem_enc, max_cond_frames_in_attn -1, memory_temporal_stride 1,
+# non_overlap_masks off, fill_hole_area: the optional CUDA extension is treated as absent (upstream then skips the step with a warning).
+# Cross-checked against the independent `transformers` Sam2VideoModel where the two implement the same published steps
+# (oracle/hf_crosscheck_video.py); where they differ (mask-prompted frames: upstream encodes their memory in the propagation preflight
+# from the UP-SAMPLED low-res mask, binarised), upstream is followed because it is what the reference executes.
+NO_OBJ_SCORE = -1024.0
+
+
+def get_1d_sine_pe(pos: T, dim: int, temperature: float = 10000.0) -> T:
+    pe_dim = dim // 2
+    dim_t = torch.arange(pe_dim, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / pe_dim)
+    e = pos.unsqueeze(-1) / dim_t
+    return torch.cat([e.sin(), e.cos()], dim=-1)
+
+
+def _mlp(W: Dict[str, T], key: str, x: T, n: int) -> T:
+    for i in range(n):
+        x = _lin(W, f"{key}.layers.{i}", x)
+        if i < n - 1:
+            x = F.relu(x)
+    return x
+
+
+class VideoPredictorRef:
+    """One model, any number of objects tracked independently (as upstream's per-object inference does)."""
+
+    def __init__(self, weights, cfg, num_maskmem: int = 2):
+        from oracle import sam2_ref
+        if num_maskmem > 7:
+            raise ValueError("num_maskmem must be less than 7")                 # reference predictor.py:28-29
+        self.S = sam2_ref
+        self.W = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(v).float()) for k, v in weights.items()}
+        self.cfg = cfg
+        self.num_maskmem = num_maskmem
+        self.tpos = self.W["maskmem_tpos_enc"][:num_maskmem]                    # (num_maskmem,1,1,64): predictor.py:31-32
+        self.image_size = cfg.image_size
+        self._dense_pe = sam2_ref.dense_pe(self.W, self.image_size // 16)
+        self.hook = None                                                         # called with the object-score logits of every decoder call
+
+    # ---- state
+    def init_state(self, images: T, video_hw=None):
+        """images (Z,3,S,S) float tensor exactly as the adapter feeds them (adapters/preprocessing.py:27-70: values in [-3,1] for
+        a tomogram normalised to [-1,1], no ImageNet statistics)."""
+        self.images = images
+        self.num_frames = images.shape[0]
+        self.video_hw = video_hw or tuple(images.shape[-2:])
+        self.feat_cache = {}
+        self.obj_ids = []
+        self.out = {}            # obj_id -> {"cond": {t: out}, "non_cond": {t: out}}
+        self.temp = {}           # obj_id -> {t: out} (prompted frames awaiting the preflight)
+
+    @torch.no_grad()
+    def _feats(self, t: int):
+        if t not in self.feat_cache:
+            S, W = self.S, self.W
+            fpn = S.fpn_neck(W, self.cfg, S.hiera_trunk(W, self.cfg, self.images[t:t + 1]))
+            d = "sam_mask_decoder."
+            s0 = F.conv2d(fpn[0], W[d + "conv_s0.weight"], W[d + "conv_s0.bias"])
+            s1 = F.conv2d(fpn[1], W[d + "conv_s1.weight"], W[d + "conv_s1.bias"])
+            pos = sine_position_encoding(fpn[2].shape, 128)
+            self.feat_cache = {t: (fpn[2], pos, s0, s1)}                         # upstream caches the latest frame only
+        return self.feat_cache[t]
+
+    # ---- SAM heads on a (possibly memory-conditioned) feature map
+    @torch.no_grad()
+    def _sam_heads(self, pix_feat: T, s0: T, s1: T, mask_inputs: Optional[T], multimask_output: bool):
+        S, W = self.S, self.W
+        pts = torch.zeros(1, 1, 2)
+        lab = -torch.ones(1, 1, dtype=torch.int64)
+        sparse, dense = S.prompt_encoder(W, pts, lab, mask_inputs, self.image_size)
+        feats = {"image_embed": pix_feat, "feat_s0": s0, "feat_s1": s1}
+        low_multi, ious, obj, all_masks, all_iou, toks = S.mask_decoder(W, feats, sparse, dense, multimask_output, self._dense_pe, return_tokens=True)
+        if self.hook is not None:
+            self.hook(obj.clone())
+        appearing = obj > 0                                                       # (1,1)
+        low_multi = torch.where(appearing[:, None, None], low_multi, torch.full_like(low_multi, NO_OBJ_SCORE))
+        if multimask_output:
+            best = int(torch.argmax(ious, dim=-1))
+            low = low_multi[:, best:best + 1]
+            tok = toks[:, 1 + best]
+        else:
+            low = low_multi
+            tok = toks[:, 0]
+        high = F.interpolate(low, size=(self.image_size, self.image_size), mode="bilinear", align_corners=False)
+        ptr = _mlp(W, "obj_ptr_proj", tok, 3)
+        lam = appearing.float()
+        ptr = lam * ptr + (1 - lam) * W["no_obj_ptr"]
+        return low, high, ptr, obj
+
+    @torch.no_grad()
+    def _use_mask_as_output(self, pix_feat: T, s0: T, s1: T, mask_inputs: T):
+        """mask_inputs (1,1,S,S) float 0/1"""
+        W = self.W
+        high = mask_inputs * 20.0 - 10.0
+        low = F.interpolate(high, size=(high.shape[-2] // 4, high.shape[-1] // 4), mode="bilinear", align_corners=False, antialias=True)
+        md = F.conv2d(mask_inputs, W["mask_downsample.weight"], W["mask_downsample.bias"], stride=4)
+        _, _, ptr, _ = self._sam_heads(pix_feat, s0, s1, md, multimask_output=False)
+        appearing = torch.any(mask_inputs.flatten(1) > 0.0, dim=1)[:, None]
+        lam = appearing.float()
+        obj = 20.0 * lam - 10.0
+        ptr = lam * ptr + (1 - lam) * W["no_obj_ptr"]
+        return low, high, ptr, obj
+
+    @torch.no_grad()
+    def _encode_memory(self, pix_feat_raw: T, high_res_masks: T, obj: T, is_mask_from_pts: bool):
+        W = self.W
+        m = (high_res_masks > 0).float() if is_mask_from_pts else torch.sigmoid(high_res_masks)
+        m = m * 20.0 - 10.0
+        feat, pos = memory_encoder(W, pix_feat_raw, m, skip_mask_sigmoid=True)
+        feat = feat + (1 - (obj > 0).float())[..., None, None] * W["no_obj_embed_spatial"][..., None, None]
+        return feat.to(torch.bfloat16).float(), pos                                # upstream stores the memory in bfloat16
+
+    # ---- prompts
+    @torch.no_grad()
+    def add_new_mask(self, frame_idx: int, obj_id: int, mask):
+        """mask: (H,W) array, non-zero = object.  Returns the frame's masks at video resolution like upstream's add_new_mask."""
+        if obj_id not in self.obj_ids:
+            self.obj_ids.append(obj_id)
+            self.out[obj_id] = {"cond": {}, "non_cond": {}}
+            self.temp[obj_id] = {}
+        m = torch.as_tensor(np.asarray(mask)).float()[None, None]
+        if m.shape[-2:] != (self.image_size, self.image_size):
+            m = F.interpolate(m, size=(self.image_size, self.image_size), mode="bilinear", align_corners=False, antialias=True)
+            m = (m >= 0.5).float()
+        else:
+            m = (m > 0).float() if m.dtype != torch.float32 else m
+        pix, pos, s0, s1 = self._feats(frame_idx)
+        low, high, ptr, obj = self._use_mask_as_output(pix, s0, s1, m)
+        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
+        return frame_idx, list(self.obj_ids), F.interpolate(low, size=self.video_hw, mode="bilinear", align_corners=False)
+
+    @torch.no_grad()
+    def _preflight(self):
+        for oid in self.obj_ids:
+            for t, out in self.temp[oid].items():
+                if out["maskmem_features"] is None:
+                    high = F.interpolate(out["pred_masks"], size=(self.image_size, self.image_size), mode="bilinear", align_corners=False)
+                    pix = self._feats(t)[0]
+                    out["maskmem_features"], out["maskmem_pos_enc"] = self._encode_memory(pix, high, out["object_score_logits"], is_mask_from_pts=True)
+                self.out[oid]["cond"][t] = out
+                self.out[oid]["non_cond"].pop(t, None)
+            self.temp[oid] = {}
+            if not self.out[oid]["cond"]:
+                raise RuntimeError("No input points or masks are provided for any object; please add inputs first.")
+
+    # ---- one tracked frame of one object
+    @torch.no_grad()
+    def _memory_conditioned(self, oid, t: int, pix: T, pos: T, reverse: bool) -> T:
+        W = self.W
+        store = self.out[oid]
+        mems, mem_pos = [], []
+        for tc, o in store["cond"].items():                                       # every conditioning frame (max_cond_frames_in_attn = -1)
+            mems.append(o["maskmem_features"]); mem_pos.append((o["maskmem_pos_enc"], self.num_maskmem - 1))
+        for t_pos in range(1, self.num_maskmem):
+            t_rel = self.num_maskmem - t_pos
+            prev = t + t_rel if reverse else t - t_rel
+            o = store["non_cond"].get(prev)
+            if o is None:
+                continue
+            mems.append(o["maskmem_features"]); mem_pos.append((o["maskmem_pos_enc"], self.num_maskmem - t_pos - 1))
+        flat = lambda x: x.flatten(2).permute(0, 2, 1)                            # (1,C,H,W) -> (1,HW,C)
+        memory = [flat(m) for m in mems]
+        memory_pos = [flat(p) + self.tpos[ti].view(1, 1, -1) for p, ti in mem_pos]      # temporal encoding added per channel
+        # object pointers: conditioning frames in the (temporal) past, then up to max_obj_ptrs - 1 tracked frames before this one
+        max_ptrs = min(self.num_frames, 16)
+        sign = -1 if reverse else 1
+        offs, ptrs = [], []
+        for tc, o in store["cond"].items():
+            if (tc >= t) if reverse else (tc <= t):
+                offs.append((t - tc) * sign); ptrs.append(o["obj_ptr"])
+        for d in range(1, max_ptrs):
+            tt = t + d if reverse else t - d
+            if tt < 0 or tt >= self.num_frames:
+                break
+            o = store["non_cond"].get(tt)
+            if o is not None:
+                offs.append(d); ptrs.append(o["obj_ptr"])
+        n_ptr_tokens = 0
+        if ptrs:
+            P = torch.stack(ptrs, 0)[:, 0]                                        # (n,256)
+            pe = get_1d_sine_pe(torch.tensor(offs, dtype=torch.float32) / float(max_ptrs - 1), 256)
+            pe = _lin(W, "obj_ptr_tpos_proj", pe)                                 # (n,64)
+            memory.append(P.reshape(-1, 4, 64).reshape(1, -1, 64))
+            memory_pos.append(pe.repeat_interleave(4, dim=0)[None])
+            n_ptr_tokens = P.shape[0] * 4
+        out = memory_attention(W, flat(pix), torch.cat(memory, 1), flat(pos), torch.cat(memory_pos, 1), n_ptr_tokens)
+        return out.permute(0, 2, 1).reshape(pix.shape)
+
+    @torch.no_grad()
+    def _track(self, oid, t: int, reverse: bool):
+        pix, pos, s0, s1 = self._feats(t)
+        cond = self._memory_conditioned(oid, t, pix, pos, reverse)
+        low, high, ptr, obj = self._sam_heads(cond, s0, s1, None, multimask_output=True)
+        feat, mpos = self._encode_memory(pix, high, obj, is_mask_from_pts=False)
+        return {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": feat, "maskmem_pos_enc": mpos}
+
+    @torch.no_grad()
+    def propagate_in_video(self, start_frame_idx: int, max_frame_num_to_track=None, reverse: bool = False):
+        """yields (frame_idx, obj_ids, video_res_masks (n_obj,1,Hv,Wv)) like upstream"""
+        self._preflight()
+        n = self.num_frames
+        if max_frame_num_to_track is None:
+            max_frame_num_to_track = n
+        if reverse:
+            end = max(start_frame_idx - max_frame_num_to_track, 0)
+            order = range(start_frame_idx, end - 1, -1) if start_frame_idx > 0 else []
+        else:
+            end = min(start_frame_idx + max_frame_num_to_track, n - 1)
+            order = range(start_frame_idx, end + 1)
+        for t in order:
+            lows = []
+            for oid in self.obj_ids:
+                if t in self.out[oid]["cond"]:
+                    lows.append(self.out[oid]["cond"][t]["pred_masks"])
+                else:
+                    o = self._track(oid, t, reverse)
+                    self.out[oid]["non_cond"][t] = o
+                    lows.append(o["pred_masks"])
+            allm = torch.cat(lows, 0)
+            yield t, list(self.obj_ids), F.interpolate(allm, size=self.video_hw, mode="bilinear", align_corners=False)
+
+
+def load_tomogram_frames(tomogram: "np.ndarray", image_size: int = 1024, light_modality: bool = False) -> T:
+    """adapters/preprocessing.py:27-76 as SAM2Adapter.create_inference_state_from_tomogram applies it: min-max to [-1,1], per-slice resize
+    to image_size (skimage.transform.resize, anti_aliasing=True: the identity at image_size, order-1 interpolation when up-sampling),
+    3 x channel repeat, then 2x - 1 again (img_mean / img_std are None on this path)."""
+    t = np.asarray(tomogram, dtype=np.float64)
+    t = (t - t.min()) / (t.max() - t.min())
+    t = (t * 2 - 1)
+    x = torch.from_numpy(t).float()[:, None]
+    if x.shape[-2:] != (image_size, image_size):
+        if x.shape[-2] > image_size or x.shape[-1] > image_size:
+            raise NotImplementedError("down-sampling resize (Gaussian anti-aliasing of skimage) is not restated")
+        x = F.interpolate(x, size=(image_size, image_size), mode="bilinear", align_corners=False)
+    x = x.repeat(1, 3, 1, 1)
+    x = 2 * x - 1
+    if light_modality:
+        x = (x - x.min()) / (x.max() - x.min()) * 255
+    return x
+
+
+def segment_volume_ref(pred: VideoPredictorRef, start_frame_idx: int, masks, vol_shape, max_frame_num_to_track=None, min_presence_score: float = 0.5):
+    """SAM2Adapter.segment_volume (predictor.py:232-348) on the oracle predictor, INCLUDING its hook bookkeeping: the forward hook on the
+    mask decoder files each call's object-score logits under `_current_frame`, which the adapter updates only AFTER the generator has
+    yielded a frame - so a frame's scores land on the previously yielded frame index (and the calls made inside add_new_mask on None).
+    Returns (vol_masks uint16 (Z,H,W), frame_metrics dict, frame_scores (Z,nMasks))."""
+    import numpy as np
+    from oracle import saber_ref
+    Z, H, Wd = vol_shape
+    mask_list = [np.squeeze(np.asarray(m)).astype(np.float32) for m in masks]
+    state = {"cur": None}
+    captured = {}
+
+    def hook(obj):
+        captured.setdefault(state["cur"], []).append(obj.detach().cpu().float().numpy())
+    pred.hook = hook
+    for obj_id, m in enumerate(mask_list, start=1):
+        if np.max(m) == 0:
+            continue
+        pred.add_new_mask(start_frame_idx, obj_id, m)
+    vol = np.zeros((Z, H, Wd), dtype=np.uint16)
+
+    def apply(t, obj_ids, logits):
+        for i, oid in enumerate(obj_ids):
+            m = np.squeeze((logits[i] > 0.0).numpy()).astype(bool)
+            if m.shape != (H, Wd):
+                m = saber_ref.resize_nearest(m, (H, Wd))
+            vol[t] = np.where(m, int(oid), vol[t])
+    for t, ids, logits in pred.propagate_in_video(start_frame_idx, max_frame_num_to_track, reverse=False):
+        state["cur"] = t
+        apply(t, ids, logits)
+    for t, ids, logits in pred.propagate_in_video(start_frame_idx, max_frame_num_to_track, reverse=True):
+        state["cur"] = t
+        if not vol[t].any():
+            apply(t, ids, logits)
+    pred.hook = None
+    n_masks = len(mask_list)
+    metrics, frame_scores = {}, np.zeros([Z, max(n_masks, 1)])[:, :n_masks]
+    if n_masks > 0:
+        for fidx, scores in captured.items():
+            if fidx is None:
+                continue
+            v = np.concatenate([s.flatten() for s in scores])
+            k = min(len(v), n_masks)
+            frame_scores[fidx, :k] = v[:k]
+        bounds = saber_ref.fit_organelle_boundaries(frame_scores)
+        for fidx in range(Z):
+            metrics[fidx] = {}
+            for mi in range(n_masks):
+                ps = float(bounds[fidx, mi])
+                metrics[fidx][mi + 1] = {"presence_score": ps}
+                if ps < min_presence_score:
+                    vol[fidx][vol[fidx] == mi + 1] = 0
+    return vol.astype(np.uint16), metrics, frame_scores

@@ -59,6 +59,9 @@ SIGNATURES = {
     "saber_prepare_rgb": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "saber_encode": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _i, _i, _vp]),
     "saber_get_features": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "saber_get_embed_tokens": (_i, [_vp, _i, _vp, _vp]),
+    "saber_set_embed_tokens": (_i, [_vp, _i, _vp, _vp]),
+    "saber_get_decoder_tokens": (_i, [_vp, _i, _vp, _vp]),
     "saber_decode_points": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),
     "saber_amg_last_syncs": (_i, [_vp]),
@@ -85,6 +88,16 @@ SIGNATURES = {
     "saber_k_perm_index": (_i, [_i, _i, _i]),
     "saber_k_dec_i2t": (_i, [_vp, C.c_int64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp]),
     "saber_k_dec_t2i": (_i, [_vp, C.c_int64, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "saber_k_rope": (_i, [_vp, C.c_int64, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "saber_k_softmax_rows": (_i, [_vp, C.c_int64, C.c_int64, _i, _f, _vp, C.c_int64, _vp]),
+    "saber_k_conv3x3s2": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "saber_k_dwconv7": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "saber_k_axpy": (_i, [_vp, _vp, _vp, _f, C.c_int64, _i, _vp, _vp]),
+    "saber_k_add_to_bf16": (_i, [_vp, _vp, _i, _vp, _vp, C.c_int64, _i, _vp]),
+    "saber_k_bf16_to_f32": (_i, [_vp, C.c_int64, _vp, _vp]),
+    "saber_k_gemm_batched": (_i, [_vp, _i, C.c_int64, _vp, _i, C.c_int64, _vp, _vp, _i, C.c_int64, _vp, _i, C.c_int64, _i, _i, _i, _i, _vp]),
     "saber_k_set_debug": (None, [_i]),
     "saber_k_set_stamp_buffer": (None, [_vp]),
 }

@@ -1,9 +1,8 @@
 """SAM2Adapter on the MI355X engine (reference: saber/adapters/sam2/predictor.py).
 
 Hot-path method: segment_image_2d (:48-70) = prep.prepare -> lazily built mask generator -> generate.
-The video-propagation methods of the ABC (set_volume / add_new_mask / propagate_in_video / segment_volume,
-:76-348) belong to the memory-attention path, a "next" row of the scope table; they raise
-NotImplementedError naming that, instead of silently doing something else."""
+The video-propagation methods of the ABC (set_volume / add_new_mask / propagate_in_video / segment_volume, :76-348) run the memory path
+of saber_amd.adapters.sam2.video on a second engine handle built from config.cfg, like the reference's second model."""
 from typing import Any, Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -14,7 +13,6 @@ from saber_amd.adapters.sam2.amg import cfgAMG
 from saber_amd.adapters.sam2.automask import build_amg
 from saber_amd.utils import preprocessing as prep
 
-_NEXT = "SAM2 video propagation (memory attention) is a 'next' row of the hot-path scope (SURVEY.md 8f-1), not built yet"
 
 
 class SAM2Adapter(BaseAdapter):
@@ -29,6 +27,7 @@ class SAM2Adapter(BaseAdapter):
         self._vol_shape: Optional[Tuple[int, int, int]] = None
         self.inference_state = None
         self._mask_generator = None
+        self._video_predictor = None
 
     def _generator(self):
         if self._mask_generator is None:
@@ -54,25 +53,134 @@ class SAM2Adapter(BaseAdapter):
         img = prep.prepare(image, to_rgb=image.ndim == 2, engine=gen.base_generator.engine)
         return gen.generate(img)
 
-    # ------------------------------------------------------------------ video path: next row
+    # ------------------------------------------------------------------ video path
+    def _video(self):
+        """The video predictor shares the trunk named by config.cfg (reference predictor.py:21-26 builds it from config.cfg, the AMG model
+        from amg_cfg.sam2_cfg - two models, as in the reference)."""
+        if self._video_predictor is None:
+            from saber_amd import pretrained_weights
+            from saber_amd.adapters.sam2.automask import get_engine
+            from saber_amd.adapters.sam2.video import VideoPredictor
+            eng = get_engine(self._config.cfg, self.device, self._config.checkpoint, max_images=1, max_prompts=8, replica=1000)
+            W = pretrained_weights.load_weights(self._config.cfg, self._config.checkpoint, video=True)
+            self._video_predictor = VideoPredictor(eng, W, num_maskmem=self._config.num_maskmem)
+        return self._video_predictor
+
+    @torch.inference_mode()
     def set_volume(self, tomogram: np.ndarray, offload_video_to_cpu: bool = False) -> None:
-        raise NotImplementedError(_NEXT)
+        """predictor.py:76-86: normalise the tomogram, resize every slice to the model's 1024^2, start an empty inference state"""
+        from saber_amd.adapters.sam2.video import load_tomogram_frames
+        self._vol_shape = tomogram.shape
+        self.frame_metrics = {}
+        frames = load_tomogram_frames(tomogram, 1024, self._config.light_modality)
+        vp = self._video()
+        vp.init_state(frames, video_hw=(1024, 1024))            # the reference reports the RESIZED size as the video size (preprocessing.py:24)
+        self.inference_state = vp
 
     def add_new_mask(self, frame_idx: int, obj_id: int, mask: np.ndarray, inference_state=None) -> Tuple:
-        raise NotImplementedError(_NEXT)
+        state = inference_state or self.inference_state
+        if state is None:
+            raise RuntimeError("Call set_volume() before add_new_mask().")
+        return state.add_new_mask(frame_idx, obj_id, mask)
 
     def add_new_points_or_box(self, frame_idx: int, obj_id: int, inference_state=None, **kwargs) -> Tuple:
-        raise NotImplementedError(_NEXT)
+        raise NotImplementedError("point / box prompts of the video predictor are not built: every SABER caller seeds propagation with masks "
+                                  "(segmenters/base.py:265-280 -> segment_volume(masks=...))")
 
+    @torch.inference_mode()
     def propagate_in_video(self, start_frame_idx, max_frame_num_to_track=None, reverse=False, inference_state=None) -> Iterator:
-        raise NotImplementedError(_NEXT)
+        """yields (frame_idx, obj_ids, mask_logits, mask_logits, None) like the reference (predictor.py:181-202)"""
+        state = inference_state or self.inference_state
+        if state is None:
+            raise RuntimeError("Call set_volume() before propagate_in_video().")
+        for t, ids, logits in state.propagate_in_video(start_frame_idx, max_frame_num_to_track, reverse):
+            yield t, ids, logits, logits, None
 
+    @staticmethod
+    def _normalize_masks(masks) -> List[np.ndarray]:
+        if masks is None:
+            return []
+        if isinstance(masks, torch.Tensor):
+            masks = masks.cpu().numpy()
+        if isinstance(masks, np.ndarray) and masks.ndim >= 3:
+            return [np.squeeze(masks[i]).astype(np.float32) for i in range(masks.shape[0])]
+        out = []
+        for m in masks:
+            if isinstance(m, torch.Tensor):
+                m = m.cpu().numpy()
+            if isinstance(m, dict):
+                m = m["segmentation"]
+            out.append(np.squeeze(m).astype(np.float32))
+        return out
+
+    @torch.inference_mode()
     def segment_volume(self, start_frame_idx: int, masks=None, vol_shape=None, max_frame_num_to_track=None,
                        min_presence_score: float = 0.5, inference_state=None) -> np.ndarray:
-        if self.inference_state is None:
-            raise RuntimeError("call set_volume() first")
-        raise NotImplementedError(_NEXT)
+        """Bidirectional propagation + presence-score filter, predictor.py:232-348 step by step.  The reference captures the mask decoder's
+        object-score logits with a forward hook and files them under `_current_frame`, which it updates only AFTER the generator has
+        yielded a frame: a frame's scores therefore land on the frame yielded before it.  Reproduced as is (it feeds the boundary fit)."""
+        from saber_amd.filters.estimate_thickness import fit_organelle_boundaries
+        from saber_amd.segmenters.utils import resize_mask_nearest
+        state = inference_state or self.inference_state
+        if state is None:
+            raise RuntimeError("Call set_volume() before segment_volume().")
+        if vol_shape is None:
+            vol_shape = self._vol_shape
+        if vol_shape is None:
+            raise RuntimeError("vol_shape required when inference_state is passed explicitly.")
+        Z, H, W = vol_shape
+        mask_list = self._normalize_masks(masks)
+        current = {"frame": None}
+        captured: Dict[Any, list] = {}
+        state.hook = lambda score: captured.setdefault(current["frame"], []).append(np.array([score], dtype=np.float32))
+        try:
+            for obj_id, mask in enumerate(mask_list, start=1):
+                if np.max(mask) == 0:
+                    continue
+                self.add_new_mask(frame_idx=start_frame_idx, obj_id=obj_id, mask=mask, inference_state=state)
+            self.frame_metrics = {}
+            vol_masks = np.zeros((Z, H, W), dtype=np.uint16)
+
+            def _apply(frame_idx, obj_ids, mask_logits):
+                binm = (mask_logits > 0.0).cpu().numpy()
+                for i, obj_id in enumerate(obj_ids):
+                    m = np.squeeze(binm[i]).astype(bool)
+                    if m.shape != (H, W):
+                        m = resize_mask_nearest(m, (H, W))
+                    vol_masks[frame_idx] = np.where(m, int(obj_id), vol_masks[frame_idx])
+
+            for frame_idx, obj_ids, mask_logits, _, _ in self.propagate_in_video(start_frame_idx, max_frame_num_to_track, False, state):
+                current["frame"] = frame_idx
+                _apply(frame_idx, obj_ids, mask_logits)
+            for frame_idx, obj_ids, mask_logits, _, _ in self.propagate_in_video(start_frame_idx, max_frame_num_to_track, True, state):
+                current["frame"] = frame_idx
+                if not vol_masks[frame_idx].any():
+                    _apply(frame_idx, obj_ids, mask_logits)
+        finally:
+            state.hook = None
+        n_masks = len(mask_list)
+        if n_masks > 0:
+            frame_scores = np.zeros([Z, n_masks])
+            for fidx, scores in captured.items():
+                if fidx is None:
+                    continue
+                v = np.concatenate([s.flatten() for s in scores])
+                n = min(len(v), n_masks)
+                frame_scores[fidx, :n] = v[:n]
+            self.frame_scores = frame_scores
+            bounds = fit_organelle_boundaries(frame_scores, plot=False)
+            for fidx in range(Z):
+                self.frame_metrics[fidx] = {}
+                for mi in range(n_masks):
+                    obj_id = mi + 1
+                    ps = float(bounds[fidx, mi])
+                    self.frame_metrics[fidx][obj_id] = {"presence_score": ps}
+                    if ps < min_presence_score:
+                        vol_masks[fidx][vol_masks[fidx] == obj_id] = 0
+        return vol_masks.astype(np.uint16)
 
     def reset_state(self, inference_state=None) -> None:
-        self.inference_state = None
+        state = inference_state or self.inference_state
+        if state is not None:
+            state.reset_state()
         self.frame_metrics = {}

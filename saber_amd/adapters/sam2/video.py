@@ -1,0 +1,423 @@
+"""SAM2 video (memory) propagation on the MI355X engine: the host side of SURVEY.md 8f-1.
+
+What `saber segment tomograms` runs after the seed slab (reference: saber/segmenters/tomo.py:81-139 -> SAM2Adapter.segment_volume,
+saber/adapters/sam2/predictor.py:232-348, which drives the third-party video predictor: add_new_mask, propagate_in_video forwards
+and backwards).  This module is the Python host of that loop; every arithmetic step is a HIP kernel behind the C-ABI:
+
+    per frame        Hiera encoder + FPN neck                      saber_encode (engine.hip: the AMG path's kernels)
+    memory attention 4 x [RoPE self-attention, RoPE cross-attention to the memory bank, MLP]
+                     projections / scores / values / MLP           saber_k_gemm_ld (bf16 MFMA GEMM)
+                     LayerNorm, RoPE, row softmax                  saber_k_layernorm, saber_k_rope, saber_k_softmax_rows
+    SAM heads        prompt encoder (no point / mask prompt) + two-way transformer + upscaling on the memory-conditioned embedding
+                                                                   saber_set_embed_tokens + saber_decode_points (+ saber_get_decoder_tokens)
+    object pointer   3-layer MLP on the chosen mask token           saber_k_gemm_ld
+    memory encoder   mask down-sampler, fuser, projection          saber_k_conv3x3s2, saber_k_layernorm (+GELU), saber_k_dwconv7, saber_k_gemm_ld, saber_k_axpy
+    masks            up / down-sampling, "mask for memory"          saber_k_resize_plane, saber_k_conv4x4s4
+
+torch is used for device allocation, host<->device copies and a handful of scalar read-backs (argmax of 3 IoU predictions, the sign
+of the object score) - the decisions upstream also takes on the host.  Objects are tracked independently, as upstream does.
+Settings follow the sam2.1 configs and the reference's construction (num_maskmem truncated to SAM2AdapterConfig.num_maskmem = 2,
+predictor.py:28-34); the optional hole-filling CUDA extension of upstream is treated as absent (upstream then skips it with a warning).
+"""
+import ctypes as C
+import math
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from saber_amd.model_config import IMAGE_MEAN, IMAGE_STD
+
+NO_OBJ_SCORE = -1024.0
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def _bf16_bits(a: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns, round to nearest even (the engine's weight conversion)"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return r.astype(np.uint16)
+
+
+def _sine_pe_2d(side: int, num_pos_feats: int) -> np.ndarray:
+    """upstream PositionEmbeddingSine(normalize=True, scale 2 pi, temperature 1e4): (side*side, 2*num_pos_feats), y half first"""
+    eps, scale = 1e-6, 2 * math.pi
+    yy, xx = np.meshgrid(np.arange(1, side + 1, dtype=np.float32), np.arange(1, side + 1, dtype=np.float32), indexing="ij")
+    yy = yy / np.float32(side + eps) * np.float32(scale)
+    xx = xx / np.float32(side + eps) * np.float32(scale)
+    d = np.arange(num_pos_feats, dtype=np.float32)
+    d = np.float32(10000.0) ** (2 * np.floor(d / 2) / np.float32(num_pos_feats))
+    px, py = xx[:, :, None] / d, yy[:, :, None] / d
+    px = np.stack((np.sin(px[:, :, 0::2]), np.cos(px[:, :, 1::2])), 3).reshape(side, side, -1)
+    py = np.stack((np.sin(py[:, :, 0::2]), np.cos(py[:, :, 1::2])), 3).reshape(side, side, -1)
+    return np.concatenate((py, px), 2).reshape(side * side, 2 * num_pos_feats).astype(np.float32)
+
+
+def _sine_pe_1d(pos: np.ndarray, dim: int) -> np.ndarray:
+    pe_dim = dim // 2
+    dim_t = np.float32(10000.0) ** (2 * np.floor(np.arange(pe_dim, dtype=np.float32) / 2) / np.float32(pe_dim))
+    e = pos.astype(np.float32)[:, None] / dim_t
+    return np.concatenate([np.sin(e), np.cos(e)], -1).astype(np.float32)
+
+
+def load_tomogram_frames(tomogram: np.ndarray, image_size: int = 1024, light_modality: bool = False) -> np.ndarray:
+    """TomogramPreprocessor as the adapter applies it (saber/adapters/preprocessing.py:27-76 via predictor.py:98-105): min-max to [-1,1],
+    per-slice resize to image_size (skimage.transform.resize(anti_aliasing=True): the identity at image_size, order-1 interpolation at
+    pixel centres when up-sampling; the Gaussian anti-aliasing of a DOWN-sampling resize is not restated), then `2x - 1` once more
+    (img_mean / img_std are None on this path, so frames span [-3, 1]).  Host glue on the whole volume, like the reference.
+    Returns (Z, image_size, image_size) float32: one gray plane per frame (the reference's 3 identical channels)."""
+    t = np.asarray(tomogram, dtype=np.float64)
+    t = (t - t.min()) / (t.max() - t.min())
+    t = t * 2 - 1
+    Z, H, W = t.shape
+    if (H, W) != (image_size, image_size):
+        if H > image_size or W > image_size:
+            raise NotImplementedError("tomograms larger than the model's 1024 px are down-sampled by skimage with Gaussian anti-aliasing in "
+                                      "the reference; resample them first (saber's Fourier cropping) - not restated here")
+        ys = np.clip((np.arange(image_size) + 0.5) * H / image_size - 0.5, 0, H - 1)
+        xs = np.clip((np.arange(image_size) + 0.5) * W / image_size - 0.5, 0, W - 1)
+        y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+        y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+        fy, fx = (ys - y0)[None, :, None], (xs - x0)[None, None, :]
+        a = t[:, y0][:, :, x0] * (1 - fx) + t[:, y0][:, :, x1] * fx
+        b = t[:, y1][:, :, x0] * (1 - fx) + t[:, y1][:, :, x1] * fx
+        t = a * (1 - fy) + b * fy
+    out = (2 * t.astype(np.float32) - 1).astype(np.float32)
+    if light_modality:
+        out = (out - out.min()) / (out.max() - out.min()) * 255
+    return out
+
+
+class VideoPredictor:
+    """add_new_mask / propagate_in_video of the SAM2 video predictor on one engine handle."""
+
+    def __init__(self, engine, weights: Dict[str, np.ndarray], num_maskmem: int = 2):
+        if num_maskmem > 7:
+            raise ValueError("num_maskmem must be less than 7")
+        self.eng, self.lib, self.dev = engine, engine.lib, engine.device
+        if self.lib.saber_k_init(engine.device_index) != 0:
+            raise RuntimeError(self.lib.saber_k_last_error().decode())
+        self.num_maskmem = num_maskmem
+        self.image_size = 1024
+        self._keep: List[torch.Tensor] = []
+        W = weights
+        missing = [k for k in ("memory_attention.norm.weight", "memory_encoder.out_proj.weight", "obj_ptr_proj.layers.0.weight", "maskmem_tpos_enc") if k not in W]
+        if missing:
+            raise ValueError(f"the video path needs the memory-model tensors of the checkpoint; missing {missing}")
+        self.f32: Dict[str, torch.Tensor] = {}
+        self.bf: Dict[str, torch.Tensor] = {}
+        for k, v in W.items():
+            if not (k.startswith(("memory_attention.", "memory_encoder.", "obj_ptr_proj.", "obj_ptr_tpos_proj.", "mask_downsample.")) or
+                    k in ("maskmem_tpos_enc", "no_obj_ptr", "no_obj_embed_spatial", "no_mem_embed")):
+                continue
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            self.f32[k] = torch.from_numpy(a).to(self.dev)
+            is_gemm_w = k.endswith(".weight") and a.ndim >= 2 and "dwconv" not in k and not k.startswith("mask_downsample.") and \
+                ("mask_downsampler.encoder" not in k or k.endswith("encoder.12.weight"))
+            if is_gemm_w:       # operands of the bf16 MFMA GEMM: [N][K] row-major, bf16 (RNE) like the engine's own weights
+                self.bf[k] = torch.from_numpy(_bf16_bits(a.reshape(a.shape[0], -1))).to(self.dev)
+        self.tpos = np.asarray(W["maskmem_tpos_enc"], dtype=np.float32)[:num_maskmem].reshape(num_maskmem, -1)      # predictor.py:31-32
+        self.no_obj_ptr = np.asarray(W["no_obj_ptr"], dtype=np.float32).reshape(1, 256)
+        self.no_obj_spatial = np.asarray(W["no_obj_embed_spatial"], dtype=np.float32).reshape(-1)
+        self.neg_no_mem = torch.from_numpy(-np.asarray(W["no_mem_embed"], dtype=np.float32).reshape(1, 256)).to(self.dev)
+        self.curr_pos = torch.from_numpy(_sine_pe_2d(64, 128)).to(self.dev)                     # (4096,256)
+        self.mem_pos = _sine_pe_2d(64, 32)                                                      # (4096,64) host: temporal encoding is added per use
+        self.hook = None
+        self.images = None
+
+    # ------------------------------------------------------------------ small wrappers over the C-ABI
+    def _p(self, t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _ck(self, st):
+        if st != 0:
+            raise RuntimeError(f"saber_amd: {self.lib.saber_k_last_error().decode()}")
+
+    def _new(self, *shape, dtype=torch.float32, zero=False):
+        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+
+    def _gemm(self, A, Wb, bias, M, N, K, out_f32=None, out_bf=None, res=None, act=ACT_NONE, lda=None, ldw=None):
+        """C = act(A[M,K] . W[N,K]^T + bias) (+ res); A, W bf16 (uint16 storage)"""
+        self._ck(self.lib.saber_k_gemm_ld(self._p(A), lda or K, self._p(Wb), ldw or K, 1 if (ldw or K) % 64 == 0 else 0, self._p(bias), self._p(res),
+                                          self._p(out_f32), self._p(out_bf), M, N, K, act, self._s()))
+
+    def _to_bf(self, x, rows, Cn, y=None, y_rows=1):
+        out = self._new(rows, Cn, dtype=torch.uint16)
+        self._ck(self.lib.saber_k_add_to_bf16(self._p(x), self._p(y), y_rows, self._p(out), None, rows, Cn, self._s()))
+        return out
+
+    def _ln(self, x, key, rows, Cn, eps, bf=True, act=ACT_NONE):
+        out = self._new(rows, Cn, dtype=torch.uint16 if bf else torch.float32)
+        self._ck(self.lib.saber_k_layernorm(self._p(x), self._p(self.f32[key + ".weight"]), self._p(self.f32[key + ".bias"]), eps,
+                                            None if bf else self._p(out), self._p(out) if bf else None, rows, Cn, act, self._s()))
+        return out
+
+    def _lin(self, x_bf, key, M, out_bf=False, res=None, act=ACT_NONE, bias=None):
+        w = self.bf[key + ".weight"]
+        N, K = w.shape
+        out = self._new(M, N, dtype=torch.uint16 if out_bf else torch.float32)
+        self._gemm(x_bf, w, self.f32[key + ".bias"] if bias is None else bias, M, N, K, None if out_bf else out, out if out_bf else None, res, act)
+        return out
+
+    # ------------------------------------------------------------------ state
+    def init_state(self, frames: np.ndarray, video_hw: Optional[Tuple[int, int]] = None):
+        """frames: (Z, 1024, 1024) float32 gray planes as load_tomogram_frames returns them"""
+        assert frames.ndim == 3 and frames.shape[1:] == (1024, 1024)
+        self.images = frames
+        self.num_frames = frames.shape[0]
+        self.video_hw = video_hw or (1024, 1024)
+        self.obj_ids: List[int] = []
+        self.out: Dict[int, Dict[str, dict]] = {}
+        self.temp: Dict[int, dict] = {}
+        self._cur = (-1, None)
+
+    def reset_state(self):
+        self.obj_ids, self.out, self.temp, self._cur = [], {}, {}, (-1, None)
+
+    def _frame(self, t: int) -> torch.Tensor:
+        """encode frame t into slot 0 (high-resolution features stay there for the decoder); returns the RAW top-level features
+        (without no_mem_embed) as (4096,256) fp32 row-major tokens"""
+        if self._cur[0] == t:
+            return self._cur[1]
+        g = self.images[t]
+        # the engine's pixel kernel applies the ImageNet statistics; the video path feeds frames WITHOUT them (preprocessing.py:55-56),
+        # so the statistics are pre-inverted per channel: ((v * std + mean) - mean) / std = v
+        img = np.stack([g * np.float32(s) + np.float32(m) for m, s in zip(IMAGE_MEAN, IMAGE_STD)], -1).astype(np.float32)
+        self.eng.encode(torch.from_numpy(np.ascontiguousarray(img)).to(self.dev), slot0=0)
+        emb = self._new(4096, 256)
+        self.eng._check(self.lib.saber_get_embed_tokens(self.eng.h, 0, self._p(emb), self._s()))
+        raw = self._new(4096, 256)
+        self._ck(self.lib.saber_k_add_to_bf16(self._p(emb), self._p(self.neg_no_mem), 1, None, self._p(raw), 4096, 256, self._s()))
+        self._cur = (t, raw)
+        return raw
+
+    # ------------------------------------------------------------------ SAM heads on a given (4096,256) embedding
+    def _sam_heads(self, embed_tokens: torch.Tensor, mask_in: Optional[torch.Tensor], multimask: bool):
+        """returns (low (256,256) device fp32, obj logit float, obj_ptr (1,256) host fp32)"""
+        self.eng._check(self.lib.saber_set_embed_tokens(self.eng.h, 0, self._p(embed_tokens), self._s()))
+        pts = torch.zeros(1, 2, device=self.dev)
+        lab = torch.full((1,), -1, dtype=torch.int32, device=self.dev)
+        low, iou, obj = self.eng.decode_points(pts, slot=0, multimask=multimask, mask_input=mask_in, labels=lab)
+        toks = self._new(8, 256)
+        self.eng._check(self.lib.saber_get_decoder_tokens(self.eng.h, 1, self._p(toks), self._s()))
+        obj_v = float(obj.cpu()[0])
+        if self.hook is not None:
+            self.hook(obj_v)
+        if multimask:
+            best = int(torch.argmax(iou[0].cpu()))
+            low_b, tok = low[0, best], toks[3 + best:4 + best]
+        else:
+            low_b, tok = low[0, 0], toks[2:3]
+        h = self._lin(self._to_bf(tok, 1, 256), "obj_ptr_proj.layers.0", 1, out_bf=True, act=ACT_RELU)
+        h = self._lin(h, "obj_ptr_proj.layers.1", 1, out_bf=True, act=ACT_RELU)
+        ptr = self._lin(h, "obj_ptr_proj.layers.2", 1).cpu().numpy()
+        appearing = obj_v > 0
+        if not appearing:
+            low_b = torch.full((256, 256), NO_OBJ_SCORE, device=self.dev)
+            ptr = self.no_obj_ptr.copy()
+        return low_b.contiguous(), obj_v, ptr
+
+    def _resize(self, x, H, W, Ho, Wo, antialias=0, post=0, a=0.0, c=0.0):
+        out = self._new(Ho, Wo)
+        self._ck(self.lib.saber_k_resize_plane(self._p(x), 1, H, W, self._p(out), Ho, Wo, antialias, post, a, c, self._s()))
+        return out
+
+    # ------------------------------------------------------------------ memory encoder
+    def _encode_memory(self, raw: torch.Tensor, mask_for_mem: torch.Tensor, appearing: bool):
+        """raw (4096,256) fp32 frame features, mask_for_mem (1024,1024) fp32 already scaled (sigmoid or binary, * 20 - 10).
+        Returns the spatial memory (4096,64) as stored: bf16 bits."""
+        x, H, Cin = mask_for_mem, 1024, 1
+        pre = "memory_encoder.mask_downsampler.encoder."
+        for j in range(4):
+            Cout = Cin * 4
+            y = self._new((H // 2) * (H // 2), Cout)
+            self._ck(self.lib.saber_k_conv3x3s2(self._p(x), H, H, Cin, self._p(self.f32[f"{pre}{3 * j}.weight"]), self._p(self.f32[f"{pre}{3 * j}.bias"]), Cout, self._p(y), self._s()))
+            H //= 2
+            x = self._ln(y, f"{pre}{3 * j + 1}", H * H, Cout, 1e-6, bf=(j == 3), act=ACT_GELU)
+            Cin = Cout
+        m = self._lin(x, pre + "12", 4096)                                                  # 1x1 conv 256 -> 256
+        p = self._lin(self._to_bf(raw, 4096, 256), "memory_encoder.pix_feat_proj", 4096, res=m)
+        for i in range(2):
+            f = f"memory_encoder.fuser.layers.{i}."
+            h = self._new(4096, 256)
+            self._ck(self.lib.saber_k_dwconv7(self._p(p), 64, 64, 256, self._p(self.f32[f + "dwconv.weight"]), self._p(self.f32[f + "dwconv.bias"]), self._p(h), self._s()))
+            hn = self._ln(h, f + "norm", 4096, 256, 1e-6)
+            h1 = self._lin(hn, f + "pwconv1", 4096, out_bf=True, act=ACT_GELU)
+            h2 = self._lin(h1, f + "pwconv2", 4096)
+            p2 = self._new(4096, 256)
+            self._ck(self.lib.saber_k_axpy(self._p(p), self._p(h2), self._p(self.f32[f + "gamma"]), 1.0, 4096, 256, self._p(p2), self._s()))
+            p = p2
+        bias = self.f32["memory_encoder.out_proj.bias"]
+        if not appearing:          # no_obj_embed_spatial on frames where the object is predicted absent
+            bias = bias + torch.from_numpy(self.no_obj_spatial).to(self.dev)
+        return self._lin(self._to_bf(p, 4096, 256), "memory_encoder.out_proj", 4096, out_bf=True, bias=bias.contiguous())
+
+    # ------------------------------------------------------------------ prompts
+    @torch.inference_mode()
+    def add_new_mask(self, frame_idx: int, obj_id: int, mask: np.ndarray):
+        """upstream add_new_mask: the mask becomes this frame's output as it is (+-10 logits), its object pointer comes from the SAM heads
+        prompted with the mask; the memory of the frame is encoded by the preflight of the next propagate_in_video."""
+        if self.images is None:
+            raise RuntimeError("call init_state() first")
+        if obj_id not in self.obj_ids:
+            self.obj_ids.append(obj_id)
+            self.out[obj_id] = {"cond": {}, "non_cond": {}}
+            self.temp[obj_id] = {}
+        m = np.ascontiguousarray(np.squeeze(np.asarray(mask)), dtype=np.float32)
+        md = torch.from_numpy(m).to(self.dev)
+        if m.shape != (1024, 1024):
+            md = self._resize(md, m.shape[0], m.shape[1], 1024, 1024, antialias=1, post=4, a=0.5)
+        appearing = bool((md > 0).any().item())
+        raw = self._frame(frame_idx)
+        high = self._resize(md, 1024, 1024, 1024, 1024, post=3, a=20.0, c=-10.0)
+        low = self._resize(high, 1024, 1024, 256, 256, antialias=1)
+        mdown = self._new(256, 256)
+        self._ck(self.lib.saber_k_conv4x4s4(self._p(md), 1024, 1024, self._p(self.f32["mask_downsample.weight"]), self._p(self.f32["mask_downsample.bias"]), self._p(mdown), self._s()))
+        _, _, ptr = self._sam_heads(raw, mdown.view(1, 256, 256), multimask=False)
+        # the pointer has been through the decoder's own object score (_forward_sam_heads); upstream then blends once more with the
+        # appearance the MASK itself says (_use_mask_as_output)
+        tok_ptr = ptr if appearing else self.no_obj_ptr.copy()
+        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": tok_ptr, "obj": 10.0 if appearing else -10.0, "mem": None, "raw": raw}
+        return frame_idx, list(self.obj_ids), low
+
+    def _preflight(self):
+        for oid in self.obj_ids:
+            for t, o in self.temp[oid].items():
+                if o["mem"] is None:
+                    mfm = self._resize(o["pred_masks"], 256, 256, 1024, 1024, antialias=0, post=2, a=20.0, c=-10.0)     # binarised: is_mask_from_pts
+                    o["mem"] = self._encode_memory(o["raw"], mfm, o["obj"] > 0)
+                    o["raw"] = None
+                self.out[oid]["cond"][t] = o
+                self.out[oid]["non_cond"].pop(t, None)
+            self.temp[oid] = {}
+            if not self.out[oid]["cond"]:
+                raise RuntimeError("No input points or masks are provided for any object; please add inputs first.")
+
+    # ------------------------------------------------------------------ memory attention
+    def _memory_conditioned(self, oid: int, t: int, raw: torch.Tensor, reverse: bool) -> torch.Tensor:
+        st = self.out[oid]
+        mems, pos = [], []
+        for tc, o in st["cond"].items():
+            mems.append(o["mem"]); pos.append(self.mem_pos + self.tpos[self.num_maskmem - 1][None])
+        for t_pos in range(1, self.num_maskmem):
+            t_rel = self.num_maskmem - t_pos
+            o = st["non_cond"].get(t + t_rel if reverse else t - t_rel)
+            if o is None:
+                continue
+            mems.append(o["mem"]); pos.append(self.mem_pos + self.tpos[self.num_maskmem - t_pos - 1][None])
+        max_ptrs = min(self.num_frames, 16)
+        sign = -1 if reverse else 1
+        offs, ptrs = [], []
+        for tc, o in st["cond"].items():
+            if (tc >= t) if reverse else (tc <= t):
+                offs.append((t - tc) * sign); ptrs.append(o["obj_ptr"])
+        for d in range(1, max_ptrs):
+            tt = t + d if reverse else t - d
+            if tt < 0 or tt >= self.num_frames:
+                break
+            o = st["non_cond"].get(tt)
+            if o is not None:
+                offs.append(d); ptrs.append(o["obj_ptr"])
+        n_spatial = 4096 * len(mems)
+        n_ptr_tok = 4 * len(ptrs)
+        Nk = n_spatial + n_ptr_tok
+        Nkp = (Nk + 63) // 64 * 64
+        # memory tokens (bf16 as stored) and their position encodings (fp32): [spatial memories ..., pointer tokens]
+        mem_bf = self._new(Nkp, 64, dtype=torch.uint16, zero=True)
+        for i, mm in enumerate(mems):
+            mem_bf[4096 * i:4096 * (i + 1)].copy_(mm)
+        pos_np = np.zeros((Nk, 64), np.float32)
+        for i, pp in enumerate(pos):
+            pos_np[4096 * i:4096 * (i + 1)] = pp
+        if ptrs:
+            P = np.concatenate(ptrs, 0).astype(np.float32)                                     # (n,256)
+            mem_bf[n_spatial:Nk].copy_(torch.from_numpy(_bf16_bits(P.reshape(-1, 64))).to(self.dev))   # pointer tokens enter the bank in fp32 upstream; the GEMM operand is bf16 either way
+            pe = _sine_pe_1d(np.asarray(offs, np.float32) / np.float32(max_ptrs - 1), 256)
+            pe_d = self._lin(self._to_bf(torch.from_numpy(pe).to(self.dev), len(ptrs), 256), "obj_ptr_tpos_proj", len(ptrs)).cpu().numpy()
+            pos_np[n_spatial:] = np.repeat(pe_d, 4, axis=0)
+        mem_f = self._new(Nk, 64)
+        self._ck(self.lib.saber_k_bf16_to_f32(self._p(mem_bf), Nk * 64, self._p(mem_f), self._s()))
+        kin_bf = self._to_bf(mem_f, Nk, 64, torch.from_numpy(pos_np).to(self.dev), Nk)              # bf16(memory + position)
+        # ---- 4 layers
+        x = self._new(4096, 256)
+        self._ck(self.lib.saber_k_axpy(self._p(raw), self._p(self.curr_pos), None, 0.1, 4096, 256, self._p(x), self._s()))
+        scale = 1.0 / 16.0
+
+        def attend(q_bf, k_bf, vT_bf, n_keys, n_keys_p, bv, ldk):
+            S = self._new(4096, n_keys)
+            self._gemm(q_bf, k_bf, None, 4096, n_keys, 256, out_f32=S)
+            Pm = self._new(4096, n_keys_p, dtype=torch.uint16)
+            self._ck(self.lib.saber_k_softmax_rows(self._p(S), n_keys, 4096, n_keys, scale, self._p(Pm), n_keys_p, self._s()))
+            O = self._new(4096, 256, dtype=torch.uint16)
+            self._gemm(Pm, vT_bf, bv, 4096, 256, n_keys_p, out_bf=O)          # softmax rows sum to 1: the value bias is added after the product
+            return O
+
+        def rope(x_f32, rows, n_rot):
+            out = self._new(rows, 256, dtype=torch.uint16)
+            self._ck(self.lib.saber_k_rope(self._p(x_f32), rows, n_rot, 256, 64, 10000.0, None, self._p(out), self._s()))
+            return out
+
+        for i in range(4):
+            L = f"memory_attention.layers.{i}."
+            tb = self._ln(x, L + "norm1", 4096, 256, 1e-5)
+            q = rope(self._lin(tb, L + "self_attn.q_proj", 4096), 4096, 4096)
+            k = rope(self._lin(tb, L + "self_attn.k_proj", 4096), 4096, 4096)
+            vT = self._new(256, 4096, dtype=torch.uint16)
+            self._gemm(self.bf[L + "self_attn.v_proj.weight"], tb, None, 256, 4096, 256, out_bf=vT)       # V^T = W_v . t^T
+            O = attend(q, k, vT, 4096, 4096, self.f32[L + "self_attn.v_proj.bias"], 256)
+            x = self._lin(O, L + "self_attn.out_proj", 4096, res=x)
+            tb = self._ln(x, L + "norm2", 4096, 256, 1e-5)
+            q = rope(self._lin(tb, L + "cross_attn_image.q_proj", 4096), 4096, 4096)
+            kf = self._new(Nkp, 256, zero=True)
+            self._gemm(kin_bf, self.bf[L + "cross_attn_image.k_proj.weight"], self.f32[L + "cross_attn_image.k_proj.bias"], Nk, 256, 64, out_f32=kf)
+            k = rope(kf, Nkp, n_spatial)
+            vT = self._new(256, Nkp, dtype=torch.uint16, zero=True)
+            self._gemm(self.bf[L + "cross_attn_image.v_proj.weight"], mem_bf, None, 256, Nk, 64, out_bf=vT, ldw=64)
+            vT2 = vT
+            if Nk != Nkp:          # the GEMM wrote Nk columns per row with leading dimension Nk: re-lay to the padded leading dimension
+                vT2 = self._new(256, Nkp, dtype=torch.uint16, zero=True)
+                vT2[:, :Nk].copy_(vT.view(-1)[:256 * Nk].view(256, Nk))
+            O = attend(q, k, vT2, Nk, Nkp, self.f32[L + "cross_attn_image.v_proj.bias"], 256)
+            x = self._lin(O, L + "cross_attn_image.out_proj", 4096, res=x)
+            tb = self._ln(x, L + "norm3", 4096, 256, 1e-5)
+            h = self._lin(tb, L + "linear1", 4096, out_bf=True, act=ACT_RELU)
+            x = self._lin(h, L + "linear2", 4096, res=x)
+        return self._ln(x, "memory_attention.norm", 4096, 256, 1e-5, bf=False)
+
+    # ------------------------------------------------------------------ tracking
+    def _track(self, oid: int, t: int, reverse: bool) -> dict:
+        raw = self._frame(t)
+        cond = self._memory_conditioned(oid, t, raw, reverse)
+        low, obj_v, ptr = self._sam_heads(cond, None, multimask=True)
+        mfm = self._resize(low, 256, 256, 1024, 1024, antialias=0, post=1, a=20.0, c=-10.0)       # sigmoid(high-res logits) * 20 - 10
+        mem = self._encode_memory(raw, mfm, obj_v > 0)
+        return {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": mem}
+
+    @torch.inference_mode()
+    def propagate_in_video(self, start_frame_idx: int, max_frame_num_to_track: Optional[int] = None, reverse: bool = False) -> Iterator:
+        """yields (frame_idx, obj_ids, video_res_mask_logits (n_obj, 1, Hv, Wv) device fp32) like upstream"""
+        self._preflight()
+        n = self.num_frames
+        if max_frame_num_to_track is None:
+            max_frame_num_to_track = n
+        if reverse:
+            end = max(start_frame_idx - max_frame_num_to_track, 0)
+            order = range(start_frame_idx, end - 1, -1) if start_frame_idx > 0 else []
+        else:
+            end = min(start_frame_idx + max_frame_num_to_track, n - 1)
+            order = range(start_frame_idx, end + 1)
+        Hv, Wv = self.video_hw
+        for t in order:
+            outs = []
+            for oid in self.obj_ids:
+                if t in self.out[oid]["cond"]:
+                    low = self.out[oid]["cond"][t]["pred_masks"]
+                else:
+                    o = self._track(oid, t, reverse)
+                    self.out[oid]["non_cond"][t] = o
+                    low = o["pred_masks"]
+                outs.append(self._resize(low, 256, 256, Hv, Wv))
+            yield t, list(self.obj_ids), torch.stack(outs, 0)[:, None]

@@ -116,3 +116,38 @@ int g_saber_debug_flags = 0;
 unsigned long long* g_saber_stamp_buf = nullptr;   // development: device buffer for in-kernel cycle stamps (nullptr in production)
 extern "C" void saber_k_set_stamp_buffer(void* dev) { g_saber_stamp_buf = (unsigned long long*)dev; }
 extern "C" void saber_k_set_debug(int flags) { g_saber_debug_flags = flags; }
+
+// ------------------------------------------------------------------------------------------------ video (memory) path kernels
+extern "C" int saber_k_rope(const float* x, int64_t rows, int n_rot, int C, int side, float theta, float* out_f32, uint16_t* out_bf16, void* stream) {
+    return kcheck(launch_rope(x, rows, n_rot, C, side, theta, out_f32, out_bf16, (hipStream_t)stream));
+}
+extern "C" int saber_k_softmax_rows(const float* S, int64_t ld_s, int64_t rows, int n, float scale, uint16_t* P, int64_t ld_p, void* stream) {
+    return kcheck(launch_softmax_rows(S, ld_s, rows, n, scale, P, ld_p, (hipStream_t)stream));
+}
+extern "C" int saber_k_conv3x3s2(const float* in, int H, int W, int Cin, const float* w, const float* b, int Cout, float* out, void* stream) {
+    return kcheck(launch_conv3x3s2(in, H, W, Cin, w, b, Cout, out, (hipStream_t)stream));
+}
+extern "C" int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream) {
+    return kcheck(launch_dwconv7(in, H, W, C, w, b, out, (hipStream_t)stream));
+}
+extern "C" int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream) {
+    return kcheck(launch_conv4x4s4(in, H, W, w, b, out, (hipStream_t)stream));
+}
+extern "C" int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream) {
+    return kcheck(launch_resize_plane(in, n_planes, H, W, out, Ho, Wo, antialias, post, a, c, (hipStream_t)stream));
+}
+extern "C" int saber_k_axpy(const float* x, const float* y, const float* g, float alpha, int64_t rows, int C, float* out, void* stream) {
+    return kcheck(launch_axpy(x, y, g, alpha, rows, C, out, (hipStream_t)stream));
+}
+extern "C" int saber_k_add_to_bf16(const float* x, const float* y, int y_rows, uint16_t* out_bf16, float* out_f32, int64_t rows, int C, void* stream) {
+    return kcheck(launch_add_to_bf16(x, y, y_rows, out_bf16, out_f32, rows, C, (hipStream_t)stream));
+}
+// batched GEMM with explicit strides (scores / values of the memory attention, one batch entry per tracked object)
+extern "C" int saber_k_gemm_batched(const uint16_t* A, int lda, int64_t strideA, const uint16_t* W, int ldw, int64_t strideW, const float* bias, float* out_f32,
+                                    int ldcf, int64_t strideCf, uint16_t* out_bf16, int ldcb, int64_t strideCb, int M, int N, int K, int batch, void* stream) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.strideA = strideA; p.W = W; p.ldw = ldw; p.strideW = strideW; p.bias = bias; p.Cf = out_f32; p.ldcf = ldcf; p.strideCf = strideCf;
+    p.Cb = out_bf16; p.ldcb = ldcb; p.strideCb = strideCb; p.M = M; p.N = N; p.K = K; p.batch = batch;
+    return kcheck(launch_gemm(p, (hipStream_t)stream));
+}
+extern "C" int saber_k_bf16_to_f32(const uint16_t* x, int64_t n, float* out, void* stream) { return kcheck(launch_bf16_to_f32(x, n, out, (hipStream_t)stream)); }

@@ -103,6 +103,7 @@ struct saber_engine {
     MaskStats* amg_stats = nullptr; int* amg_idx = nullptr; size_t amg_stats_cap = 0;
     int* order_dev = nullptr; size_t order_cap = 0;
 
+    int *rm_to_eng = nullptr, *eng_to_rm = nullptr;   // 64x64 grid: row-major (y * 64 + x) <-> engine token order (video path, on demand)
     int amg_last_syncs = 0;           // host synchronisations of the last saber_amg_generate call (saber_amg_last_syncs)
 
     // optional per-launch HIP-event profiling (saber_profile_begin / saber_profile_end)

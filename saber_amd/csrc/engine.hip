@@ -790,6 +790,52 @@ extern "C" int saber_get_features(saber_engine* e, int slot, float* image_embed,
     return SABER_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ video path access to a slot
+// The memory path replaces a frame's image embedding by its memory-conditioned version before the mask decoder runs
+// (upstream SAM2Base.track_step: pix_feat_with_mem -> _forward_sam_heads).  Tokens cross this boundary in row-major (y, x) order.
+static int ensure_rm_tables(saber_engine* e) {
+    if (e->rm_to_eng) return SABER_OK;
+    std::vector<int> a(4096), b(4096);
+    for (int y = 0; y < 64; ++y)
+        for (int x = 0; x < 64; ++x) { const int r = y * 64 + x, g = perm_index(y, x, 2); a[r] = g; b[g] = r; }
+    TRY(eng_alloc(e, &e->rm_to_eng, 4096));
+    TRY(eng_alloc(e, &e->eng_to_rm, 4096));
+    ENG_HIP(e, hipMemcpy(e->rm_to_eng, a.data(), 4096 * sizeof(int), hipMemcpyHostToDevice));
+    ENG_HIP(e, hipMemcpy(e->eng_to_rm, b.data(), 4096 * sizeof(int), hipMemcpyHostToDevice));
+    return SABER_OK;
+}
+extern "C" int saber_get_embed_tokens(saber_engine* e, int slot, float* out_tokens_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot] || !out_tokens_dev) return eng_fail(e, SABER_ERR_STATE, "get_embed_tokens: slot holds no encoded image; call saber_encode first");
+    ENG_DEVICE(e);
+    TRY(ensure_rm_tables(e));
+    hipStream_t s = (hipStream_t)stream;
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(e->emb + (size_t)slot * 4096 * 256, 4096, out_tokens_dev, 4096, e->rm_to_eng, 256, 1, s));
+    return SABER_OK;
+}
+extern "C" int saber_set_embed_tokens(saber_engine* e, int slot, const float* tokens_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (slot < 0 || slot >= e->max_images || !e->slot_valid[slot] || !tokens_dev) return eng_fail(e, SABER_ERR_STATE, "set_embed_tokens: slot holds no encoded image; call saber_encode first");
+    ENG_DEVICE(e);
+    TRY(ensure_rm_tables(e));
+    hipStream_t s = (hipStream_t)stream;
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(tokens_dev, 4096, e->emb + (size_t)slot * 4096 * 256, 4096, e->eng_to_rm, 256, 1, s));
+    e->slot_shared_valid[slot] = 0;        // image_embed + no_mask_embed of this slot must be rebuilt
+    return SABER_OK;
+}
+// the 8 tokens of the first n prompts of the LAST decode call after the two-way transformer ([obj, iou, mask0..3, point, pad] x 256 fp32):
+// the video path projects one mask token to the object pointer (upstream obj_ptr_proj(sam_output_token))
+extern "C" int saber_get_decoder_tokens(saber_engine* e, int n, float* out_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (n < 1 || n > e->max_prompts || !out_dev) return eng_fail(e, SABER_ERR_INVALID, "get_decoder_tokens: n must be 1..max_prompts");
+    ENG_DEVICE(e);
+    ENG_HIP(e, hipMemcpyAsync(out_dev, e->queries, sizeof(float) * (size_t)n * 8 * 256, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SABER_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ decoder
 static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
     if (e->slot_shared_valid[slot]) return SABER_OK;

@@ -131,3 +131,13 @@ const char* launch_label_plane(const uint32_t* bits, const int* order, int n, in
 const char* launch_pair_intersections(const uint32_t* bits, int n, int64_t words, int* inter, hipStream_t s);
 // gather token-major [tokens][C] (engine order, stage s grid) -> NCHW fp32 for inspection / parity tests
 const char* launch_unpermute_nchw(const float* tok, int C, int stage, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------ video_ops.hip (SAM2 memory path, channels-last fp32, row-major pixels)
+const char* launch_rope(const float* x, int64_t rows, int n_rot, int C, int side, float theta, float* out_f, bf16_t* out_bf, hipStream_t s);
+const char* launch_softmax_rows(const float* S, int64_t lds_, int64_t rows, int n, float scale, bf16_t* P, int64_t ldp, hipStream_t s);
+const char* launch_conv3x3s2(const float* in, int H, int W, int Cin, const float* w, const float* b, int Cout, float* out, hipStream_t s);
+const char* launch_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, hipStream_t s);
+const char* launch_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, hipStream_t s);
+const char* launch_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, hipStream_t s);
+const char* launch_axpy(const float* x, const float* y, const float* g, float alpha, int64_t rows, int C, float* out, hipStream_t s);
+const char* launch_bf16_to_f32(const bf16_t* x, int64_t n, float* out, hipStream_t s);

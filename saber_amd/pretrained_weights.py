@@ -35,3 +35,15 @@ def resolve_weights(sam2_cfg: str, checkpoint: str = None):
         return {"seed": int(os.environ.get("SABER_AMD_SEED", "0"))}
     raise FileNotFoundError(f"SAM2.1 checkpoint '{path}' not found (no network: nothing is downloaded). Place the file there, "
                             f"or set SABER_AMD_SEEDED_WEIGHTS=1 to run with deterministic synthetic weights.")
+
+
+def load_weights(sam2_cfg: str, checkpoint: str = None, video: bool = False):
+    """-> {upstream checkpoint key: fp32 numpy array} from the resolved source (checkpoint file, or the seeded tensors when
+    SABER_AMD_SEEDED_WEIGHTS=1); video=True adds the memory model of the video predictor (memory attention / encoder, object pointers)."""
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import load_checkpoint, seeded_weights
+    src = resolve_weights(sam2_cfg, checkpoint)
+    cfg = get_config(sam2_cfg)
+    if "checkpoint" in src:
+        return load_checkpoint(src["checkpoint"], cfg, video=video)
+    return seeded_weights(cfg, src["seed"], video=video)

@@ -82,3 +82,12 @@ def separate_masks(combined_mask: np.ndarray, min_mask_area: int = 100) -> np.nd
     remap[alive] = np.arange(1, int(alive.sum()) + 1, dtype=np.uint32)
     out[sl] = remap[lab]
     return out
+
+
+def resize_mask_nearest(mask: np.ndarray, shape) -> np.ndarray:
+    """skimage.transform.resize(mask, shape, order=0, anti_aliasing=False) of a bool mask as SAM2Adapter.segment_volume applies it when
+    the video resolution differs from the tomogram's (adapters/sam2/predictor.py:294-296): nearest source pixel of every output pixel centre."""
+    H, W = mask.shape
+    ys = np.clip(np.floor((np.arange(shape[0]) + 0.5) * H / shape[0]).astype(np.int64), 0, H - 1)
+    xs = np.clip(np.floor((np.arange(shape[1]) + 0.5) * W / shape[1]).astype(np.int64), 0, W - 1)
+    return mask[np.ix_(ys, xs)]

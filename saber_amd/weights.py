@@ -21,6 +21,68 @@ import numpy as np
 from .model_config import HieraConfig, DEC_DIM, DEC_MLP, DEC_DEPTH, NUM_MASK_TOKENS
 
 
+MEM_DIM = 64          # channels of a spatial memory / of an object-pointer token
+NUM_MASKMEM_CKPT = 7  # rows of maskmem_tpos_enc in the checkpoints (the reference keeps the first `num_maskmem`, default 2)
+
+
+def video_param_specs() -> "OrderedDict[str, Tuple[tuple, str, float]]":
+    """The tensors the video (memory) path adds to the image model, under their upstream checkpoint keys: memory attention,
+    memory encoder, object-pointer heads and the learned 'no memory / no object' embeddings (sam2.1 configs: 4 memory-attention
+    layers, d_model 256, memory dim 64, 2 fuser blocks).  Same for every trunk."""
+    P: "OrderedDict[str, Tuple[tuple, str, float]]" = OrderedDict()
+
+    def lin(prefix, out_f, in_f, gain=1.0):
+        P[prefix + ".weight"] = ((out_f, in_f), "w", gain)
+        P[prefix + ".bias"] = ((out_f,), "b", 1.0)
+
+    def ln(prefix, c):
+        P[prefix + ".weight"] = ((c,), "ln_w", 1.0)
+        P[prefix + ".bias"] = ((c,), "ln_b", 1.0)
+
+    for i in range(4):
+        L = f"memory_attention.layers.{i}."
+        for a, kv in (("self_attn", DEC_DIM), ("cross_attn_image", MEM_DIM)):
+            lin(L + a + ".q_proj", DEC_DIM, DEC_DIM)
+            lin(L + a + ".k_proj", DEC_DIM, kv)
+            lin(L + a + ".v_proj", DEC_DIM, kv)
+            lin(L + a + ".out_proj", DEC_DIM, DEC_DIM, 0.5)
+        lin(L + "linear1", DEC_MLP, DEC_DIM)
+        lin(L + "linear2", DEC_DIM, DEC_MLP, 0.5)
+        for n in ("norm1", "norm2", "norm3"):
+            ln(L + n, DEC_DIM)
+    ln("memory_attention.norm", DEC_DIM)
+    me = "memory_encoder."
+    chans = [1, 4, 16, 64, 256]
+    for j in range(4):
+        P[f"{me}mask_downsampler.encoder.{3 * j}.weight"] = ((chans[j + 1], chans[j], 3, 3), "w", 1.5)
+        P[f"{me}mask_downsampler.encoder.{3 * j}.bias"] = ((chans[j + 1],), "b", 1.0)
+        ln(f"{me}mask_downsampler.encoder.{3 * j + 1}", chans[j + 1])
+    P[me + "mask_downsampler.encoder.12.weight"] = ((DEC_DIM, DEC_DIM, 1, 1), "w", 1.0)
+    P[me + "mask_downsampler.encoder.12.bias"] = ((DEC_DIM,), "b", 1.0)
+    P[me + "pix_feat_proj.weight"] = ((DEC_DIM, DEC_DIM, 1, 1), "w", 1.0)
+    P[me + "pix_feat_proj.bias"] = ((DEC_DIM,), "b", 1.0)
+    for i in range(2):
+        f = f"{me}fuser.layers.{i}."
+        P[f + "dwconv.weight"] = ((DEC_DIM, 1, 7, 7), "w", 1.0)
+        P[f + "dwconv.bias"] = ((DEC_DIM,), "b", 1.0)
+        ln(f + "norm", DEC_DIM)
+        lin(f + "pwconv1", 4 * DEC_DIM, DEC_DIM)
+        lin(f + "pwconv2", DEC_DIM, 4 * DEC_DIM, 0.5)
+        P[f + "gamma"] = ((DEC_DIM,), "emb", 0.5)          # layer scale (1e-6 at initialisation upstream; trained values are O(0.1-1))
+    P[me + "out_proj.weight"] = ((MEM_DIM, DEC_DIM, 1, 1), "w", 1.0)
+    P[me + "out_proj.bias"] = ((MEM_DIM,), "b", 1.0)
+    P["maskmem_tpos_enc"] = ((NUM_MASKMEM_CKPT, 1, 1, MEM_DIM), "emb", 0.3)
+    P["no_mem_pos_enc"] = ((1, 1, DEC_DIM), "emb", 0.2)
+    P["no_obj_ptr"] = ((1, DEC_DIM), "emb", 0.5)
+    P["no_obj_embed_spatial"] = ((1, MEM_DIM), "emb", 0.3)
+    for l in range(3):
+        lin(f"obj_ptr_proj.layers.{l}", DEC_DIM, DEC_DIM, 1.4)
+    lin("obj_ptr_tpos_proj", MEM_DIM, DEC_DIM)
+    P["mask_downsample.weight"] = ((1, 1, 4, 4), "w", 2.0)
+    P["mask_downsample.bias"] = ((1,), "b", 1.0)
+    return P
+
+
 def param_specs(cfg: HieraConfig) -> "OrderedDict[str, Tuple[tuple, str, float]]":
     """name -> (shape, kind, gain).  kind in {w, b, ln_w, ln_b, emb, pe}."""
     P: "OrderedDict[str, Tuple[tuple, str, float]]" = OrderedDict()
@@ -140,12 +202,15 @@ def _gen(name: str, shape, kind: str, gain: float, seed: int) -> np.ndarray:
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
-def seeded_weights(cfg: HieraConfig, seed: int = 0) -> Dict[str, np.ndarray]:
-    """Deterministic fp32 weights for every tensor of the image model."""
-    return OrderedDict((n, _gen(n, s, k, g, seed)) for n, (s, k, g) in param_specs(cfg).items())
+def seeded_weights(cfg: HieraConfig, seed: int = 0, video: bool = False) -> Dict[str, np.ndarray]:
+    """Deterministic fp32 weights for every tensor of the image model (video=True: plus the memory path of the video predictor)."""
+    specs = param_specs(cfg)
+    if video:
+        specs = OrderedDict(list(specs.items()) + list(video_param_specs().items()))
+    return OrderedDict((n, _gen(n, s, k, g, seed)) for n, (s, k, g) in specs.items())
 
 
-def load_checkpoint(path: str, cfg: HieraConfig) -> Dict[str, np.ndarray]:
+def load_checkpoint(path: str, cfg: HieraConfig, video: bool = False) -> Dict[str, np.ndarray]:
     """Read an upstream ``sam2.1_hiera_*.pt`` and keep the image-model tensors.
 
     Raises ValueError naming any tensor that is missing or mis-shaped, so a wrong
@@ -156,7 +221,10 @@ def load_checkpoint(path: str, cfg: HieraConfig) -> Dict[str, np.ndarray]:
     if isinstance(sd, dict) and "model" in sd:
         sd = sd["model"]
     out = OrderedDict()
-    for name, (shape, _, _) in param_specs(cfg).items():
+    specs = param_specs(cfg)
+    if video:
+        specs = OrderedDict(list(specs.items()) + list(video_param_specs().items()))
+    for name, (shape, _, _) in specs.items():
         if name not in sd:
             raise ValueError(f"checkpoint {path} lacks tensor '{name}'")
         t = sd[name].detach().to(torch.float32).cpu().numpy()

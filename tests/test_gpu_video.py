@@ -1,0 +1,187 @@
+"""GPU: the SAM2 video (memory) path, SURVEY.md 8f-1 - kernels against torch formulas, then the tracking loop (add_new_mask,
+propagate_in_video both ways, SAM2Adapter.segment_volume with its presence-score filter) against the CPU oracle
+(oracle/sam2_video_ref.py) on the reference's own synthetic recipe (saber/adapters/sam3/tests/test_tomogram_predictor.py:67-68,101-104:
+default_rng(42).uniform(-1, 1, (Z, 128, 128)) tomogram, centred disk seed of radius min(H, W) // 6)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ck(lib, st):
+    assert st == 0, lib.saber_k_last_error().decode()
+
+
+def bf_to_f(t):
+    return (t.to(torch.int32) << 16).view(torch.float32)
+
+
+def test_rope_and_softmax_kernels(gpu_lib):
+    from oracle import sam2_video_ref as V
+    g = torch.Generator().manual_seed(0)
+    rows, n_rot = 2 * 4096 + 12, 2 * 4096
+    x = torch.randn(rows, 256, generator=g)
+    cos, sin = V.rope_table(64, 64, 256)
+    ref = torch.cat([V.rope_rotate(x[:n_rot].view(2, 4096, 256), cos, sin).reshape(n_rot, 256), x[n_rot:]], 0)
+    out = torch.empty(rows, 256, device="cuda")
+    outb = torch.empty(rows, 256, dtype=torch.uint16, device="cuda")
+    ck(gpu_lib, gpu_lib.saber_k_rope(ptr(x.cuda()), rows, n_rot, 256, 64, 10000.0, ptr(out), ptr(outb), None))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 2e-4          # sincosf of angles up to 63 rad
+    assert (bf_to_f(outb.cpu()) - ref).abs().max().item() < 0.03
+    S = torch.randn(300, 1000, generator=g) * 4
+    P = torch.empty(300, 1024, dtype=torch.uint16, device="cuda")
+    ck(gpu_lib, gpu_lib.saber_k_softmax_rows(ptr(S.cuda()), 1000, 300, 1000, 0.0625, ptr(P), 1024, None))
+    torch.cuda.synchronize()
+    p = bf_to_f(P.cpu())
+    assert (p[:, :1000] - torch.softmax(S * 0.0625, -1)).abs().max().item() < 2e-5 + 2 ** -9 * torch.softmax(S * 0.0625, -1).max().item()
+    assert (p[:, 1000:] == 0).all()
+
+
+def test_conv_and_resize_kernels(gpu_lib):
+    g = torch.Generator().manual_seed(1)
+    for (H, Cin, Cout) in ((64, 1, 4), (32, 4, 16), (16, 64, 256)):
+        x = torch.randn(1, Cin, H, H, generator=g)
+        w, b = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3, torch.randn(Cout, generator=g)
+        ref = F.conv2d(x, w, b, stride=2, padding=1)[0].permute(1, 2, 0).reshape(-1, Cout)
+        out = torch.empty((H // 2) ** 2, Cout, device="cuda")
+        ck(gpu_lib, gpu_lib.saber_k_conv3x3s2(ptr(x[0].permute(1, 2, 0).contiguous().cuda()), H, H, Cin, ptr(w.cuda()), ptr(b.cuda()), Cout, ptr(out), None))
+        assert (out.cpu() - ref).abs().max().item() < 1e-4 * (1 + ref.abs().max().item())
+    x = torch.randn(1, 256, 64, 64, generator=g)
+    w, b = torch.randn(256, 1, 7, 7, generator=g) * 0.2, torch.randn(256, generator=g)
+    ref = F.conv2d(x, w, b, padding=3, groups=256)[0].permute(1, 2, 0).reshape(-1, 256)
+    out = torch.empty(4096, 256, device="cuda")
+    ck(gpu_lib, gpu_lib.saber_k_dwconv7(ptr(x[0].permute(1, 2, 0).contiguous().cuda()), 64, 64, 256, ptr(w.cuda()), ptr(b.cuda()), ptr(out), None))
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    m = (torch.rand(1, 1, 1024, 1024, generator=g) > 0.5).float()
+    w, b = torch.randn(1, 1, 4, 4, generator=g), torch.randn(1, generator=g)
+    out = torch.empty(256, 256, device="cuda")
+    ck(gpu_lib, gpu_lib.saber_k_conv4x4s4(ptr(m[0, 0].contiguous().cuda()), 1024, 1024, ptr(w.cuda()), ptr(b.cuda()), ptr(out), None))
+    assert (out.cpu() - F.conv2d(m, w, b, stride=4)[0, 0]).abs().max().item() < 1e-5
+    low = F.interpolate(torch.randn(1, 1, 32, 32, generator=g) * 5, size=(256, 256), mode="bicubic")
+    for (Ho, aa, post, a, c, fn) in ((1024, 0, 0, 0.0, 0.0, lambda v: v), (1024, 0, 1, 20.0, -10.0, lambda v: torch.sigmoid(v) * 20 - 10),
+                                     (600, 0, 3, 2.0, 1.0, lambda v: 2 * v + 1)):
+        out = torch.empty(Ho, Ho, device="cuda")
+        ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(low[0, 0].contiguous().cuda()), 1, 256, 256, ptr(out), Ho, Ho, aa, post, a, c, None))
+        ref = fn(F.interpolate(low, size=(Ho, Ho), mode="bilinear", align_corners=False))[0, 0]
+        assert (out.cpu() - ref).abs().max().item() < 2e-4, (Ho, post)
+    high = m * 20 - 10
+    out = torch.empty(256, 256, device="cuda")
+    ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(high[0, 0].contiguous().cuda()), 1, 1024, 1024, ptr(out), 256, 256, 1, 0, 0.0, 0.0, None))
+    ref = F.interpolate(high, size=(256, 256), mode="bilinear", align_corners=False, antialias=True)[0, 0]
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    small = (torch.rand(1, 1, 128, 128, generator=g) > 0.6).float()
+    out = torch.empty(1024, 1024, device="cuda")
+    ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(small[0, 0].contiguous().cuda()), 1, 128, 128, ptr(out), 1024, 1024, 1, 4, 0.5, 0.0, None))
+    ref = (F.interpolate(small, size=(1024, 1024), mode="bilinear", align_corners=False, antialias=True) >= 0.5).float()[0, 0]
+    assert (out.cpu() != ref).float().mean().item() < 1e-4
+
+
+@pytest.fixture(scope="module")
+def video_case():
+    """tiny trunk, seeded weights with a positive object-score bias (the seeded head otherwise predicts 'absent' on every frame and all
+    tracked masks collapse to the NO_OBJ constant)"""
+    from saber_amd.engine import Engine
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    from saber_amd.adapters.sam2.video import VideoPredictor
+    cfg = get_config("tiny")
+    W = seeded_weights(cfg, 0, video=True)
+    W["sam_mask_decoder.pred_obj_score_head.layers.2.bias"] = W["sam_mask_decoder.pred_obj_score_head.layers.2.bias"] + np.float32(3.0)
+    from saber_amd.weights import param_specs
+    img_keys = set(param_specs(cfg).keys())
+    eng = Engine("tiny", device=0, weights={k: v for k, v in W.items() if k in img_keys}, max_images=1, max_prompts=8)
+    vp = VideoPredictor(eng, W, num_maskmem=2)
+    rng = np.random.default_rng(42)
+    Z = 7
+    tomo = rng.uniform(-1, 1, (Z, 128, 128)).astype(np.float32)
+    yy, xx = np.mgrid[:128, :128]
+    seed = ((yy - 64) ** 2 + (xx - 64) ** 2 < (128 // 6) ** 2).astype(np.float32)
+    yield cfg, W, vp, tomo, seed
+    eng.close()
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
+
+
+def test_tracking_loop_against_oracle(video_case):
+    """frame by frame: low-res mask logits, object scores and object pointers of the tracked frames, both directions"""
+    from oracle import sam2_video_ref as V
+    from saber_amd.adapters.sam2.video import load_tomogram_frames
+    cfg, W, vp, tomo, seed = video_case
+    start = 3
+    frames = load_tomogram_frames(tomo)
+    ref_frames = V.load_tomogram_frames(tomo)
+    assert np.abs(frames - ref_frames[:, 0].numpy()).max() < 1e-5
+    P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.init_state(ref_frames)
+    P.add_new_mask(start, 1, seed)
+    ref_out = {}
+    for rev in (False, True):
+        for t, ids, logits in P.propagate_in_video(start, None, reverse=rev):
+            ref_out[(t, rev)] = logits.clone()
+    vp.init_state(frames)
+    vp.add_new_mask(start, 1, seed)
+    got_out = {}
+    for rev in (False, True):
+        for t, ids, logits in vp.propagate_in_video(start, None, reverse=rev):
+            got_out[(t, rev)] = logits.cpu()
+    torch.cuda.synchronize()
+    assert set(ref_out) == set(got_out)
+    # conditioning frame: the mask itself (+-10 logits through the antialiased down- and the bilinear up-sampling)
+    e0 = (got_out[(start, False)] - ref_out[(start, False)]).abs().max().item()
+    print("conditioning frame max abs diff", e0)
+    assert e0 < 1e-3
+    worst = 0.0
+    for t in range(tomo.shape[0]):
+        if t == start:
+            continue
+        r, g = P.out[1]["non_cond"][t], vp.out[1]["non_cond"][t]
+        e_low = _rel(g["pred_masks"].cpu(), r["pred_masks"][0, 0])
+        e_ptr = _rel(torch.from_numpy(g["obj_ptr"]), r["obj_ptr"])
+        e_obj = abs(g["obj"] - float(r["object_score_logits"]))
+        iou = ((got_out[(t, t < start)] > 0) & (ref_out[(t, t < start)] > 0)).sum().item() / max(1, ((got_out[(t, t < start)] > 0) | (ref_out[(t, t < start)] > 0)).sum().item())
+        print(f"frame {t}: low-res rel-rms {e_low:.3e}, pointer rel-rms {e_ptr:.3e}, object score |diff| {e_obj:.3e} (ref {float(r['object_score_logits']):.2f}), mask IoU {iou:.4f}")
+        worst = max(worst, e_low)
+        assert e_low < 3e-2 and e_ptr < 3e-2 and e_obj < 0.15 and iou > 0.97
+    print("worst tracked-frame low-res rel-rms", worst)
+
+
+def test_segment_volume_adapter_against_oracle(video_case):
+    """SAM2Adapter.segment_volume end to end: (Z,H,W) uint16, the hook's frame bookkeeping, presence scores from the reference's fit"""
+    from oracle import sam2_video_ref as V
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.predictor import SAM2Adapter
+    cfg, W, vp, tomo, seed = video_case
+    P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.init_state(V.load_tomogram_frames(tomo))
+    ref_vol, ref_metrics, ref_scores = V.segment_volume_ref(P, 3, [seed], tomo.shape, min_presence_score=0.5)
+    ad = SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0")
+    ad._video_predictor = vp                                         # the fixture's weights (object-score bias) instead of the env-selected ones
+    ad.set_volume(tomo)
+    vol = ad.segment_volume(3, masks=[seed], min_presence_score=0.5)
+    assert vol.shape == tomo.shape and vol.dtype == np.uint16
+    print("frame scores (engine):", np.round(ad.frame_scores[:, 0], 3), "\\nframe scores (oracle):", np.round(ref_scores[:, 0], 3))
+    assert np.abs(ad.frame_scores - ref_scores).max() < 0.15
+    assert set(ad.frame_metrics) == set(ref_metrics)
+    ps_e = np.array([ad.frame_metrics[z][1]["presence_score"] for z in range(tomo.shape[0])])
+    ps_r = np.array([ref_metrics[z][1]["presence_score"] for z in range(tomo.shape[0])])
+    print("presence scores:", np.round(ps_e, 3), np.round(ps_r, 3))
+    inter = ((vol > 0) & (ref_vol > 0)).sum()
+    uni = ((vol > 0) | (ref_vol > 0)).sum()
+    print(f"volume IoU {inter / max(1, uni):.4f}; voxels {int((vol > 0).sum())} vs {int((ref_vol > 0).sum())}")
+    assert (vol[3] == ref_vol[3]).mean() > 0.999                     # the seeded frame
+    assert inter / max(1, uni) > 0.95
+    with pytest.raises(RuntimeError, match="set_volume"):
+        SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0").segment_volume(0, [], (3, 8, 8))
