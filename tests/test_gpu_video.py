@@ -21,6 +21,15 @@ def ck(lib, st):
     assert st == 0, lib.saber_k_last_error().decode()
 
 
+_ALIVE = []
+
+
+def dev(t):
+    """device copy that outlives the asynchronous launch reading it (a temporary's block is recycled by the caching allocator at once)"""
+    _ALIVE.append(t.contiguous().cuda())
+    return _ALIVE[-1]
+
+
 def bf_to_f(t):
     return (t.to(torch.int32) << 16).view(torch.float32)
 
@@ -34,13 +43,13 @@ def test_rope_and_softmax_kernels(gpu_lib):
     ref = torch.cat([V.rope_rotate(x[:n_rot].view(2, 4096, 256), cos, sin).reshape(n_rot, 256), x[n_rot:]], 0)
     out = torch.empty(rows, 256, device="cuda")
     outb = torch.empty(rows, 256, dtype=torch.uint16, device="cuda")
-    ck(gpu_lib, gpu_lib.saber_k_rope(ptr(x.cuda()), rows, n_rot, 256, 64, 10000.0, ptr(out), ptr(outb), None))
+    ck(gpu_lib, gpu_lib.saber_k_rope(ptr(dev(x)), rows, n_rot, 256, 64, 10000.0, ptr(out), ptr(outb), None))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max().item() < 2e-4          # sincosf of angles up to 63 rad
     assert (bf_to_f(outb.cpu()) - ref).abs().max().item() < 0.03
     S = torch.randn(300, 1000, generator=g) * 4
     P = torch.empty(300, 1024, dtype=torch.uint16, device="cuda")
-    ck(gpu_lib, gpu_lib.saber_k_softmax_rows(ptr(S.cuda()), 1000, 300, 1000, 0.0625, ptr(P), 1024, None))
+    ck(gpu_lib, gpu_lib.saber_k_softmax_rows(ptr(dev(S)), 1000, 300, 1000, 0.0625, ptr(P), 1024, None))
     torch.cuda.synchronize()
     p = bf_to_f(P.cpu())
     assert (p[:, :1000] - torch.softmax(S * 0.0625, -1)).abs().max().item() < 2e-5 + 2 ** -9 * torch.softmax(S * 0.0625, -1).max().item()
@@ -54,34 +63,34 @@ def test_conv_and_resize_kernels(gpu_lib):
         w, b = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3, torch.randn(Cout, generator=g)
         ref = F.conv2d(x, w, b, stride=2, padding=1)[0].permute(1, 2, 0).reshape(-1, Cout)
         out = torch.empty((H // 2) ** 2, Cout, device="cuda")
-        ck(gpu_lib, gpu_lib.saber_k_conv3x3s2(ptr(x[0].permute(1, 2, 0).contiguous().cuda()), H, H, Cin, ptr(w.cuda()), ptr(b.cuda()), Cout, ptr(out), None))
+        ck(gpu_lib, gpu_lib.saber_k_conv3x3s2(ptr(dev(x[0].permute(1, 2, 0))), H, H, Cin, ptr(dev(w)), ptr(dev(b)), Cout, ptr(out), None))
         assert (out.cpu() - ref).abs().max().item() < 1e-4 * (1 + ref.abs().max().item())
     x = torch.randn(1, 256, 64, 64, generator=g)
     w, b = torch.randn(256, 1, 7, 7, generator=g) * 0.2, torch.randn(256, generator=g)
     ref = F.conv2d(x, w, b, padding=3, groups=256)[0].permute(1, 2, 0).reshape(-1, 256)
     out = torch.empty(4096, 256, device="cuda")
-    ck(gpu_lib, gpu_lib.saber_k_dwconv7(ptr(x[0].permute(1, 2, 0).contiguous().cuda()), 64, 64, 256, ptr(w.cuda()), ptr(b.cuda()), ptr(out), None))
+    ck(gpu_lib, gpu_lib.saber_k_dwconv7(ptr(dev(x[0].permute(1, 2, 0))), 64, 64, 256, ptr(dev(w)), ptr(dev(b)), ptr(out), None))
     assert (out.cpu() - ref).abs().max().item() < 1e-4
     m = (torch.rand(1, 1, 1024, 1024, generator=g) > 0.5).float()
     w, b = torch.randn(1, 1, 4, 4, generator=g), torch.randn(1, generator=g)
     out = torch.empty(256, 256, device="cuda")
-    ck(gpu_lib, gpu_lib.saber_k_conv4x4s4(ptr(m[0, 0].contiguous().cuda()), 1024, 1024, ptr(w.cuda()), ptr(b.cuda()), ptr(out), None))
+    ck(gpu_lib, gpu_lib.saber_k_conv4x4s4(ptr(dev(m[0, 0])), 1024, 1024, ptr(dev(w)), ptr(dev(b)), ptr(out), None))
     assert (out.cpu() - F.conv2d(m, w, b, stride=4)[0, 0]).abs().max().item() < 1e-5
     low = F.interpolate(torch.randn(1, 1, 32, 32, generator=g) * 5, size=(256, 256), mode="bicubic")
     for (Ho, aa, post, a, c, fn) in ((1024, 0, 0, 0.0, 0.0, lambda v: v), (1024, 0, 1, 20.0, -10.0, lambda v: torch.sigmoid(v) * 20 - 10),
                                      (600, 0, 3, 2.0, 1.0, lambda v: 2 * v + 1)):
         out = torch.empty(Ho, Ho, device="cuda")
-        ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(low[0, 0].contiguous().cuda()), 1, 256, 256, ptr(out), Ho, Ho, aa, post, a, c, None))
+        ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(dev(low[0, 0])), 1, 256, 256, ptr(out), Ho, Ho, aa, post, a, c, None))
         ref = fn(F.interpolate(low, size=(Ho, Ho), mode="bilinear", align_corners=False))[0, 0]
         assert (out.cpu() - ref).abs().max().item() < 2e-4, (Ho, post)
     high = m * 20 - 10
     out = torch.empty(256, 256, device="cuda")
-    ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(high[0, 0].contiguous().cuda()), 1, 1024, 1024, ptr(out), 256, 256, 1, 0, 0.0, 0.0, None))
+    ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(dev(high[0, 0])), 1, 1024, 1024, ptr(out), 256, 256, 1, 0, 0.0, 0.0, None))
     ref = F.interpolate(high, size=(256, 256), mode="bilinear", align_corners=False, antialias=True)[0, 0]
     assert (out.cpu() - ref).abs().max().item() < 1e-4
     small = (torch.rand(1, 1, 128, 128, generator=g) > 0.6).float()
     out = torch.empty(1024, 1024, device="cuda")
-    ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(small[0, 0].contiguous().cuda()), 1, 128, 128, ptr(out), 1024, 1024, 1, 4, 0.5, 0.0, None))
+    ck(gpu_lib, gpu_lib.saber_k_resize_plane(ptr(dev(small[0, 0])), 1, 128, 128, ptr(out), 1024, 1024, 1, 4, 0.5, 0.0, None))
     ref = (F.interpolate(small, size=(1024, 1024), mode="bilinear", align_corners=False, antialias=True) >= 0.5).float()[0, 0]
     assert (out.cpu() != ref).float().mean().item() < 1e-4
 
@@ -154,7 +163,7 @@ def test_tracking_loop_against_oracle(video_case):
         iou = ((got_out[(t, t < start)] > 0) & (ref_out[(t, t < start)] > 0)).sum().item() / max(1, ((got_out[(t, t < start)] > 0) | (ref_out[(t, t < start)] > 0)).sum().item())
         print(f"frame {t}: low-res rel-rms {e_low:.3e}, pointer rel-rms {e_ptr:.3e}, object score |diff| {e_obj:.3e} (ref {float(r['object_score_logits']):.2f}), mask IoU {iou:.4f}")
         worst = max(worst, e_low)
-        assert e_low < 3e-2 and e_ptr < 3e-2 and e_obj < 0.15 and iou > 0.97
+        assert e_low < 2.2e-2 and e_ptr < 1.5e-2 and e_obj < 5e-2 and iou > 0.995      # measured <= 1.1e-2 / 7.5e-3 / 2.3e-2 / >= 0.9985
     print("worst tracked-frame low-res rel-rms", worst)
 
 
@@ -173,7 +182,7 @@ def test_segment_volume_adapter_against_oracle(video_case):
     vol = ad.segment_volume(3, masks=[seed], min_presence_score=0.5)
     assert vol.shape == tomo.shape and vol.dtype == np.uint16
     print("frame scores (engine):", np.round(ad.frame_scores[:, 0], 3), "\\nframe scores (oracle):", np.round(ref_scores[:, 0], 3))
-    assert np.abs(ad.frame_scores - ref_scores).max() < 0.15
+    assert np.abs(ad.frame_scores - ref_scores).max() < 0.05                              # measured 2.3e-2
     assert set(ad.frame_metrics) == set(ref_metrics)
     ps_e = np.array([ad.frame_metrics[z][1]["presence_score"] for z in range(tomo.shape[0])])
     ps_r = np.array([ref_metrics[z][1]["presence_score"] for z in range(tomo.shape[0])])
@@ -182,6 +191,6 @@ def test_segment_volume_adapter_against_oracle(video_case):
     uni = ((vol > 0) | (ref_vol > 0)).sum()
     print(f"volume IoU {inter / max(1, uni):.4f}; voxels {int((vol > 0).sum())} vs {int((ref_vol > 0).sum())}")
     assert (vol[3] == ref_vol[3]).mean() > 0.999                     # the seeded frame
-    assert inter / max(1, uni) > 0.95
+    assert inter / max(1, uni) > 0.997 and np.abs(ps_e - ps_r).max() < 0.02                # measured 0.9988 / 7e-3
     with pytest.raises(RuntimeError, match="set_volume"):
         SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0").segment_volume(0, [], (3, 8, 8))
