@@ -182,5 +182,4 @@ class SAM2Adapter(BaseAdapter):
     def reset_state(self, inference_state=None) -> None:
         state = inference_state or self.inference_state
         if state is not None:
-            state.reset_state()
-        self.frame_metrics = {}
+            state.reset_state()          # like upstream's reset_state: prompts and tracking results go, the loaded frames stay

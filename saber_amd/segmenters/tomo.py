@@ -1,6 +1,6 @@
 """tomoSegmenter (reference: saber/segmenters/tomo.py:14-139).  segment_slab's 2-D path (z-smoothing -> normalise ->
-slab projection -> segment_image) is kept; segment_vol continues into SAM2 video propagation, which is a 'next' row
- and raises through the adapter.  The z Gaussian (filters/gaussian.py:17-74, sigma 5, conv1d) is host
+slab projection -> segment_image) feeds segment_vol, which continues into SAM2 video propagation on the engine
+(SAM2Adapter.segment_volume, saber_amd/adapters/sam2/video.py).  The z Gaussian (filters/gaussian.py:17-74, sigma 5, conv1d) is host
 glue outside the per-slice loop and is evaluated with scipy's separable filter of the same kernel."""
 from typing import Optional
 
@@ -54,9 +54,10 @@ class tomoSegmenter(saber3D):
         self.segment_slab(vol, thickness, zSlice, display=False, text=text, target_class=target_class)
         if len(self.masks) == 0:
             return None
-        if not self._vol_loaded:
-            self.video_predictor.set_volume(self.vol)   # raises NotImplementedError: propagation is a next row
-            self._vol_loaded = True
+        # the reference loads the volume once per segmenter (`_vol_loaded` is never reset, tomo.py:117-119), so a pooled segmenter
+        # propagates its FIRST tomogram's frames for every later one (known reference bug): here every call loads its own
+        self.video_predictor.set_volume(self.vol)
+        self._vol_loaded = True
         nx = self.vol.shape[0]
         ny, nz = self.masks[0]["segmentation"].shape
         self.ann_frame_idx = zSlice if zSlice is not None else nx // 2

@@ -87,3 +87,23 @@ def test_slice_loop_with_device_smoothing(segmenter):
     assert sm.dtype == np.uint8 and sm.shape == vol.shape
     ref, near = saber_ref.fast_3d_gaussian_smoothing(labels, 0.05, band=1e-5)
     assert not ((sm != ref) & ~near).any()
+
+
+def test_tomo_segmenter_segment_vol_runs_the_video_path():
+    """tomoSegmenter.segment_vol (what `saber segment tomograms` runs, reference tomo.py:81-139): slab AMG on the engine, then seed ->
+    bidirectional SAM2 video propagation -> presence filter on the engine's memory path; contract: (Z,H,W) uint16, seeded frame kept"""
+    import os
+    os.environ["SABER_AMD_SEEDED_WEIGHTS"] = "1"
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.segmenters.tomo import tomoSegmenter
+    amg = cfgAMG(npoints=8, crop_n_layers=0, pred_iou_thresh=0.2, stability_score_thresh=0.3, sam2_cfg="small")
+    seg = tomoSegmenter(deviceID=0, cfg=SAM2AdapterConfig(cfg="tiny", amg_cfg=amg, min_mask_area=50), min_mask_area=50)
+    vol = _volume(Z=5, S=384)
+    seg.filter_threshold = -1.0                       # keep every frame: the untrained object-score head says nothing about presence
+    out = seg.segment_vol(vol, thickness=2, zSlice=2)
+    assert out is not None and out.shape == vol.shape and out.dtype == np.uint16
+    assert out[2].any(), "the seeded frame lost its masks"
+    assert set(seg.adapter.frame_metrics) == set(range(5))
+    out2 = seg.segment_vol(vol[::-1].copy(), thickness=2, zSlice=2)      # a second volume through the same segmenter loads its own frames
+    assert out2.shape == vol.shape
