@@ -199,7 +199,10 @@ def main():
         """`count` slices starting at index `first`; with several workers they are dealt round-robin to the engine handles, each driven
         from its own thread on its own stream (the C-ABI calls release the GIL)."""
         if len(engines) == 1:
-            return sum(step(first + i, planes) for i in range(count))
+            with torch.cuda.stream(streams[0]):     # (hipGraph capture needs a non-default stream)
+                tot = sum(step(first + i, planes) for i in range(count))
+                streams[0].synchronize()
+            return tot
         import threading
         totals = [0] * len(engines)
 
@@ -282,6 +285,20 @@ def main():
         torch.cuda.synchronize()
         out["stitch"] = {"what": "3-D connected components of the gathered label planes on rank 0's GPU (saber_separate_masks)",
                          "slices": int(vol.shape[0]), "ms": (time.perf_counter() - t0) * 1e3, "labels": n_lab}
+    if rank == 0 and world == 1:
+        # hipGraph replay A/B on the same handle (the headline above runs with replay on unless SABER_AMD_GRAPHS=0)
+        ab = {}
+        for name, on in (("eager", False), ("graphs", True)):
+            eng.set_graphs(on)
+            run_steps(0, 2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(0, 6)
+            torch.cuda.synchronize()
+            ab[f"ms_per_slice_{name}"] = (time.perf_counter() - t0) / 6 * 1e3
+        cap, rep = eng.graph_stats()
+        out["hipgraph"] = dict(ab, what="same step, 6 slices each, launch sequences issued eagerly vs replayed from hipGraphs (encoder pass + each decoder batch)",
+                               sequences_captured=cap, replays_so_far=rep, headline_uses_graphs=os.environ.get("SABER_AMD_GRAPHS", "1") != "0")
     if rank == 0 and world == 1 and not a.no_profile:
         eng.profile_begin()
         step(0)

@@ -133,6 +133,13 @@ int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const i
 int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* params,
                        uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta_host, int* out_count, void* stream);
 
+/* hipGraph replay of saber_amg_generate's launch sequences (BASELINE configs[4]: "hipGraph-captured per-slice encode+decode"): the batched
+ * encoder pass and each decoder batch are run eagerly the first time their shapes are seen on a handle, captured the second time and
+ * replayed from then on (needs a non-default stream; on by default, SABER_AMD_GRAPHS=0 or saber_engine_set_graphs(e, 0) turns it off).
+ * saber_engine_graph_stats: sequences captured / replayed so far on this handle. */
+int saber_engine_set_graphs(saber_engine* e, int enable);
+int saber_engine_graph_stats(const saber_engine* e, int* captures, int* replays);
+
 /* Host synchronisations (hipStreamSynchronize) the last saber_amg_generate call on this handle needed: 2 per group of crops decoded
  * together + 1 at the end (7 for cfgAMG's default 1 + 4 + 16 crop pyramid), more only when a scratch buffer had to grow. */
 int saber_amg_last_syncs(const saber_engine* e);

@@ -159,12 +159,28 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     std::vector<int> h_idx;
     std::vector<float> h_pts, h_pts2;
 
+    // engine-owned copy of the image: the encoder pass below is replayed from a hipGraph whose launches hold its address
+    {
+        const size_t need = (size_t)H * W * channels;
+        if (e->amg_img_elems < need) { TRY(eng_regrow(e, &e->amg_img, need, s)); e->amg_img_elems = need; }
+        ENG_HIP(e, hipMemcpyAsync(e->amg_img, img_dev, need * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    auto key_of = [](std::initializer_list<long long> v) { std::string k; for (long long x : v) { k += std::to_string(x); k += ','; } return k; };
     const int nc = (int)crops.size();
     for (int c0 = 0; c0 < nc; c0 += e->max_images) {
         const int ncb = std::min(e->max_images, nc - c0);
         std::vector<int> cb(4 * ncb);
         for (int i = 0; i < ncb; ++i) for (int k = 0; k < 4; ++k) cb[4 * i + k] = crops[c0 + i][k];
-        TRY(eng_encode(e, img_dev, H, W, channels, cb.data(), ncb, 0, s));
+        {
+            const float* img = e->amg_img;
+            // the crop boxes go through the pinned buffer the (possibly replayed) H2D copy of eng_encode reads at execution time
+            if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 4 * 64));
+            std::copy(cb.begin(), cb.begin() + 4 * ncb, e->crops_pin);
+            TRY(eng_graphed(e, "enc," + key_of({(long long)(uintptr_t)img, H, W, channels, ncb, c0, prm->crop_n_layers, (long long)(prm->crop_overlap_ratio * 1e6)}), s,
+                            [&]() { return eng_encode(e, img, H, W, channels, e->crops_pin, ncb, 0, s); }));
+            // host-side bookkeeping of eng_encode, which a replay does not execute
+            for (int i = 0; i < ncb; ++i) { e->slot_valid[i] = 1; e->slot_shared_valid[i] = 0; }
+        }
         for (int ci = 0, G = 1; ci < ncb; ci += G) {
             const int layer = layers[c0 + ci];
             for (G = 1; ci + G < ncb && layers[c0 + ci + G] == layer; ++G) {}
@@ -186,7 +202,9 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                     }
             }
             ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * G * np, hipMemcpyHostToDevice, s));
-            TRY(eng_decode(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, 0.f, e->amg_low1, e->amg_iou1, nullptr, s));
+            TRY(eng_graphed(e, "dec1," + key_of({ci, np, (long long)(uintptr_t)e->amg_pts, G * np, prm->multimask_output, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_iou1}), s,
+                            [&]() { return eng_decode(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, 0.f, e->amg_low1, e->amg_iou1, nullptr, s); }));
+            for (int g = 0; g < G; ++g) e->slot_shared_valid[ci + g] = 1;      // (bookkeeping of the first-pass decode, for replays)
             const float* masks = e->amg_low1;
             const float* ious = e->amg_iou1;
             if (prm->use_m2m) {
@@ -195,7 +213,8 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                 for (size_t k = 0; k < (size_t)G * np; ++k)
                     for (int m = 0; m < M; ++m) { h_pts2[2 * (k * M + m)] = h_pts[2 * k]; h_pts2[2 * (k * M + m) + 1] = h_pts[2 * k + 1]; }
                 ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * G * nm, hipMemcpyHostToDevice, s));
-                TRY(eng_decode(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, 32.0f, e->amg_low2, e->amg_iou2, nullptr, s));
+                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)e->amg_pts2, G * nm, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_low2, (long long)(uintptr_t)e->amg_iou2}), s,
+                                [&]() { return eng_decode(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, 32.0f, e->amg_low2, e->amg_iou2, nullptr, s); }));
                 masks = e->amg_low2;
                 ious = e->amg_iou2;
             }

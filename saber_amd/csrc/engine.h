@@ -1,7 +1,9 @@
 // Engine state shared by engine.hip (encode / decode) and amg.hip (automatic mask generation).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -103,6 +105,14 @@ struct saber_engine {
     MaskStats* amg_stats = nullptr; int* amg_idx = nullptr; size_t amg_stats_cap = 0;
     int* order_dev = nullptr; size_t order_cap = 0;
 
+    // hipGraph replay of the AMG driver's launch sequences (one batched encoder pass, 12 decoder batches per slice with the default
+    // pyramid): a sequence is run eagerly the first time its arguments are seen, captured the second time, replayed from then on
+    bool graphs_on = true;
+    std::map<std::string, hipGraphExec_t> graphs;
+    std::set<std::string> graph_seen, graph_bad;
+    int graph_replays = 0, graph_captures = 0;
+    float* amg_img = nullptr; size_t amg_img_elems = 0;     // engine-owned copy of the caller's image: a stable address for the captured launches
+    int* crops_pin = nullptr;                                // pinned host copy of the crop boxes of an encoder pass (read by the captured H2D copy)
     int *rm_to_eng = nullptr, *eng_to_rm = nullptr;   // 64x64 grid: row-major (y * 64 + x) <-> engine token order (video path, on demand)
     int amg_last_syncs = 0;           // host synchronisations of the last saber_amg_generate call (saber_amg_last_syncs)
 
@@ -149,6 +159,8 @@ struct DeviceGuard {
         if (_m) return eng_fail((e), SABER_ERR_INVALID, _m);             \
     } while (0)
 
+// hipGraph replay of a fixed launch sequence (engine.hip)
+int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const std::function<int()>& body);
 // internal entry points used by amg.hip
 int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crops_host, int n, int slot0, hipStream_t s);
 // per_slot > 0: the prompts span consecutive slots, per_slot prompts each (crops of one AMG layer decoded in one batch);

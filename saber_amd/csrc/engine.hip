@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <utility>
 
 #include "common.h"
@@ -86,6 +87,50 @@ static const char* hiera_spec(saber_engine* e, const TrunkSpec& t) {
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI: lifecycle
+// ------------------------------------------------------------------------------------------------ hipGraph replay
+// body() issues a fixed launch sequence on stream s (no host synchronisation, no allocation).  `key` names the sequence AND every pointer /
+// size baked into its launches.  First sight: eager (lazy one-time setup inside launchers happens here); second: captured + launched;
+// afterwards: one hipGraphLaunch.  Anything that goes wrong while capturing marks the key bad and the sequence stays eager.
+int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const std::function<int()>& body) {
+    if (!e->graphs_on || e->prof_on || s == nullptr || e->graph_bad.count(key)) return body();
+    auto it = e->graphs.find(key);
+    if (it != e->graphs.end()) {
+        ENG_HIP(e, hipGraphLaunch(it->second, s));
+        ++e->graph_replays;
+        return SABER_OK;
+    }
+    if (!e->graph_seen.count(key)) { e->graph_seen.insert(key); return body(); }
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e->graph_bad.insert(key); return body(); }
+    const int r = body();
+    hipGraph_t g = nullptr;
+    const hipError_t st = hipStreamEndCapture(s, &g);
+    if (r != SABER_OK || st != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        e->graph_bad.insert(key);
+        return body();                              // nothing ran while capturing: run it now, eagerly
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t si = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (si != hipSuccess || !exec) { (void)hipGetLastError(); e->graph_bad.insert(key); return body(); }
+    e->graphs[key] = exec;
+    ++e->graph_captures;
+    ENG_HIP(e, hipGraphLaunch(exec, s));
+    return SABER_OK;
+}
+extern "C" int saber_engine_set_graphs(saber_engine* e, int enable) {
+    if (!e) return SABER_ERR_INVALID;
+    e->graphs_on = enable != 0;
+    return SABER_OK;
+}
+extern "C" int saber_engine_graph_stats(const saber_engine* e, int* captures, int* replays) {
+    if (!e) return SABER_ERR_INVALID;
+    if (captures) *captures = e->graph_captures;
+    if (replays) *replays = e->graph_replays;
+    return SABER_OK;
+}
+
 extern "C" int saber_engine_create(int device_id, const char* trunk, int max_images, int max_prompts, saber_engine** out) {
     if (!out) return eng_fail(nullptr, SABER_ERR_INVALID, "saber_engine_create: out is NULL");
     *out = nullptr;
@@ -106,6 +151,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     e->trunk = t;
     e->max_images = max_images;
     e->max_prompts = max_prompts;
+    if (const char* g = getenv("SABER_AMD_GRAPHS")) e->graphs_on = atoi(g) != 0;
     if (const char* m = hiera_spec(e, *spec)) { delete e; return eng_fail(nullptr, SABER_ERR_INVALID, m); }
     {
         const char* m = gemm_init_device();
@@ -124,6 +170,8 @@ extern "C" void saber_engine_destroy(saber_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (e->crops_pin) (void)hipHostFree(e->crops_pin);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
@@ -661,7 +709,10 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         const int* c = crops_host + 4 * i;
         if (c[0] < 0 || c[1] < 0 || c[2] > W || c[3] > H || c[2] <= c[0] || c[3] <= c[1]) return eng_fail(e, SABER_ERR_INVALID, "encode: crop box outside the image");
     }
-    ENG_HIP(e, hipMemcpyAsync(e->crops_dev, crops_host, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
+    // (through a pinned engine-owned buffer: when this pass is captured into a hipGraph the copy node reads its source at replay time)
+    if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 4 * 64));
+    if (crops_host != e->crops_pin) memcpy(e->crops_pin, crops_host, sizeof(int) * 4 * n);
+    ENG_HIP(e, hipMemcpyAsync(e->crops_dev, e->crops_pin, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_resize_normalize(img_dev, H, W, channels, e->crops_dev, n, e->pix, 1024, s));
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
     float* x = e->xa;

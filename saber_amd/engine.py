@@ -155,7 +155,17 @@ class Engine:
         bits = torch.empty((max_masks, H, W32), dtype=torch.int32, device=self.device)
         meta = (_lib.MaskMeta * max_masks)()
         cnt = C.c_int(0)
-        st = self.lib.saber_amg_generate(self.h, _ptr(img), H, W, ch, C.byref(params), _ptr(bits), max_masks, meta, C.byref(cnt), _stream())
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == 0:
+            # hipGraph capture is not possible on the legacy default stream: run on a stream of this handle, ordered after / before it
+            side = getattr(self, "_side_stream", None)
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            st = self.lib.saber_amg_generate(self.h, _ptr(img), H, W, ch, C.byref(params), _ptr(bits), max_masks, meta, C.byref(cnt), C.c_void_p(side.cuda_stream))
+            cur.wait_stream(side)
+        else:
+            st = self.lib.saber_amg_generate(self.h, _ptr(img), H, W, ch, C.byref(params), _ptr(bits), max_masks, meta, C.byref(cnt), _stream())
         if st == _lib.SABER_ERR_CAPACITY and cnt.value > max_masks:
             # the engine reports the count it needed: retry once with that capacity instead of failing the slice
             return self.amg_generate(img, params, max_masks=cnt.value)
@@ -205,6 +215,17 @@ class Engine:
         out = torch.empty((Z, H, W), dtype=torch.float32, device=mask.device)
         self._check(self.lib.saber_gaussian_smoothing_3d(self.h, _ptr(mask), Z, H, W, float(sigma), _ptr(out), _stream()))
         return out
+
+    def set_graphs(self, enable: bool):
+        """hipGraph replay of the AMG launch sequences (include/saber_amd.h: saber_engine_set_graphs)."""
+        self._check(self.lib.saber_engine_set_graphs(self.h, int(bool(enable))))
+
+    def graph_stats(self):
+        """(sequences captured, sequences replayed) on this handle."""
+        import ctypes as C
+        c, r = C.c_int(0), C.c_int(0)
+        self._check(self.lib.saber_engine_graph_stats(self.h, C.byref(c), C.byref(r)))
+        return c.value, r.value
 
     def profile_begin(self):
         self._check(self.lib.saber_profile_begin(self.h))

@@ -1,0 +1,51 @@
+"""hipGraph replay of the AMG launch sequences (BASELINE configs[4]): replayed results are bit-identical to the eager
+ones, the sequences really are captured and replayed, and switching to an image of another size or to other AMG parameters falls back to
+eager for the first sight of the new shapes instead of replaying a stale graph."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(eng, img, params):
+    bits, meta = eng.amg_generate(img, params, max_masks=8192)
+    torch.cuda.synchronize()
+    return bits.cpu().numpy().copy(), [(m.predicted_iou, m.stability_score, m.area, tuple(m.bbox_xywh), tuple(m.point_xy), tuple(m.crop_box_xywh)) for m in meta]
+
+
+def test_graph_replay_is_bit_identical_to_eager():
+    from oracle import saber_ref
+    from saber_amd.engine import Engine, make_amg_params
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    cfg = get_config("tiny")
+    w = seeded_weights(cfg, 0)
+    eng = Engine("tiny", weights=w, max_images=5, max_prompts=256)
+    ref = Engine("tiny", weights=w, max_images=5, max_prompts=256)
+    ref.set_graphs(False)
+    params = make_amg_params(dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.0, stability_score_thresh=0.0, box_nms_thresh=1.0, crop_nms_thresh=1.0))
+    imgs = [eng.prepare(torch.from_numpy(saber_ref.synthetic_slice(seed=s, size=512)).cuda()) for s in (1, 2, 3)]
+    # slice 0: eager (first sight), slice 1: captured and launched, slice 2 and 3: replayed
+    for k, i in enumerate((0, 1, 2, 0)):
+        b, m = _run(eng, imgs[i], params)
+        b0, m0 = _run(ref, imgs[i], params)
+        assert len(m) > 0 and m == m0, f"call {k}"
+        assert np.array_equal(b, b0), f"call {k}"
+        cap, rep = eng.graph_stats()
+        if k == 0:
+            assert (cap, rep) == (0, 0)
+        if k == 1:
+            assert cap > 0 and rep == 0
+        if k >= 2:
+            assert rep > 0
+    assert ref.graph_stats() == (0, 0)
+    ncap = eng.graph_stats()[0]
+    # other parameters (fewer grid points) and another image size: new sequences, first eager then captured; the old graphs stay valid
+    p2 = make_amg_params(dict(npoints=4, crop_n_layers=0, pred_iou_thresh=0.0, stability_score_thresh=0.0, box_nms_thresh=1.0))
+    small = eng.prepare(torch.from_numpy(saber_ref.synthetic_slice(seed=4, size=256)).cuda())
+    for img, p in ((imgs[0], p2), (small, params), (imgs[0], p2), (small, params), (imgs[1], params)):
+        b, m = _run(eng, img, p)
+        b0, m0 = _run(ref, img, p)
+        assert m == m0 and np.array_equal(b, b0)
+    assert eng.graph_stats()[0] > ncap
