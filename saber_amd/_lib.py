@@ -117,6 +117,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SaberAmdError(f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
                             f"(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # torch first: its wheel bundles the HIP runtime this process must share with the engine (device pointers and streams cross the
+    # C-ABI).  Loading libsaber_amd.so before torch would bind it to /opt/rocm's copy and leave two runtimes in one process.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
