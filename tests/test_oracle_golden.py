@@ -181,3 +181,68 @@ def test_prepare_rgb_restatement_matches_reference_fixture():
     from oracle import saber_ref
     out = saber_ref.prepare(g["rgb_in"], to_rgb=False)
     assert out.shape == g["rgb_in"].shape and np.array_equal(out.astype(np.float32), g["rgb_out"])
+
+
+# ------------------------------------------------------------------------------------------ classifier filter glue
+def _cls_golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "saber_classifier_glue.npz"))
+
+
+def test_classifier_crops_and_preprocess_match_reference():
+    import torch
+    from oracle import classifier_ref as cr
+    G = _cls_golden()
+    ti, tm = torch.from_numpy(G["image"]), torch.from_numpy(G["masks"])
+    ic, mc = cr.crop_and_resize_adaptive(ti[None], tm[1])
+    assert np.array_equal(ic.numpy(), G["crop1_image"]) and np.array_equal(mc.numpy(), G["crop1_mask"])
+    ci, cm = cr.apply_crops(ti, tm)
+    assert np.array_equal(ci.numpy()[7], G["crops_invalid_image"]) and np.array_equal((cm.numpy() > 0).sum(axis=(1, 2)), G["crops_mask_area"])
+    batch, valid = cr.preprocess(ci, cm, 250)
+    assert valid == G["valid"].tolist() and np.array_equal(batch.numpy(), G["batch"])
+    mf = cr.mask_features(torch.from_numpy(G["feats"]), batch[:, 1:2])
+    assert np.array_equal(mf.numpy(), G["masked_feats"])
+
+
+def test_classifier_resolution_matches_reference():
+    from oracle import classifier_ref as cr
+    G = _cls_golden()
+    dicts = [{"segmentation": m.astype(bool), "area": int(m.sum())} for m in G["masks"][:6]]
+    inst = cr.convert_predictions_to_masks(G["pred"], list(dicts), 1, 32)
+    assert len(inst) == int(G["inst_n"])
+    assert np.array_equal(np.stack([m["segmentation"] for m in inst]).astype(np.uint8), G["inst_seg"])
+    assert [m["area"] for m in inst] == G["inst_area"].tolist() and [m["bbox"] for m in inst] == G["inst_bbox"].tolist()
+    assert np.allclose([m["predicted_iou"] for m in inst], G["inst_conf"], rtol=0, atol=1e-7)
+    sem = cr.convert_predictions_to_masks(G["pred"], list(dicts), 0, 32)
+    assert np.array_equal(np.stack([np.asarray(m["segmentation"]) for m in sem]).astype(np.uint8), G["sem_seg"])
+    assert [m["area"] for m in sem] == G["sem_area"].tolist() and [m["label"] for m in sem] == G["sem_label"].tolist()
+
+
+def test_classifier_head_restatement_equals_torch_modules():
+    """The functional head of the oracle against torch.nn modules assembled in the layer order of the reference's source
+    (saber/classifier/models/SAM2.py:58-92) and loaded through load_state_dict with the reference's parameter names."""
+    import torch
+    import torch.nn as nn
+    from oracle import classifier_ref as cr
+
+    class Head(nn.Module):
+        def __init__(self, nc, h=256):
+            super().__init__()
+            d = [h, h // 2]
+            self.projection = nn.Sequential(nn.Conv2d(512, d[0], 1), nn.BatchNorm2d(d[0]), nn.PReLU(), nn.Dropout2d(0.05),
+                                            nn.Conv2d(d[0], d[0], 3, padding=1), nn.BatchNorm2d(d[0]), nn.PReLU(), nn.MaxPool2d(2, 2), nn.Dropout2d(0.1),
+                                            nn.Conv2d(d[0], d[1], 3, padding=1), nn.BatchNorm2d(d[1]), nn.PReLU(), nn.MaxPool2d(2, 2), nn.Dropout2d(0.2))
+            self.classifier = nn.Sequential(nn.Linear(d[1], 64), nn.LayerNorm(64), nn.PReLU(), nn.Dropout(0.1), nn.Linear(64, nc))
+
+        def forward(self, f):
+            f = self.projection(f)
+            return self.classifier(nn.functional.adaptive_avg_pool2d(f, (1, 1)).view(f.size(0), -1))
+
+    W = cr.seeded_head(3, 0)
+    m = Head(3).eval()
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys)
+    x = torch.from_numpy(np.random.default_rng(0).normal(0, 1, (2, 512, 64, 64)).astype(np.float32))
+    with torch.no_grad():
+        a = m(x)
+        b = cr.head({k: torch.from_numpy(v) for k, v in W.items()}, x)
+    assert torch.allclose(a, b, rtol=0, atol=1e-5)
