@@ -21,6 +21,9 @@
  *       <- the paint loop of propagationSegmenter.slice_by_slice      saber/segmenters/propagation.py:185-186
  *   saber_separate_masks
  *       <- separate_masks(vol_masks, min_mask_area)                   saber/segmenters/utils.py:88-131
+ *   saber_classifier_*
+ *       <- Predictor(model_config, model_weights).predict / SAM2Classifier.forward
+ *                                                                     saber/classifier/models/predictor.py:117-175, SAM2.py:118-197
  *   saber_smooth_labels / saber_gaussian_smoothing_3d
  *       <- fast_3d_gaussian_smoothing(volume, scale, deviceID)        saber/filters/masks.py:230-287
  *          gaussian_smoothing_3d(volume, sigma, device)               saber/filters/gaussian.py:76-138
@@ -173,6 +176,32 @@ int saber_smooth_labels(saber_engine* e, const void* labels_dev, int elem_bytes,
 /* The separable filter itself on one 0/1 mask with a given sigma (saber/filters/gaussian.py:76-138): mask_dev (Z,H,W) uint8,
  * out_dev (Z,H,W) float32. */
 int saber_gaussian_smoothing_3d(saber_engine* e, const uint8_t* mask_dev, int Z, int H, int W, double sigma, float* out_dev, void* stream);
+
+/* ---- domain-expert classifier filter on the engine's image embeddings ----
+ * Replaces saber.classifier.models.predictor.Predictor (saber/classifier/models/predictor.py:9-60 construction, :117-175 predict) with the
+ * SAM2Classifier model (saber/classifier/models/SAM2.py:21-197) behind it; hook: saber2D._apply_classifier -> filters.apply_classifier
+ * (saber/segmenters/base.py:159-176, saber/filters/masks.py:8-21).
+ * A classifier is bound to a finalized engine handle (its Hiera encoder is the classifier's frozen backbone) and is used from the same
+ * thread as that handle.  Weights: the state_dict entries of SAM2Classifier under their own names ("projection.0.weight", ...,
+ * "projection.1.running_var", "projection.2.weight", ..., "classifier.4.bias"; num_batches_tracked is not needed), fp32 host arrays.
+ * Eval-mode BatchNorm is folded into the convolutions at finalize. */
+typedef struct saber_classifier saber_classifier;
+int saber_classifier_create(saber_engine* e, int num_classes, saber_classifier** out);
+void saber_classifier_destroy(saber_classifier* c);
+int saber_classifier_set_weight(saber_classifier* c, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int saber_classifier_finalize(saber_classifier* c);
+/* Predictor.predict: image_dev (H,W) float32 (the grey image handed to apply_classifier), masks_dev (n,H,W) uint8 candidate masks.
+ * Per mask: whole-image z-score (monai NormalizeIntensity), crop_and_resize_adaptive (margin 1.5, 320x320, bilinear image / nearest
+ * mask), masks whose resized crop holds fewer than min_area pixels are skipped (their row of probs stays 0, predictor.py:139-141,170-173),
+ * SAM2 image embedding of the crop, ROI/RONI features, head, softmax.  probs_host: (n, num_classes) float32 HOST memory.
+ * Synchronises the stream (bounding boxes, areas and the probabilities come back to the host). */
+int saber_classifier_predict(saber_classifier* c, const float* image_dev, int H, int W, const uint8_t* masks_dev, int n, int min_area,
+                             float* probs_host, void* stream);
+/* SAM2Classifier.forward after the backbone, on the embeddings engine slots 0..k-1 hold now (saber_encode / saber_set_embed_tokens):
+ * mask_crops_dev (k,320,320) uint8 -> probs_host (k, num_classes). */
+int saber_classifier_head(saber_classifier* c, const uint8_t* mask_crops_dev, int k, float* probs_host, void* stream);
+/* The 320x320 image crops / binarised mask crops the last saber_classifier_predict call made for its first n masks (device copies). */
+int saber_classifier_get_crops(saber_classifier* c, int n, float* crops_out_dev, uint8_t* masks_out_dev, void* stream);
 
 /* Per-launch HIP-event profiling of the engine's own kernels, by kernel class (events are recorded on the
  * stream the kernels are launched on).  Class order: 0 gemm_bf16, 1 hiera_attention, 2 layernorm,

@@ -72,6 +72,13 @@ SIGNATURES = {
     "saber_separate_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
     "saber_smooth_labels": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_double, _vp, C.POINTER(_i), _vp]),
     "saber_gaussian_smoothing_3d": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp]),
+    "saber_classifier_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "saber_classifier_destroy": (None, [_vp]),
+    "saber_classifier_set_weight": (_i, [_vp, C.c_char_p, _vp, _i64p, _i]),
+    "saber_classifier_finalize": (_i, [_vp]),
+    "saber_classifier_predict": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "saber_classifier_head": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "saber_classifier_get_crops": (_i, [_vp, _i, _vp, _vp, _vp]),
     "saber_profile_begin": (_i, [_vp]),
     "saber_profile_end": (_i, [_vp, C.POINTER(ProfileClass), _i]),
     "saber_encoder_flops": (C.c_double, [_vp]),

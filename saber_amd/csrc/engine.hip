@@ -37,6 +37,8 @@ template int eng_alloc<bf16_t>(saber_engine*, bf16_t**, size_t);
 template int eng_alloc<int>(saber_engine*, int**, size_t);
 template int eng_alloc<uint32_t>(saber_engine*, uint32_t**, size_t);
 template int eng_alloc<MaskStats>(saber_engine*, MaskStats**, size_t);
+template int eng_alloc<double>(saber_engine*, double**, size_t);
+template int eng_alloc<uint8_t>(saber_engine*, uint8_t**, size_t);
 
 #define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
 
@@ -855,6 +857,7 @@ static int ensure_rm_tables(saber_engine* e) {
     ENG_HIP(e, hipMemcpy(e->eng_to_rm, b.data(), 4096 * sizeof(int), hipMemcpyHostToDevice));
     return SABER_OK;
 }
+int eng_rm_tables(saber_engine* e) { return ensure_rm_tables(e); }
 extern "C" int saber_get_embed_tokens(saber_engine* e, int slot, float* out_tokens_dev, void* stream) {
     if (!e) return SABER_ERR_INVALID;
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");

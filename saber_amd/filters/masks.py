@@ -49,3 +49,74 @@ def fast_3d_gaussian_smoothing(volume, scale=0.075, deviceID=None):
     with torch.cuda.device(eng.device):
         out, _ = eng.smooth_labels(lab.contiguous(), scale)
     return out if is_tensor else out.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ classifier filter
+def apply_classifier(image, masks, classifier, desired_class: int = None, min_mask_area: int = 100, batchsize: int = 32):
+    """saber/filters/masks.py:8-21: class probabilities of every candidate mask (the device part, Predictor.batch_predict), then
+    the host resolution below."""
+    segs = np.array([m["segmentation"].astype(np.uint8) for m in masks])
+    predictions = classifier.batch_predict(image, segs, batchsize)
+    return convert_predictions_to_masks(predictions, masks, desired_class, min_mask_area)
+
+
+def convert_predictions_to_masks(predictions, masks, desired_class: int = None, min_mask_area: int = 100):
+    """saber/filters/masks.py:23-62.  desired_class > 0: the masks predicted as that class, merged where they overlap
+    (_consensus_based_resolution), area-filtered, ascending area.  Otherwise one merged mask per non-background class."""
+    if isinstance(masks, np.ndarray):
+        masks = masks_to_list(masks)
+    predicted = np.argmax(predictions, axis=1)
+    if desired_class > 0 and desired_class is not None:        # (operand order of the reference: desired_class=None raises there as well)
+        conf = predictions[:, desired_class]
+        idx = [i for i, p in enumerate(predicted) if p == desired_class]
+        masks = [masks[i] for i in idx]
+        conf = conf[idx]
+        if len(masks) > 0:
+            masks = _consensus_based_resolution(masks[0]["segmentation"].shape, masks, conf)
+            masks = sorted([m for m in masks if m["area"] >= min_mask_area], key=lambda m: m["area"], reverse=False)
+        return masks
+    if len(masks) == 0:
+        return np.array([])
+    return _semantic_segmentation(masks, predictions)
+
+
+def _consensus_based_resolution(image_shape, masks, confidences):
+    """saber/filters/masks.py:64-122: connected components of the union of the masks; each component's score is the mean, over its
+    pixels, of the overlap-averaged class confidence."""
+    from scipy import ndimage
+    h, w = image_shape
+    conf_map = np.zeros((h, w), dtype=np.float32)
+    count = np.zeros((h, w), dtype=np.int32)
+    for m, c in zip(masks, confidences):
+        conf_map += m["segmentation"] * c
+        count += m["segmentation"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        avg = np.nan_to_num(np.divide(conf_map, count))
+    labeled, ncomp = ndimage.label(count > 0)
+    out = []
+    for lab in range(1, ncomp + 1):
+        comp = labeled == lab
+        score = float(np.mean(avg[comp]))
+        ys, xs = np.where(comp)
+        y0, y1, x0, x1 = int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max())
+        out.append({"segmentation": comp, "area": int(np.sum(comp)), "bbox": [x0, y0, x1 - x0, y1 - y0], "predicted_iou": score,
+                    "point_coords": [[int((x0 + x1) / 2), int((y0 + y1) / 2)]], "stability_score": score, "crop_box": [x0, y0, x1, y1]})
+    return out
+
+
+def _semantic_segmentation(masks, predictions):
+    """saber/filters/masks.py:124-158"""
+    predicted = np.argmax(predictions, axis=1)
+    out = [{"segmentation": np.zeros(masks[0]["segmentation"].shape, dtype=np.uint8), "area": 0, "label": k} for k in range(1, predictions.shape[1])]
+    for m, p in zip(masks, predicted):
+        if p > 0:
+            out[p - 1]["segmentation"] = np.logical_or(out[p - 1]["segmentation"], m["segmentation"]).astype(bool)
+            out[p - 1]["area"] += m["area"]
+    return out
+
+
+def masks_to_list(masks):
+    """saber/filters/masks.py:188-206"""
+    if isinstance(masks, list):
+        return masks
+    return [{"segmentation": masks == v, "area": np.sum((masks == v) > 0)} for v in np.unique(masks)]

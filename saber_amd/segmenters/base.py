@@ -1,7 +1,7 @@
 """saber2D / saber3D (reference: saber/segmenters/base.py:18-280): the 2-D segmentation entry used by every
 volumetric loop.  Behaviour kept: adapter construction from an AdapterConfig or a bare cfgAMG, the non-sliding and
 sliding-window branches of segment_image, the min-area filter, duplicate removal and ascending-area ordering of
-_apply_classifier (classifier=None), get_sliding_windows, rasterize_masks, and saber3D.propagate's contract."""
+_apply_classifier (with and without a classifier), get_sliding_windows, rasterize_masks, and saber3D.propagate's contract."""
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -70,7 +70,11 @@ class saber2D:
             masks = utils.remove_duplicate_masks(masks)
         if self.classifier is None:
             return sorted(masks, key=lambda m: m["area"], reverse=False)
-        raise NotImplementedError("the domain-expert classifier filter is a 'next' row (SURVEY.md 8f-3)")
+        from saber_amd.filters import masks as filters
+        gray = image[:, :, 0] if image.ndim == 3 else image
+        # (positional arguments as in the reference, base.py:172-174: self.batchsize lands in apply_classifier's min_mask_area slot and
+        # the group size stays at its default of 32)
+        return filters.apply_classifier(gray, masks, self.classifier, self.target_class, self.batchsize)
 
     def get_sliding_windows(self, image_shape: Tuple[int, int]) -> List[Tuple[int, int, int, int]]:
         h, w = image_shape[:2]

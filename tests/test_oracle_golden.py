@@ -246,3 +246,17 @@ def test_classifier_head_restatement_equals_torch_modules():
         a = m(x)
         b = cr.head({k: torch.from_numpy(v) for k, v in W.items()}, x)
     assert torch.allclose(a, b, rtol=0, atol=1e-5)
+
+
+def test_product_classifier_resolution_matches_reference():
+    """saber_amd.filters.masks (host part of the classifier filter) against the reference's outputs."""
+    from saber_amd.filters import masks as fm
+    G = _cls_golden()
+    dicts = [{"segmentation": m.astype(bool), "area": int(m.sum())} for m in G["masks"][:6]]
+    inst = fm.convert_predictions_to_masks(G["pred"], list(dicts), 1, 32)
+    assert np.array_equal(np.stack([m["segmentation"] for m in inst]).astype(np.uint8), G["inst_seg"])
+    assert [m["area"] for m in inst] == G["inst_area"].tolist() and [m["bbox"] for m in inst] == G["inst_bbox"].tolist()
+    assert np.allclose([m["predicted_iou"] for m in inst], G["inst_conf"], rtol=0, atol=1e-7)
+    sem = fm.convert_predictions_to_masks(G["pred"], list(dicts), 0, 32)
+    assert np.array_equal(np.stack([np.asarray(m["segmentation"]) for m in sem]).astype(np.uint8), G["sem_seg"])
+    assert [m["area"] for m in sem] == G["sem_area"].tolist()
