@@ -678,7 +678,7 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
     int nsplit = 1;
     while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's tiles over several blocks
     extern int g_saber_debug_flags;
-    if (g_saber_debug_flags >> 8) nsplit = g_saber_debug_flags >> 8;
+    if (g_saber_debug_flags >> 20) nsplit = g_saber_debug_flags >> 20;      // (bits 8-19 belong to the GEMM kernels)
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
     if (g_saber_debug_flags & 1)

@@ -347,6 +347,15 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         w.fc2 = F.lin(b + "mlp.layers.1", bs.dout, 4 * bs.dout);
         if (bs.din != bs.dout) w.sc = F.lin(b + "proj", bs.dout, bs.din);
         if (F.status != SABER_OK) return F.status;
+        // qkv / fc1 run on the persistent 256x256 kernel: the same K-step-packed copy makes each of its W pieces one contiguous KB
+        if (!e->padded) {
+            for (LinW* l : {&w.qkv, &w.fc1}) {
+                bf16_t* d = nullptr;
+                TRY(eng_alloc(e, &d, gemm_rowln_packed_elems(l->out, l->in)));
+                if (const char* m = launch_pack_w_kstep(l->w, l->ldw, l->out, l->in, d, nullptr)) return eng_fail(e, SABER_ERR_INVALID, m);
+                l->wpk = d;
+            }
+        }
         // residual widths the row-owner GEMM + LayerNorm kernel covers: a K-step-packed copy of the two weights it replaces
         if (!e->padded && (bs.dout == 144 || bs.dout == 288 || bs.dout == 576)) {
             for (LinW* l : {&w.proj, &w.fc2}) {

@@ -675,13 +675,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
         return L;
     };
     int Li, tmi = 0, tni = 0, kti = 0, si = 0;
+    const bool wpk = p.Wpk != nullptr && p.batch <= 1 && !(p.dbg & 16384);
+    const int64_t wpk_kstride = (int64_t)p.N * 32;
     const bf16_t* asrc[2];
     const bf16_t* wsrc[2];
     auto set_issue_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             asrc[i] = A + (int64_t)min(tmi * 256 + prow[i], p.M - 1) * p.lda;
-            wsrc[i] = W + (int64_t)min(tni * 256 + prow[i], p.N - 1) * p.ldw;
+            // W pre-packed per K-step (launch_pack_w_kstep: Wpk[ks][n][physical chunk][8]): the piece of 16 rows is one contiguous KB
+            if (wpk) wsrc[i] = p.Wpk + ((int64_t)min(tni * 256 + prow[i], p.N - 1) * 4 + lslot) * 8;
+            else wsrc[i] = W + (int64_t)min(tni * 256 + prow[i], p.N - 1) * p.ldw;
         }
     };
     // one K-tile = 4 pieces per wave (A0, W0, A1, W1); piece q of the issue cursor's K-tile, then advance() moves the cursor
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
         char* sa = smem + si * P2_STAGE;
         const int i = q >> 1;
         const int k = kti * BK2 + pchunk[i] * 8;
-        if (q & 1) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + k), (lptr_t)(sa + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
+        if (q & 1) __builtin_amdgcn_global_load_lds((gptr_t)(wpk ? wsrc[i] + (int64_t)kti * wpk_kstride : wsrc[i] + k), (lptr_t)(sa + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
         else __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (k < p.K ? k : 0)), (lptr_t)(sa + (wave * 2 + i) * 1024), 16, 0, 0);   // K tail of A: any finite data, W supplies the zeros
     };
     auto advance = [&]() {
