@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--max-prompts", type=int, default=1024, help="prompts decoded per batched pass")
     ap.add_argument("--workers", type=int, default=2, help="engine handles per GPU, each on its own thread and HIP stream, slices dealt round-robin "
                     "(the reference's GPUPool runs one thread per GPU; kernels of two slices in flight fill each other's idle issue slots)")
+    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16", help="fp8: e4m3 weights (per-row power-of-two scales) for the stage-2/3 block GEMMs, "
+                    "bf16 activations and MFMA operands, fp32 accumulate (BASELINE configs[4]); a SEPARATE line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-encoder-only", action="store_true", help="skip the extra encoder-only timing (profiling runs: keeps the kernel population of the trace = whole slices)")
@@ -179,7 +181,7 @@ def main():
 
     cfg = get_config("large")
     weights = seeded_weights(cfg, 0)
-    eng = Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts)
+    eng = Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, weight_format=a.dtype)
     amg = dict(npoints=a.npoints, crop_n_layers=a.crop_n_layers)
     params = make_amg_params(amg)
 
@@ -192,7 +194,7 @@ def main():
             planes[i] = plane
         return n_masks
 
-    engines = [eng] + [Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts) for _ in range(a.workers - 1)]
+    engines = [eng] + [Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, weight_format=a.dtype) for _ in range(a.workers - 1)]
     streams = [torch.cuda.Stream() for _ in engines]
 
     def run_steps(first, count, planes=None):
@@ -260,11 +262,12 @@ def main():
         out = {
             "metric": "EM slices/sec (1024^2, Hiera-L)", "value": world * a.steps / dt, "unit": "slices/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "bf16 operands, e4m3 weights (stage-2/3 block GEMMs)", "data": "synthetic",
             "config": {"workload": f"1024x1024 uint16 EM slice -> prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults: npoints={a.npoints}, "
                                    f"crop_n_layers={a.crop_n_layers} -> {n_crops} crops, {n_first} grid prompts + {3 * n_first} m2m refinements, multimask) "
                                    f"-> dedup/sort -> uint16 label plane; BASELINE configs[1]",
-                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)", "slices_per_rank": a.steps, "engine_handles_per_gpu": a.workers,
+                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)" + ("" if a.dtype == "bf16" else "; qkv / proj / fc1 / fc2 of stages 2-3 quantised to OCP e4m3fn with "
+                                  "per-row power-of-two scales at load, expanded to bf16 MFMA operands (no fp8-operand kernel is built: the roofline stays the bf16 one)"), "slices_per_rank": a.steps, "engine_handles_per_gpu": a.workers,
                        "parallelism": (f"REHEARSAL on one GPU (gloo), not a multi-GPU measurement, x{world}" if rehearsal else
                                        f"WEAK scaling: every one of the {world} ranks (one process per GPU) segments its own {a.steps} slices "
                                        f"(slices are independent units, no data-path collective); one RCCL all_gather of the {world} x {a.steps} uint16 "

@@ -136,6 +136,15 @@ int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const i
 int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* params,
                        uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta_host, int* out_count, void* stream);
 
+/* Weight format of the Hiera stage-2 / stage-3 block GEMMs (qkv, proj, fc1, fc2: 94 % of the encoder's weights), to be chosen before
+ * saber_engine_finalize.  SABER_WEIGHTS_FP8_E4M3 (BASELINE configs[4], "fp8 weights"): every output row is quantised to OCP e4m3fn with
+ * one power-of-two scale per row (round to nearest even, saturating at 448).  The MFMA operands stay bf16 (activations are bf16, and the
+ * quantised value times its scale is exact in bf16), accumulation fp32: this is the numerics of an fp8-weight checkpoint, not an
+ * fp8-operand kernel (none is built).  Narrower than the reference's precision: never the default. */
+#define SABER_WEIGHTS_BF16 0
+#define SABER_WEIGHTS_FP8_E4M3 1
+int saber_engine_set_weight_format(saber_engine* e, int format);
+
 /* hipGraph replay of saber_amg_generate's launch sequences (BASELINE configs[4]: "hipGraph-captured per-slice encode+decode"): the batched
  * encoder pass and each decoder batch are run eagerly the first time their shapes are seen on a handle, captured the second time and
  * replayed from then on (needs a non-default stream; on by default, SABER_AMD_GRAPHS=0 or saber_engine_set_graphs(e, 0) turns it off).

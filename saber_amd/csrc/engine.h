@@ -31,6 +31,7 @@ struct saber_engine {
     int max_images = 1, max_prompts = 64;
     std::string err;
     bool finalized = false;
+    int weight_format = 0;          // SABER_WEIGHTS_*
 
     // model description (tiny / small / base+ / large)
     int embed_dim = 0;

@@ -121,6 +121,13 @@ int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const st
     ENG_HIP(e, hipGraphLaunch(exec, s));
     return SABER_OK;
 }
+extern "C" int saber_engine_set_weight_format(saber_engine* e, int format) {
+    if (!e) return SABER_ERR_INVALID;
+    if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "set_weight_format after finalize");
+    if (format != SABER_WEIGHTS_BF16 && format != SABER_WEIGHTS_FP8_E4M3) return eng_fail(e, SABER_ERR_INVALID, "set_weight_format: unknown format");
+    e->weight_format = format;
+    return SABER_OK;
+}
 extern "C" int saber_engine_set_graphs(saber_engine* e, int enable) {
     if (!e) return SABER_ERR_INVALID;
     e->graphs_on = enable != 0;
@@ -234,8 +241,32 @@ struct Finalizer {
         if (hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { status = eng_fail(e, SABER_ERR_HIP, "weight upload failed"); return nullptr; }
         return d;
     }
+    // fp8 weight format (saber_engine_set_weight_format): OCP e4m3fn values with one power-of-two scale per output row, so that
+    // value * scale is exact in bf16 (what an fp8-operand kernel that applies the scale to its fp32 accumulators computes)
+    bool q8 = false;
+    static float e4m3_round(float x) {
+        const float a = std::fabs(x);
+        if (!(a > 0.f)) return 0.f;
+        int ex; (void)std::frexp(a, &ex);                      // a = f * 2^ex, f in [0.5, 1)
+        const int e2 = std::max(ex - 1, -6);                   // binade (subnormals share 2^-6)
+        const float quantum = std::ldexp(1.0f, e2 - 3);        // 3 mantissa bits
+        const float q = std::min(std::nearbyint(a / quantum) * quantum, 448.0f);   // round to nearest even, saturate
+        return x < 0.f ? -q : q;
+    }
+    void quantise_rows_e4m3(std::vector<float>& w, int rows, int cols) {
+        for (int r = 0; r < rows; ++r) {
+            float mx = 0.f;
+            for (int c = 0; c < cols; ++c) mx = std::max(mx, std::fabs(w[(size_t)r * cols + c]));
+            if (!(mx > 0.f)) continue;
+            const float scale = std::ldexp(1.0f, (int)std::ceil(std::log2(mx / 448.0f)));
+            for (int c = 0; c < cols; ++c) w[(size_t)r * cols + c] = e4m3_round(w[(size_t)r * cols + c] / scale) * scale;
+        }
+    }
     // [rows][cols] fp32 -> bf16 with every row zero-padded to a multiple of 64 (direct-to-LDS GEMM contract)
-    void up_lin(LinW* l, const std::vector<float>& w, int rows, int cols) {
+    void up_lin(LinW* l, const std::vector<float>& w_in, int rows, int cols) {
+        std::vector<float> wq;
+        if (q8) { wq = w_in; quantise_rows_e4m3(wq, rows, cols); }
+        const std::vector<float>& w = q8 ? wq : w_in;
         const int ld = (cols + 63) / 64 * 64;
         std::vector<float> padded((size_t)rows * ld, 0.0f);
         for (int r = 0; r < rows; ++r) std::copy(w.begin() + (size_t)r * cols, w.begin() + (size_t)(r + 1) * cols, padded.begin() + (size_t)r * ld);
@@ -340,11 +371,13 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         const std::string b = t + "blocks." + std::to_string(i) + ".";
         BlockW& w = e->bw[i];
         w.n1 = F.ln(b + "norm1", bs.din);
+        F.q8 = e->weight_format == SABER_WEIGHTS_FP8_E4M3 && bs.dout >= 4 * e->embed_dim;      // stages 2 and 3: 94 % of the encoder's weights
         w.qkv = F.lin(b + "attn.qkv", 3 * bs.dout, bs.din);
         w.proj = F.lin(b + "attn.proj", bs.dout, bs.dout);
         w.n2 = F.ln(b + "norm2", bs.dout);
         w.fc1 = F.lin(b + "mlp.layers.0", 4 * bs.dout, bs.dout);
         w.fc2 = F.lin(b + "mlp.layers.1", bs.dout, 4 * bs.dout);
+        F.q8 = false;                                   // (the stage-transition shortcut projection stays bf16)
         if (bs.din != bs.dout) w.sc = F.lin(b + "proj", bs.dout, bs.din);
         if (F.status != SABER_OK) return F.status;
         // qkv / fc1 run on the persistent 256x256 kernel: the same K-step-packed copy makes each of its W pieces one contiguous KB

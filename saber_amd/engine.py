@@ -30,7 +30,7 @@ class Engine:
     """One engine handle bound to one device (reference threading contract: one caller per device)."""
 
     def __init__(self, trunk: str = "large", device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
-                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64):
+                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64, weight_format: str = "bf16"):
         self.lib = _lib.load()
         self.cfg = get_config(trunk)  # ValueError for unknown names, like the reference
         if not torch.cuda.is_available():
@@ -44,6 +44,11 @@ class Engine:
             raise (ValueError if st == -1 else RuntimeError)(msg)
         self.h = h
         self.max_images, self.max_prompts = max_images, max_prompts
+        if weight_format not in ("bf16", "fp8"):
+            raise ValueError(f"weight_format must be 'bf16' or 'fp8', got '{weight_format}'")
+        self.weight_format = weight_format
+        if weight_format == "fp8":       # e4m3 stage-2/3 block weights (include/saber_amd.h: saber_engine_set_weight_format)
+            self._check(self.lib.saber_engine_set_weight_format(self.h, 1))
         if weights is None:
             weights = load_checkpoint(checkpoint, self.cfg) if checkpoint else seeded_weights(self.cfg, seed)
         for name, arr in weights.items():
