@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-encoder-only", action="store_true", help="skip the extra encoder-only timing (profiling runs: keeps the kernel population of the trace = whole slices)")
+    ap.add_argument("--no-video", action="store_true", help="skip the extra measurement of the SAM2 video (memory) path, SURVEY.md 8f-1")
     ap.add_argument("--no-tail", action="store_true", help="skip the extra measurement of the post-filter tail on a slice with a few hundred masks")
     return ap.parse_args()
 
@@ -344,6 +345,13 @@ def main():
             out["tail"] = tail_mode(eng, pool, a, segment_slice_to_plane, make_amg_params)
         except Exception as ex:     # the extra key must never take the headline down with it
             out["tail"] = {"error": str(ex)[:300]}
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_video and a.dtype == "bf16":
+        try:        # the next row of the scope table: frames per second of the memory path, beside the metric, never in it
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import video_bench
+            out["propagation"] = video_bench.run("large", 32)
+        except Exception as ex:
+            out["propagation"] = {"error": str(ex)[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         img01 = eng.prepare(pool[0]).cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(cfg, weights, img01, a.crop_n_layers)

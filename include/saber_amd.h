@@ -106,7 +106,10 @@ int saber_prepare(saber_engine* e, const void* img_dev, int dtype, int H, int W,
 int saber_prepare_rgb(saber_engine* e, const float* img_dev, int H, int W, float* out_dev, void* stream);
 
 /* Encode n crops of one image.  img_dev: (H,W) [channels==1] or (H,W,3) float32 in [0,1];
- * crop_boxes_host: n x [x0,y0,x1,y1].  Features stay resident in slots slot0..slot0+n-1. */
+ * crop_boxes_host: n x [x0,y0,x1,y1].  Features stay resident in slots slot0..slot0+n-1.
+ * channels == -1: one grey plane that already carries the model's input normalisation; it is replicated to three channels WITHOUT the
+ * ImageNet statistics (the video path's frames, saber/adapters/preprocessing.py:55-56; a stack of Z frames is a (Z*1024, 1024) image
+ * whose crop boxes are the frames, so a window of frames is one batched pass). */
 int saber_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crop_boxes_host, int n,
                  int slot0, void* stream);
 /* Copy a slot's features out as NCHW fp32: image_embed (256,64,64), feat_s0 (32,256,256), feat_s1 (64,128,128).

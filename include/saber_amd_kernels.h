@@ -71,6 +71,11 @@ int saber_k_rope(const float* x, int64_t rows, int n_rot, int C, int side, float
 int saber_k_softmax_rows(const float* S, int64_t ld_s, int64_t rows, int n, float scale, uint16_t* P, int64_t ld_p, void* stream);
 /* Conv2d(k3, s2, p1) of the memory encoder's mask down-sampler; w (Cout,Cin,3,3) */
 int saber_k_conv3x3s2(const float* in, int H, int W, int Cin, const float* w, const float* b, int Cout, float* out, void* stream);
+/* the same with the weights pre-arranged as (3,3,Cin,Cout) (Cout a multiple of 4): the layout the tracking loop keeps per model */
+int saber_k_conv3x3s2_t(const float* in, int H, int W, int Cin, const float* wt, const float* b, int Cout, float* out, void* stream);
+/* plane[y][x] = label wherever logits (Hv,Wv) > thr at the nearest source pixel of the output pixel centre; any_flag (optional, device
+ * int) is OR-ed with 1 when a pixel was painted.  SAM2Adapter.segment_volume's _apply, saber/adapters/sam2/predictor.py:288-298. */
+int saber_k_paint_nearest(const float* logits, int Hv, int Wv, float thr, int label, uint16_t* plane, int H, int W, int* any_flag, void* stream);
 /* depth-wise Conv2d(k7, p3) of the memory fuser's ConvNeXt blocks; w (C,1,7,7) */
 int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream);
 /* the video predictor's mask_downsample: Conv2d(1, 1, k4, s4) */

@@ -101,6 +101,8 @@ SIGNATURES = {
     "saber_k_rope": (_i, [_vp, C.c_int64, _i, _i, _i, _f, _vp, _vp, _vp]),
     "saber_k_softmax_rows": (_i, [_vp, C.c_int64, C.c_int64, _i, _f, _vp, C.c_int64, _vp]),
     "saber_k_conv3x3s2": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "saber_k_conv3x3s2_t": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "saber_k_paint_nearest": (_i, [_vp, _i, _i, _f, _i, _vp, _i, _i, _vp, _vp]),
     "saber_k_dwconv7": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),

@@ -88,6 +88,27 @@ def load_tomogram_frames(tomogram: np.ndarray, image_size: int = 1024, light_mod
     return out
 
 
+def load_tomogram_frames_device(tomogram: np.ndarray, lib, device, image_size: int = 1024, light_modality: bool = False) -> torch.Tensor:
+    """load_tomogram_frames on the device: the two affine steps (min-max to [-1,1], then 2x - 1) commute with the bilinear resize, so the
+    volume is uploaded once and one resize launch with the fused affine map v -> 4 (v - min) / (max - min) - 3 produces the (Z, 1024, 1024)
+    frame stack in HBM (the host version spends ~25 ms per slice in numpy).  Same restrictions as the host version."""
+    t = torch.from_numpy(np.ascontiguousarray(tomogram, dtype=np.float32)).to(device)
+    Z, H, W = t.shape
+    if H > image_size or W > image_size:
+        raise NotImplementedError("tomograms larger than the model's 1024 px are down-sampled by skimage with Gaussian anti-aliasing in "
+                                  "the reference; resample them first (saber's Fourier cropping) - not restated here")
+    mn, mx = (float(v) for v in torch.aminmax(t))
+    a = 4.0 / (mx - mn)
+    out = torch.empty((Z, image_size, image_size), dtype=torch.float32, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if lib.saber_k_resize_plane(C.c_void_p(t.data_ptr()), Z, H, W, C.c_void_p(out.data_ptr()), image_size, image_size, 0, 3, a, -a * mn - 3.0, stream) != 0:
+        raise RuntimeError(lib.saber_k_last_error().decode())
+    if light_modality:
+        lo, hi = torch.aminmax(out)
+        out = (out - lo) / (hi - lo) * 255
+    return out
+
+
 class VideoPredictor:
     """add_new_mask / propagate_in_video of the SAM2 video predictor on one engine handle."""
 
@@ -121,7 +142,15 @@ class VideoPredictor:
         self.no_obj_spatial = np.asarray(W["no_obj_embed_spatial"], dtype=np.float32).reshape(-1)
         self.neg_no_mem = torch.from_numpy(-np.asarray(W["no_mem_embed"], dtype=np.float32).reshape(1, 256)).to(self.dev)
         self.curr_pos = torch.from_numpy(_sine_pe_2d(64, 128)).to(self.dev)                     # (4096,256)
-        self.mem_pos = _sine_pe_2d(64, 32)                                                      # (4096,64) host: temporal encoding is added per use
+        self.mem_pos = _sine_pe_2d(64, 32)                                                      # (4096,64)
+        # spatial position + temporal encoding of a memory that is k slots away, once per model (device)
+        self.mem_pos_t = [torch.from_numpy(self.mem_pos + self.tpos[k][None]).to(self.dev) for k in range(num_maskmem)]
+        self.no_obj_ptr_dev = torch.from_numpy(self.no_obj_ptr).to(self.dev)
+        self.no_obj_spatial_bias = (self.f32["memory_encoder.out_proj.bias"] + torch.from_numpy(self.no_obj_spatial).to(self.dev)).contiguous()
+        # mask down-sampler convolutions with the weights laid out (3,3,Cin,Cout) for saber_k_conv3x3s2_t
+        self.conv_t = {j: torch.from_numpy(np.ascontiguousarray(np.asarray(W[f"memory_encoder.mask_downsampler.encoder.{3 * j}.weight"], dtype=np.float32)
+                                                                .transpose(2, 3, 1, 0))).to(self.dev) for j in range(4)}
+        self._pe1d_cache: Dict[tuple, torch.Tensor] = {}
         self.hook = None
         self.images = None
 
@@ -163,61 +192,76 @@ class VideoPredictor:
         return out
 
     # ------------------------------------------------------------------ state
-    def init_state(self, frames: np.ndarray, video_hw: Optional[Tuple[int, int]] = None):
-        """frames: (Z, 1024, 1024) float32 gray planes as load_tomogram_frames returns them"""
-        assert frames.ndim == 3 and frames.shape[1:] == (1024, 1024)
+    def init_state(self, frames, video_hw: Optional[Tuple[int, int]] = None):
+        """frames: (Z, 1024, 1024) float32 gray planes as load_tomogram_frames (numpy) or load_tomogram_frames_device (tensor) return them"""
+        assert frames.ndim == 3 and tuple(frames.shape[1:]) == (1024, 1024)
         self.images = frames
         self.num_frames = frames.shape[0]
         self.video_hw = video_hw or (1024, 1024)
         self.obj_ids: List[int] = []
         self.out: Dict[int, Dict[str, dict]] = {}
         self.temp: Dict[int, dict] = {}
-        self._cur = (-1, None)
+        self._raw: Dict[int, torch.Tensor] = {}
+        self._win = (0, 0)
+        self._frames_dev = None
 
     def reset_state(self):
-        self.obj_ids, self.out, self.temp, self._cur = [], {}, {}, (-1, None)
+        self.obj_ids, self.out, self.temp, self._raw, self._win = [], {}, {}, {}, (0, 0)
 
-    def _frame(self, t: int) -> torch.Tensor:
-        """encode frame t into slot 0 (high-resolution features stay there for the decoder); returns the RAW top-level features
-        (without no_mem_embed) as (4096,256) fp32 row-major tokens"""
-        if self._cur[0] == t:
-            return self._cur[1]
-        g = self.images[t]
-        # the engine's pixel kernel applies the ImageNet statistics; the video path feeds frames WITHOUT them (preprocessing.py:55-56),
-        # so the statistics are pre-inverted per channel: ((v * std + mean) - mean) / std = v
-        img = np.stack([g * np.float32(s) + np.float32(m) for m, s in zip(IMAGE_MEAN, IMAGE_STD)], -1).astype(np.float32)
-        self.eng.encode(torch.from_numpy(np.ascontiguousarray(img)).to(self.dev), slot0=0)
-        emb = self._new(4096, 256)
-        self.eng._check(self.lib.saber_get_embed_tokens(self.eng.h, 0, self._p(emb), self._s()))
-        raw = self._new(4096, 256)
-        self._ck(self.lib.saber_k_add_to_bf16(self._p(emb), self._p(self.neg_no_mem), 1, None, self._p(raw), 4096, 256, self._s()))
-        self._cur = (t, raw)
-        return raw
+    def _frame(self, t: int, reverse: bool = False) -> torch.Tensor:
+        """RAW top-level features of frame t (without no_mem_embed) as (4096,256) fp32 row-major tokens.  Frames are encoded a WINDOW at a
+        time: the per-frame Hiera passes are independent, so the next max_images frames in the direction of travel
+        go through the encoder as one batched pass (the device copy of the frame stack is a (Z*1024, 1024) image whose crop boxes are
+        the frames) and stay in the engine's slots, where the decoder finds their high-resolution features."""
+        if t in self._raw:
+            return self._raw[t]
+        B = self.eng.max_images
+        t0, t1 = (max(0, t - B + 1), t + 1) if reverse else (t, min(self.num_frames, t + B))
+        if self._frames_dev is None:
+            self._frames_dev = (self.images.to(self.dev, dtype=torch.float32).contiguous() if isinstance(self.images, torch.Tensor) else
+                                torch.from_numpy(np.ascontiguousarray(self.images, dtype=np.float32)).to(self.dev))
+        k = t1 - t0
+        self.eng.encode(self._frames_dev[t0:t1].view(k * 1024, 1024), crop_boxes=[[0, i * 1024, 1024, (i + 1) * 1024] for i in range(k)],
+                        slot0=0, normalised_grey=True)
+        self._raw, self._win = {}, (t0, t1)
+        for i in range(k):
+            emb = self._new(4096, 256)
+            self.eng._check(self.lib.saber_get_embed_tokens(self.eng.h, i, self._p(emb), self._s()))
+            raw = self._new(4096, 256)
+            self._ck(self.lib.saber_k_add_to_bf16(self._p(emb), self._p(self.neg_no_mem), 1, None, self._p(raw), 4096, 256, self._s()))
+            self._raw[t0 + i] = raw
+        return self._raw[t]
+
+    def _slot(self, t: int) -> int:
+        assert self._win[0] <= t < self._win[1]
+        return t - self._win[0]
 
     # ------------------------------------------------------------------ SAM heads on a given (4096,256) embedding
-    def _sam_heads(self, embed_tokens: torch.Tensor, mask_in: Optional[torch.Tensor], multimask: bool):
-        """returns (low (256,256) device fp32, obj logit float, obj_ptr (1,256) host fp32)"""
-        self.eng._check(self.lib.saber_set_embed_tokens(self.eng.h, 0, self._p(embed_tokens), self._s()))
+    def _sam_heads(self, embed_tokens: torch.Tensor, mask_in: Optional[torch.Tensor], multimask: bool, slot: int = 0):
+        """returns (low (256,256) device fp32, obj logit float, obj_ptr (1,256) device fp32); slot: the engine slot that holds the frame"""
+        self.eng._check(self.lib.saber_set_embed_tokens(self.eng.h, slot, self._p(embed_tokens), self._s()))
         pts = torch.zeros(1, 2, device=self.dev)
         lab = torch.full((1,), -1, dtype=torch.int32, device=self.dev)
-        low, iou, obj = self.eng.decode_points(pts, slot=0, multimask=multimask, mask_input=mask_in, labels=lab)
+        low, iou, obj = self.eng.decode_points(pts, slot=slot, multimask=multimask, mask_input=mask_in, labels=lab)
         toks = self._new(8, 256)
         self.eng._check(self.lib.saber_get_decoder_tokens(self.eng.h, 1, self._p(toks), self._s()))
-        obj_v = float(obj.cpu()[0])
+        host = torch.cat([obj.reshape(-1)[:1], iou[0].reshape(-1)]).cpu()       # the one synchronisation of a tracked frame: object score + IoUs
+        obj_v = float(host[0])
         if self.hook is not None:
             self.hook(obj_v)
         if multimask:
-            best = int(torch.argmax(iou[0].cpu()))
+            best = int(torch.argmax(host[1:]))
             low_b, tok = low[0, best], toks[3 + best:4 + best]
         else:
             low_b, tok = low[0, 0], toks[2:3]
-        h = self._lin(self._to_bf(tok, 1, 256), "obj_ptr_proj.layers.0", 1, out_bf=True, act=ACT_RELU)
-        h = self._lin(h, "obj_ptr_proj.layers.1", 1, out_bf=True, act=ACT_RELU)
-        ptr = self._lin(h, "obj_ptr_proj.layers.2", 1).cpu().numpy()
         appearing = obj_v > 0
-        if not appearing:
+        if appearing:
+            h = self._lin(self._to_bf(tok, 1, 256), "obj_ptr_proj.layers.0", 1, out_bf=True, act=ACT_RELU)
+            h = self._lin(h, "obj_ptr_proj.layers.1", 1, out_bf=True, act=ACT_RELU)
+            ptr = self._lin(h, "obj_ptr_proj.layers.2", 1)                       # (1,256) fp32, stays on the device
+        else:
             low_b = torch.full((256, 256), NO_OBJ_SCORE, device=self.dev)
-            ptr = self.no_obj_ptr.copy()
+            ptr = self.no_obj_ptr_dev
         return low_b.contiguous(), obj_v, ptr
 
     def _resize(self, x, H, W, Ho, Wo, antialias=0, post=0, a=0.0, c=0.0):
@@ -234,7 +278,7 @@ class VideoPredictor:
         for j in range(4):
             Cout = Cin * 4
             y = self._new((H // 2) * (H // 2), Cout)
-            self._ck(self.lib.saber_k_conv3x3s2(self._p(x), H, H, Cin, self._p(self.f32[f"{pre}{3 * j}.weight"]), self._p(self.f32[f"{pre}{3 * j}.bias"]), Cout, self._p(y), self._s()))
+            self._ck(self.lib.saber_k_conv3x3s2_t(self._p(x), H, H, Cin, self._p(self.conv_t[j]), self._p(self.f32[f"{pre}{3 * j}.bias"]), Cout, self._p(y), self._s()))
             H //= 2
             x = self._ln(y, f"{pre}{3 * j + 1}", H * H, Cout, 1e-6, bf=(j == 3), act=ACT_GELU)
             Cin = Cout
@@ -250,10 +294,9 @@ class VideoPredictor:
             p2 = self._new(4096, 256)
             self._ck(self.lib.saber_k_axpy(self._p(p), self._p(h2), self._p(self.f32[f + "gamma"]), 1.0, 4096, 256, self._p(p2), self._s()))
             p = p2
-        bias = self.f32["memory_encoder.out_proj.bias"]
-        if not appearing:          # no_obj_embed_spatial on frames where the object is predicted absent
-            bias = bias + torch.from_numpy(self.no_obj_spatial).to(self.dev)
-        return self._lin(self._to_bf(p, 4096, 256), "memory_encoder.out_proj", 4096, out_bf=True, bias=bias.contiguous())
+        # no_obj_embed_spatial on frames where the object is predicted absent
+        bias = self.f32["memory_encoder.out_proj.bias"] if appearing else self.no_obj_spatial_bias
+        return self._lin(self._to_bf(p, 4096, 256), "memory_encoder.out_proj", 4096, out_bf=True, bias=bias)
 
     # ------------------------------------------------------------------ prompts
     @torch.inference_mode()
@@ -276,10 +319,10 @@ class VideoPredictor:
         low = self._resize(high, 1024, 1024, 256, 256, antialias=1)
         mdown = self._new(256, 256)
         self._ck(self.lib.saber_k_conv4x4s4(self._p(md), 1024, 1024, self._p(self.f32["mask_downsample.weight"]), self._p(self.f32["mask_downsample.bias"]), self._p(mdown), self._s()))
-        _, _, ptr = self._sam_heads(raw, mdown.view(1, 256, 256), multimask=False)
+        _, _, ptr = self._sam_heads(raw, mdown.view(1, 256, 256), multimask=False, slot=self._slot(frame_idx))
         # the pointer has been through the decoder's own object score (_forward_sam_heads); upstream then blends once more with the
         # appearance the MASK itself says (_use_mask_as_output)
-        tok_ptr = ptr if appearing else self.no_obj_ptr.copy()
+        tok_ptr = ptr if appearing else self.no_obj_ptr_dev
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": tok_ptr, "obj": 10.0 if appearing else -10.0, "mem": None, "raw": raw}
         return frame_idx, list(self.obj_ids), low
 
@@ -301,13 +344,13 @@ class VideoPredictor:
         st = self.out[oid]
         mems, pos = [], []
         for tc, o in st["cond"].items():
-            mems.append(o["mem"]); pos.append(self.mem_pos + self.tpos[self.num_maskmem - 1][None])
+            mems.append(o["mem"]); pos.append(self.mem_pos_t[self.num_maskmem - 1])
         for t_pos in range(1, self.num_maskmem):
             t_rel = self.num_maskmem - t_pos
             o = st["non_cond"].get(t + t_rel if reverse else t - t_rel)
             if o is None:
                 continue
-            mems.append(o["mem"]); pos.append(self.mem_pos + self.tpos[self.num_maskmem - t_pos - 1][None])
+            mems.append(o["mem"]); pos.append(self.mem_pos_t[self.num_maskmem - t_pos - 1])
         max_ptrs = min(self.num_frames, 16)
         sign = -1 if reverse else 1
         offs, ptrs = [], []
@@ -325,22 +368,28 @@ class VideoPredictor:
         n_ptr_tok = 4 * len(ptrs)
         Nk = n_spatial + n_ptr_tok
         Nkp = (Nk + 63) // 64 * 64
-        # memory tokens (bf16 as stored) and their position encodings (fp32): [spatial memories ..., pointer tokens]
+        # memory tokens (bf16 as stored) and their position encodings (fp32): [spatial memories ..., pointer tokens], assembled on the device
         mem_bf = self._new(Nkp, 64, dtype=torch.uint16, zero=True)
-        for i, mm in enumerate(mems):
+        pos_d = self._new(Nk, 64)
+        for i, (mm, pp) in enumerate(zip(mems, pos)):
             mem_bf[4096 * i:4096 * (i + 1)].copy_(mm)
-        pos_np = np.zeros((Nk, 64), np.float32)
-        for i, pp in enumerate(pos):
-            pos_np[4096 * i:4096 * (i + 1)] = pp
+            pos_d[4096 * i:4096 * (i + 1)].copy_(pp)
         if ptrs:
-            P = np.concatenate(ptrs, 0).astype(np.float32)                                     # (n,256)
-            mem_bf[n_spatial:Nk].copy_(torch.from_numpy(_bf16_bits(P.reshape(-1, 64))).to(self.dev))   # pointer tokens enter the bank in fp32 upstream; the GEMM operand is bf16 either way
-            pe = _sine_pe_1d(np.asarray(offs, np.float32) / np.float32(max_ptrs - 1), 256)
-            pe_d = self._lin(self._to_bf(torch.from_numpy(pe).to(self.dev), len(ptrs), 256), "obj_ptr_tpos_proj", len(ptrs)).cpu().numpy()
-            pos_np[n_spatial:] = np.repeat(pe_d, 4, axis=0)
+            P = torch.cat(ptrs, 0).contiguous()                                                # (n,256) fp32, device
+            # pointer tokens enter the bank in fp32 upstream; the GEMM operand is bf16 either way
+            mem_bf[n_spatial:Nk].copy_(self._to_bf(P, len(ptrs), 256).view(4 * len(ptrs), 64))
+            key = (tuple(offs), max_ptrs)
+            pe_bf = self._pe1d_cache.get(key)
+            if pe_bf is None:
+                pe = _sine_pe_1d(np.asarray(offs, np.float32) / np.float32(max_ptrs - 1), 256)
+                pe_bf = self._to_bf(torch.from_numpy(pe).to(self.dev), len(ptrs), 256)
+                if len(self._pe1d_cache) < 256:
+                    self._pe1d_cache[key] = pe_bf
+            pe_d = self._lin(pe_bf, "obj_ptr_tpos_proj", len(ptrs))                           # (n,64)
+            pos_d[n_spatial:].copy_(pe_d.repeat_interleave(4, dim=0))
         mem_f = self._new(Nk, 64)
         self._ck(self.lib.saber_k_bf16_to_f32(self._p(mem_bf), Nk * 64, self._p(mem_f), self._s()))
-        kin_bf = self._to_bf(mem_f, Nk, 64, torch.from_numpy(pos_np).to(self.dev), Nk)              # bf16(memory + position)
+        kin_bf = self._to_bf(mem_f, Nk, 64, pos_d, Nk)                                          # bf16(memory + position)
         # ---- 4 layers
         x = self._new(4096, 256)
         self._ck(self.lib.saber_k_axpy(self._p(raw), self._p(self.curr_pos), None, 0.1, 4096, 256, self._p(x), self._s()))
@@ -389,9 +438,9 @@ class VideoPredictor:
 
     # ------------------------------------------------------------------ tracking
     def _track(self, oid: int, t: int, reverse: bool) -> dict:
-        raw = self._frame(t)
+        raw = self._frame(t, reverse)
         cond = self._memory_conditioned(oid, t, raw, reverse)
-        low, obj_v, ptr = self._sam_heads(cond, None, multimask=True)
+        low, obj_v, ptr = self._sam_heads(cond, None, multimask=True, slot=self._slot(t))
         mfm = self._resize(low, 256, 256, 1024, 1024, antialias=0, post=1, a=20.0, c=-10.0)       # sigmoid(high-res logits) * 20 - 10
         mem = self._encode_memory(raw, mfm, obj_v > 0)
         return {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": mem}

@@ -127,6 +127,12 @@ extern "C" int saber_k_softmax_rows(const float* S, int64_t ld_s, int64_t rows, 
 extern "C" int saber_k_conv3x3s2(const float* in, int H, int W, int Cin, const float* w, const float* b, int Cout, float* out, void* stream) {
     return kcheck(launch_conv3x3s2(in, H, W, Cin, w, b, Cout, out, (hipStream_t)stream));
 }
+extern "C" int saber_k_conv3x3s2_t(const float* in, int H, int W, int Cin, const float* wt, const float* b, int Cout, float* out, void* stream) {
+    return kcheck(launch_conv3x3s2_t(in, H, W, Cin, wt, b, Cout, out, (hipStream_t)stream));
+}
+extern "C" int saber_k_paint_nearest(const float* logits, int Hv, int Wv, float thr, int label, uint16_t* plane, int H, int W, int* any_flag, void* stream) {
+    return kcheck(launch_paint_nearest(logits, Hv, Wv, thr, label, plane, H, W, any_flag, (hipStream_t)stream));
+}
 extern "C" int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream) {
     return kcheck(launch_dwconv7(in, H, W, C, w, b, out, (hipStream_t)stream));
 }

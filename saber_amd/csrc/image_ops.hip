@@ -211,6 +211,8 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const float* __re
     const int cw = x1 - x0, ch = y1 - y0;
     const int ox = blockIdx.x * 16 + (threadIdx.x & 15), oy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (ox >= res || oy >= res) return;
+    const bool no_stats = channels < 0;              // channels == -1: one grey plane that already carries the model's normalisation
+    if (no_stats) channels = 1;
     const AxisTaps tx = axis_taps(ox, cw, res), ty = axis_taps(oy, ch, res);
     float wxs = 0.f, wys = 0.f;
     for (int j = 0; j < tx.n; ++j) wxs += tri(((float)(j + tx.lo) - tx.center + 0.5f) * tx.invscale);
@@ -242,13 +244,13 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(const float* __re
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = channels == 1 ? acc[0] : acc[c];
-        out[((int64_t)b * 3 + c) * plane + (int64_t)oy * res + ox] = (v - mean[c]) / stdv[c];
+        out[((int64_t)b * 3 + c) * plane + (int64_t)oy * res + ox] = no_stats ? v : (v - mean[c]) / stdv[c];
     }
 }
 
 const char* launch_resize_normalize(const float* img, int H, int W, int channels, const int* crops_dev, int n, float* out, int res,
                                     hipStream_t s) {
-    if (channels != 1 && channels != 3) return "resize_normalize: channels must be 1 or 3";
+    if (channels != 1 && channels != 3 && channels != -1) return "resize_normalize: channels must be 1, 3 or -1 (grey, no statistics)";
     hipLaunchKernelGGL(resize_normalize_kernel, dim3(res / 16, res / 16, n), dim3(256), 0, s, img, H, W, channels, crops_dev, out, res);
     return nullptr;
 }

@@ -104,6 +104,43 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const float* __restrict_
         out[idx] = acc;
     }
 }
+// the same convolution with the weights laid out [ky][kx][ci][co] (prepared once per model): four consecutive output channels per
+// thread, so a wave's weight loads are whole lines and the input value is a broadcast (the (co, ci, ky, kx) layout reads one word per
+// 36-byte stride: 2.5 ms per tracked frame on the four layers of the mask down-sampler)
+__global__ __launch_bounds__(256) void conv3x3s2_t_kernel(const float* __restrict__ in, int H, int W, int Cin, const float* __restrict__ wt,
+                                                          const float* __restrict__ b, int Cout, float* __restrict__ out) {
+    const int Ho = H >> 1, Wo = W >> 1, c4n = Cout >> 2;
+    const int64_t total = (int64_t)Ho * Wo * c4n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int co = (int)(idx % c4n) * 4;
+        const int64_t pix = idx / c4n;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        float4 acc = *reinterpret_cast<const float4*>(b + co);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const float* ip = in + ((int64_t)iy * W + ix) * Cin;
+                const float* wp = wt + (int64_t)(ky * 3 + kx) * Cin * Cout + co;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float v = ip[ci];
+                    const float4 w4 = *reinterpret_cast<const float4*>(wp + (int64_t)ci * Cout);
+                    acc.x = fmaf(w4.x, v, acc.x); acc.y = fmaf(w4.y, v, acc.y); acc.z = fmaf(w4.z, v, acc.z); acc.w = fmaf(w4.w, v, acc.w);
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(out + pix * Cout + co) = acc;
+    }
+}
+const char* launch_conv3x3s2_t(const float* in, int H, int W, int Cin, const float* wt, const float* b, int Cout, float* out, hipStream_t s) {
+    if ((H | W) & 1) return "conv3x3s2: H and W must be even";
+    if (Cout & 3) return "conv3x3s2_t: Cout must be a multiple of 4";
+    const int64_t total = (int64_t)(H / 2) * (W / 2) * (Cout / 4);
+    hipLaunchKernelGGL(conv3x3s2_t_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, s, in, H, W, Cin, wt, b, Cout, out);
+    return nullptr;
+}
 // depth-wise 7x7, padding 3: out[(y,x)][c] = b[c] + sum w[c][ky][kx] in[(y+ky-3, x+kx-3)][c]
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, int H, int W, int C, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ out) {
@@ -226,5 +263,28 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restri
 const char* launch_bf16_to_f32(const bf16_t* x, int64_t n, float* out, hipStream_t s) {
     if (n <= 0) return nullptr;
     hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n, out);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ painting a tracked mask into the label volume
+// plane[y][x] = label where logits[ys][xs] > thr, (ys, xs) = nearest source pixel of the output pixel centre (skimage resize order 0:
+// floor((i + 0.5) * in / out)); other pixels keep their value.  SAM2Adapter.segment_volume's _apply (predictor.py:288-298) per object.
+__global__ __launch_bounds__(256) void paint_nearest_kernel(const float* __restrict__ logits, int Hv, int Wv, float thr, int label,
+                                                            uint16_t* __restrict__ plane, int H, int W, int* __restrict__ any_flag) {
+    const int64_t total = (int64_t)H * W;
+    bool hit = false;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int y = (int)(idx / W), x = (int)(idx - (int64_t)y * W);
+        const int ys = min(max((int)floor(((double)y + 0.5) * Hv / H), 0), Hv - 1);
+        const int xs = min(max((int)floor(((double)x + 0.5) * Wv / W), 0), Wv - 1);
+        if (logits[(int64_t)ys * Wv + xs] > thr) { plane[idx] = (uint16_t)label; hit = true; }
+    }
+    if (any_flag && __any(hit) && (threadIdx.x & 63) == 0) atomicOr(any_flag, 1);
+}
+const char* launch_paint_nearest(const float* logits, int Hv, int Wv, float thr, int label, uint16_t* plane, int H, int W, int* any_flag, hipStream_t s) {
+    if (Hv <= 0 || Wv <= 0 || H <= 0 || W <= 0) return "paint_nearest: bad shape";
+    if (label < 0 || label > 65535) return "paint_nearest: label does not fit uint16";
+    const int64_t total = (int64_t)H * W;
+    hipLaunchKernelGGL(paint_nearest_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, logits, Hv, Wv, thr, label, plane, H, W, any_flag);
     return nullptr;
 }

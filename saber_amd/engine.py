@@ -115,11 +115,15 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ encoder
-    def encode(self, img: torch.Tensor, crop_boxes: Optional[Sequence[Sequence[int]]] = None, slot0: int = 0):
-        """img: (H,W) or (H,W,3) float32 in [0,1] on the device; crop_boxes: list of [x0,y0,x1,y1]."""
+    def encode(self, img: torch.Tensor, crop_boxes: Optional[Sequence[Sequence[int]]] = None, slot0: int = 0, normalised_grey: bool = False):
+        """img: (H,W) or (H,W,3) float32 in [0,1] on the device; crop_boxes: list of [x0,y0,x1,y1].  normalised_grey: (H,W) plane that
+        already carries the model's input normalisation (channels = -1 of saber_encode)."""
         assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
         H, W = img.shape[:2]
         ch = 1 if img.dim() == 2 else img.shape[2]
+        if normalised_grey:
+            assert img.dim() == 2
+            ch = -1
         if crop_boxes is None:
             crop_boxes = [[0, 0, W, H]]
         cb = np.ascontiguousarray(np.asarray(crop_boxes, dtype=np.int32).reshape(-1, 4))

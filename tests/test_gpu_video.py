@@ -108,7 +108,7 @@ def video_case():
     W["sam_mask_decoder.pred_obj_score_head.layers.2.bias"] = W["sam_mask_decoder.pred_obj_score_head.layers.2.bias"] + np.float32(3.0)
     from saber_amd.weights import param_specs
     img_keys = set(param_specs(cfg).keys())
-    eng = Engine("tiny", device=0, weights={k: v for k, v in W.items() if k in img_keys}, max_images=1, max_prompts=8)
+    eng = Engine("tiny", device=0, weights={k: v for k, v in W.items() if k in img_keys}, max_images=3, max_prompts=8)      # windows of 3 frames per encoder pass
     vp = VideoPredictor(eng, W, num_maskmem=2)
     rng = np.random.default_rng(42)
     Z = 7
@@ -158,7 +158,7 @@ def test_tracking_loop_against_oracle(video_case):
             continue
         r, g = P.out[1]["non_cond"][t], vp.out[1]["non_cond"][t]
         e_low = _rel(g["pred_masks"].cpu(), r["pred_masks"][0, 0])
-        e_ptr = _rel(torch.from_numpy(g["obj_ptr"]), r["obj_ptr"])
+        e_ptr = _rel(g["obj_ptr"].cpu(), r["obj_ptr"])
         e_obj = abs(g["obj"] - float(r["object_score_logits"]))
         iou = ((got_out[(t, t < start)] > 0) & (ref_out[(t, t < start)] > 0)).sum().item() / max(1, ((got_out[(t, t < start)] > 0) | (ref_out[(t, t < start)] > 0)).sum().item())
         print(f"frame {t}: low-res rel-rms {e_low:.3e}, pointer rel-rms {e_ptr:.3e}, object score |diff| {e_obj:.3e} (ref {float(r['object_score_logits']):.2f}), mask IoU {iou:.4f}")
