@@ -289,7 +289,7 @@ def main():
         torch.cuda.synchronize()
         out["stitch"] = {"what": "3-D connected components of the gathered label planes on rank 0's GPU (saber_separate_masks)",
                          "slices": int(vol.shape[0]), "ms": (time.perf_counter() - t0) * 1e3, "labels": n_lab}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail:
         # hipGraph replay A/B on the same handle (the headline above runs with replay on unless SABER_AMD_GRAPHS=0)
         ab = {}
         for name, on in (("eager", False), ("graphs", True)):

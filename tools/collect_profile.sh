@@ -8,11 +8,11 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --workers 1 --no-cpu-baseline --no-encoder-only --no-tail > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --workers 1 --no-cpu-baseline --no-encoder-only --no-tail --no-video > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile --no-video > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile --no-video > $OUT/bench_write.log 2>&1
 # MFMA utilisation (north star: "rocprof MFMA utilisation"): matrix-core busy cycles summed over the SIMDs, and the GPU-active cycles
 # (summed over the 8 XCDs) of the same dispatches; SQ and GRBM counters share a pass
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile > $OUT/bench_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-profile --no-video > $OUT/bench_mfma.log 2>&1
 python3 tools/summarize_pmc.py $OUT $TAG
 ls -la $OUT
