@@ -102,6 +102,7 @@ int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const st
         return SABER_OK;
     }
     if (!e->graph_seen.count(key)) { e->graph_seen.insert(key); return body(); }
+    if (e->graphs.size() >= 256 || e->graph_seen.size() >= 4096) return body();      // a caller that never repeats a shape: stay eager, bounded memory
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e->graph_bad.insert(key); return body(); }
     const int r = body();
     hipGraph_t g = nullptr;

@@ -11,7 +11,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // A [M][K] bf16 row-major (lda = K).  Every workgroup walks tiles of 256 rows (tile = blockIdx.x + i * gridDim.x); per K-step of KS
 // elements it fetches 256 rows x KS*2 bytes for "A" and the same again for "W" (a second matrix of 256*tiles_n rows).
-template <int ROWB, bool TO_LDS, int INFLIGHT, bool PANEL = false>
+template <int ROWB, bool TO_LDS, int INFLIGHT, bool PANEL = false, bool PANEL_W_ONLY = false>
 __global__ __launch_bounds__(512) void probe(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, int M, int K, int n_issuers,
                                              unsigned long long* out_cycles, float* sink, int passes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(512) void probe(const unsigned short* __restrict__ 
                 for (int pc = wave; pc < 2 * pieces_per_operand; pc += n_issuers) {
                     const bool isw = pc >= pieces_per_operand;
                     const int pr = (isw ? pc - pieces_per_operand : pc) * ROWS_PER_PIECE + lrow;
-                    const unsigned short* src = PANEL ? (isw ? W + ((size_t)kt * 2048 + (tile % 8) * 256 + pr) * KS + lslot * 8 : A + ((size_t)kt * M + tile * 256 + pr) * KS + lslot * 8) : (isw ? W + (size_t)((tile % 8) * 256 + pr) * K : A + (size_t)(tile * 256 + pr) * K) + kt * KS + lslot * 8;
+                    const unsigned short* src = (PANEL && (isw || !PANEL_W_ONLY)) ? (isw ? W + ((size_t)kt * 2048 + (tile % 8) * 256 + pr) * KS + lslot * 8 : A + ((size_t)kt * M + tile * 256 + pr) * KS + lslot * 8) : (isw ? W + (size_t)((tile % 8) * 256 + pr) * K : A + (size_t)(tile * 256 + pr) * K) + kt * KS + lslot * 8;
                     if (TO_LDS) {
                         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + ((slot & 63) * 8 + wave) * 1024 % (128 * 1024)), 16, 0, 0);
                     } else {
@@ -57,13 +57,13 @@ __global__ __launch_bounds__(512) void probe(const unsigned short* __restrict__ 
     if (acc == 123.456f) sink[0] = acc;
 }
 
-template <int ROWB, bool TO_LDS, int INFLIGHT, bool PANEL = false>
+template <int ROWB, bool TO_LDS, int INFLIGHT, bool PANEL = false, bool PANEL_W_ONLY = false>
 void run(const char* name, const unsigned short* A, const unsigned short* W, int M, int K, int issuers, unsigned long long* cyc, float* sink, int passes) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(probe<ROWB, TO_LDS, INFLIGHT, PANEL>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe<ROWB, TO_LDS, INFLIGHT, PANEL, PANEL_W_ONLY>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((probe<ROWB, TO_LDS, INFLIGHT, PANEL>), dim3(256), dim3(512), 128 * 1024, 0, A, W, M, K, issuers, cyc, sink, passes);
+        hipLaunchKernelGGL((probe<ROWB, TO_LDS, INFLIGHT, PANEL, PANEL_W_ONLY>), dim3(256), dim3(512), 128 * 1024, 0, A, W, M, K, issuers, cyc, sink, passes);
         hipEventRecord(b); hipEventSynchronize(b);
     }
     float ms; hipEventElapsedTime(&ms, a, b);
@@ -85,6 +85,7 @@ int main() {
             run<128, true, 12>("lds-dma  8 rows x 128 B vm12", A, W, c.M, K, issuers, cyc, sink, c.passes);
             run<64, true, 8, true>("lds-dma K-panel layout (1 KB contiguous) vm8", A, W, c.M, K, issuers, cyc, sink, c.passes);
             run<64, true, 12, true>("lds-dma K-panel layout vm12", A, W, c.M, K, issuers, cyc, sink, c.passes);
+            run<64, true, 8, true, true>("lds-dma A 16x64B rows, W panel vm8", A, W, c.M, K, issuers, cyc, sink, c.passes);
         }
     }
     return 0;
