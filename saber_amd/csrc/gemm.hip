@@ -870,249 +870,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// The same kernel with the A operand fed in 64-deep pieces (gemm_bf16_p256k_kernel).  tools/probes/dma_probe.hip: a CU's LDS-DMA intake
-// from L2 tops out at 44 GB/s when a 1-KB piece is 16 rows x 64 B (a 32-deep K-step of a row-major operand: 16 half-used lines per
-// instruction), at 62 GB/s for 8 rows x 128 B, at 57 GB/s for a contiguous KB; the 256x256 kernel measures 45 GB/s.  Here
-//   * A goes through a ring of THREE 64-deep stages (256 rows x 128 B = 32 KB each): a piece = 8 rows x 128 B = 8 whole lines; chunk c of
-//     row r sits at slot c ^ (r & 7) of the row (conflict-free ds_read_b128 for both 32-deep halves), a super-tile's two halves are
-//     consumed by two consecutive K-tiles of the unchanged 32-deep MFMA schedule;
-//   * W comes K-step-packed (launch_pack_w_kstep: a piece = one contiguous KB) through a ring of three 32-deep stages (16 KB each);
-//   * per K-tile every wave still issues 4 pieces (2 of A's super-tile four K-tiles ahead, 2 of W two K-tiles ahead); LDS = 96 + 48 +
-//     16 KB (epilogue staging) = the whole 160 KB.
-// Needs K % 64 == 0 and the packed W; everything else (persistent tile walk, staggered wave groups, epilogue) is the kernel above.
-#define P2K_A_STAGE (256 * 128)
-#define P2K_W_STAGE (256 * 64)
-#define P2K_LDS (3 * P2K_A_STAGE + 3 * P2K_W_STAGE + 8 * 2048)
-__device__ __forceinline__ int swzk(int row, int chunk8) { return row * 128 + ((chunk8 ^ (row & 7)) << 4); }
-
-template <bool STAMPS>
-__global__ __launch_bounds__(512) void gemm_bf16_p256k_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* w_ring = smem + 3 * P2K_A_STAGE;
-    char* epi_lds = w_ring + 3 * P2K_W_STAGE;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves: rows 128 wm .., columns 64 wn ..
-    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-    const int padded = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    const int64_t z = blockIdx.z;
-    const bf16_t* __restrict__ A = p.A + z * p.strideA;
-    const bf16_t* __restrict__ W = p.W + z * p.strideW;
-    const int fi = lane & 15, fg = lane >> 4;
-    const int nk = (p.K + BK2 - 1) / BK2;
-
-    // W: one wave-instruction = 16 rows x 64 B of the packed copy (contiguous KB), 2 per wave and K-tile;
-    // A: one wave-instruction = 8 rows x 128 B, 4 per wave and 64-deep super-tile
-    const int lrow = lane >> 2, lslot = lane & 3;
-    const int arow8 = lane >> 3, aslot8 = lane & 7;
-    auto next_tile = [&](int L, int* tm, int* tn) {
-        while (L < padded && !tile_map(L, tiles_m, tiles_n, tm, tn)) L += gridDim.x;
-        return L;
-    };
-    // two issue cursors over the same stream of (tile, K-tile): W runs 2 K-tiles ahead of the consumer, A 2 super-tiles ahead
-    int Liw, tmw = 0, tnw = 0, ktw = 0, sw_i = 0;          // W cursor: tile slot, its coordinates, K-tile, ring stage
-    int Lia, tma = 0, tna = 0, kta = 0, sa_i = 0;          // A cursor: tile slot, coordinates, super-tile, ring stage
-    const int64_t wpk_kstride = (int64_t)p.N * 32;
-    const int nks = nk >> 1;                               // super-tiles per output tile
-    // per-lane source addresses are rebuilt per piece from two ints (pointer arrays cost 12 VGPRs here: 9 spills)
-    int w_row0 = 0, a_row0 = 0;
-    const int a_coff = (aslot8 ^ arow8) << 3;              // (row & 7) == arow8 for every piece: rows advance by 8
-    auto set_w_tile = [&]() { w_row0 = tnw * 256 + wave * 32 + lrow; };
-    auto set_a_tile = [&]() { a_row0 = tma * 256 + wave * 32 + arow8; };
-    auto issue_w = [&]() {                                 // both W pieces of the cursor's K-tile, then advance
-        char* sw = w_ring + sw_i * P2K_W_STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.Wpk + ((int64_t)min(w_row0 + 16 * i, p.N - 1) * 4 + lslot) * 8 + (int64_t)ktw * wpk_kstride), (lptr_t)(sw + (wave * 2 + i) * 1024), 16, 0, 0);
-        sw_i = sw_i == 2 ? 0 : sw_i + 1;
-        if (++ktw == nk) {
-            ktw = 0;
-            Liw = next_tile(Liw + gridDim.x, &tmw, &tnw);
-            if (Liw < padded) set_w_tile();
-        }
-    };
-    auto issue_a_half = [&](int h) {                       // pieces 2h, 2h+1 of the cursor's super-tile; the second half advances
-        char* sa = smem + sa_i * P2K_A_STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = 2 * h + j;
-            __builtin_amdgcn_global_load_lds((gptr_t)(A + (int64_t)min(a_row0 + 8 * i, p.M - 1) * p.lda + a_coff + kta * 64), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
-        }
-        if (h) {
-            sa_i = sa_i == 2 ? 0 : sa_i + 1;
-            if (++kta == nks) {
-                kta = 0;
-                Lia = next_tile(Lia + gridDim.x, &tma, &tna);
-                if (Lia < padded) set_a_tile();
-            }
-        }
-    };
-    int step = 0;                                          // issue steps done (one per consumed K-tile): step s puts W(s + 2) and half of A((s + 4) / 2) in flight
-    int last_cnt = 0;                                      // pieces the most recent step issued (4, or 2 / 0 where the stream ends)
-    auto issue = [&]() {
-        last_cnt = 0;
-        if (Lia < padded) { issue_a_half(step & 1); last_cnt += 2; }
-        if (Liw < padded) { issue_w(); last_cnt += 2; }
-        ++step;
-    };
-    Liw = next_tile(blockIdx.x, &tmw, &tnw);
-    if (Liw >= padded) return;                     // block-uniform
-    Lia = Liw; tma = tmw; tna = tnw;
-    set_w_tile(); set_a_tile();
-    int Lc = Liw, tmc = tmw, tnc = tnw, ktc = 0, sc = 0;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bias4[4];
-    auto load_bias = [&](int tn) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = tn * 256 + wn * 64 + j * 16 + fg * 4;
-            // unconditional load from a clamped address + select: a load inside a branch is waited for on its own with vmcnt(0), which
-            // here also drains the LDS-DMA pieces in flight
-            const float4 bv = *reinterpret_cast<const float4*>((p.bias ? p.bias + z * p.strideBias : reinterpret_cast<const float*>(p.W)) + min(n, p.N - 4));
-            bias4[j] = (p.bias && n + 3 < p.N) ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    load_bias(tnc);
-    // STAGGERED: the two wave groups (rows 0-127: waves 0-3, rows 128-255: waves 4-7; wave w and w + 4 share a SIMD) run half an
-    // iteration apart.  In every half-step one group of each SIMD feeds the matrix core with the 32 MFMAs of its K-tile while the
-    // other one does the memory work - 12 fragment reads of the next K-tile and 4 LDS-DMA issues - behind them:
-    //     half-step 2t     : group 0  MFMA(t)                    | group 1  read(t), issue(t + 3)
-    //     half-step 2t + 1 : group 0  read(t + 1), issue(t + 3)  | group 1  MFMA(t)
-    // The stage of K-tile t - 1 is free from half-step 2t - 1 on (group 1 read it in 2t - 2), which is when tile t + 3 goes into it;
-    // tile t + 1 was issued in half-steps 2t - 4 / 2t - 3 and must have landed (own pieces, counted vmcnt) before the barrier that
-    // ends half-step 2t.
-    const int grp = wave >> 2;
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define P2S_STAMP(k) do { if (STAMPS) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
-    int computed = 0;                               // K-tiles of the stream consumed so far (index of the current one)
-    // prologue: A super-tiles 0 and 1, W K-tiles 0 and 1 (nk >= 4: guaranteed by the launcher); issue order A0 W0 A1 W1
-    issue_a_half(0); issue_a_half(1); issue_w(); issue_a_half(0); issue_a_half(1); issue_w();
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // A0 and W0 landed (own pieces)
-    __builtin_amdgcn_s_barrier();
-    bf16x8 af[8], wf[4];
-    auto read_frags = [&](int t) {                  // fragments of stream K-tile t: W stage t % 3, A stage (t / 2) % 3, half t & 1
-        const char* sa = smem + ((t >> 1) % 3) * P2K_A_STAGE;
-        const char* sw = w_ring + (t % 3) * P2K_W_STAGE;
-        const int hb = (t & 1) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + j * 16 + fi, fg));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + swzk(wm * 128 + i * 16 + fi, hb + fg));
-    };
-    // The MFMA cluster must stay inside its half-step: MFMAs touch no memory, so hipcc is free to move them across the raw barriers and
-    // the inline-asm waits (it did, depending on unrelated edits: 305 us <-> 335 us on the fc1 shape).  s_setprio around the cluster
-    // keeps it together (cdna_hip_programming.md T5) and sched_barrier(0) pins its place.
-    auto mfma_tile = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // Everything issued through step t - 1 has landed (own pieces): W(t + 1) and both halves of its A super-tile.  What may still be in
-    // flight are the 4 pieces of step t, if this wave has issued it already (group 1 issues before it waits, group 0 after).
-    auto wait_tile = [&](int t) {
-        const int fly = step > t ? last_cnt : 0;
-        if (fly == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (fly == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto epilogue = [&]() {
-        const int m0 = tmc * 256, n0 = tnc * 256;
-        bf16_t* Cb = p.Cb + z * p.strideCb;
-        const uint32_t tb_a = (uint32_t)(uintptr_t)(lptr_t)(epi_lds + wave * 2048);
-        const uint32_t tb_r0 = tb_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);   // rows 0-7; rows 8-15 are +1024 (same swizzle)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
-                if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }                                              // (only ACT_NONE / ACT_GELU are routed to this kernel)
-                const int chunk = j * 2 + (fg >> 1);
-                // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS loads in
-                // flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous rows
-                const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
-                asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            u32x4 val0, val1;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(val0), "=&v"(val1) : "v"(tb_r0), "v"(tb_r0 + 1024) : "memory");
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = it * 8 + (lane >> 3), chunk = lane & 7;
-                const int m = m0 + wm * 128 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
-                if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
-            }
-        }
-        ktc = 0;
-        Lc = next_tile(Lc + gridDim.x, &tmc, &tnc);
-        if (Lc < padded) load_bias(tnc);
-    };
-    if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
-    // two straight-line loops (one per group) with the same barrier sequence: a single loop that branches on the group inside
-    // every half-step made hipcc spill 215 VGPRs
-    // (All four LDS-DMA issues stay in the memory half-step: moving two of them between the MFMAs made the pieces land later and
-    // the MFMA half-step longer - 330 us instead of 303 us on the fc1 shape.)
-    const bool more = true;
-    if (grp == 0) {
-        read_frags(0);
-        while (Lc < padded) {
-            const int t = computed;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mfma_tile();                                    // half-step 2t
-            P2S_STAMP(0);
-            wait_tile(t);
-            P2S_STAMP(1);
-            __builtin_amdgcn_s_barrier();
-            P2S_STAMP(2);
-            read_frags(t + 1);                              // half-step 2t + 1 (a surplus read of a stale stage at the stream's end is harmless)
-            issue();
-            P2S_STAMP(3);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            ++computed;
-            if (++ktc == nk) { epilogue(); P2S_STAMP(4); }
-            P2S_STAMP(5);
-        }
-    } else {
-        while (Lc < padded) {
-            const int t = computed;
-            read_frags(t);                                  // half-step 2t
-            issue();
-            P2S_STAMP(0);
-            wait_tile(t);
-            P2S_STAMP(1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            P2S_STAMP(2);
-            mfma_tile();                                    // half-step 2t + 1
-            P2S_STAMP(3);
-            __builtin_amdgcn_s_barrier();
-            ++computed;
-            if (++ktc == nk) { epilogue(); P2S_STAMP(4); }
-            P2S_STAMP(5);
-        }
-    }
-    (void)more; (void)sc;
-    if (STAMPS && lane == 0)
-        for (int k = 0; k < 6; ++k) p.stamps[((int64_t)blockIdx.x * 8 + wave) * 6 + k] = ts[k];
-}
-
-
 #define GS_LDS_128 (3 * (128 * BK * 2 + BN * BK * 2) + 4 * 2048)
 #define GS_LDS_256 (3 * (256 * BK * 2 + BN * BK * 2) + 8 * 2048)
 
@@ -1124,8 +881,7 @@ const char* gemm_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256k_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P2K_LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p256k_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P2K_LDS);
+
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
@@ -1155,10 +911,7 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);
-        const bool k64 = p.Wpk && (p.K % 64) == 0 && p.K >= 256 && p.batch <= 1 && (p.dbg & 32768);      // 64-deep A pieces (development switch until measured)
-        if (k64 && p.stamps) hipLaunchKernelGGL(gemm_bf16_p256k_kernel<true>, dim3(slots < 256 ? slots : 256), dim3(512), P2K_LDS, stream, p);
-        else if (k64) hipLaunchKernelGGL(gemm_bf16_p256k_kernel<false>, dim3(slots < 256 ? slots : 256), dim3(512), P2K_LDS, stream, p);
-        else if (p.stamps) hipLaunchKernelGGL(gemm_bf16_p256s_kernel<true>, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);   // development build with cycle stamps
+        if (p.stamps) hipLaunchKernelGGL(gemm_bf16_p256s_kernel<true>, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);   // development build with cycle stamps
         else hipLaunchKernelGGL(gemm_bf16_p256s_kernel<false>, dim3(slots < 256 ? slots : 256), dim3(512), P2_LDS, stream, p);
     } else if (direct_ok && tiles256 >= 512 && !(p.dbg & 16)) {
         // two co-resident workgroups per CU: one's epilogue overlaps the other's main loop
