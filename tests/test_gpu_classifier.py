@@ -97,3 +97,12 @@ def test_saber2d_hook_runs_the_classifier(setup):
         assert np.array_equal(a["segmentation"], b["segmentation"]) and a["area"] == b["area"] and abs(a["predicted_iou"] - b["predicted_iou"]) < 2.5e-3
     sem = fm.apply_classifier(G["image"], list(dicts), pred, 0, 32)
     assert [m["label"] for m in sem] == [1, 2]
+
+
+def test_reference_script_assertions_finite_and_repeatable(setup):
+    """The reference's classifier test script (saber/classifier/tests/test_sam3_classifier.py:73-77,144-145): probabilities of the right
+    shape, finite, and two runs on the same input equal (there within 1e-4; here bit-identical)."""
+    eng, pred, ref, cr = setup
+    a = pred.predict(G["image"], G["masks"][:3])
+    b = pred.predict(G["image"], G["masks"][:3])
+    assert a.shape == (3, NC) and np.isfinite(a).all() and np.array_equal(a, b)

@@ -194,3 +194,28 @@ def test_segment_volume_adapter_against_oracle(video_case):
     assert inter / max(1, uni) > 0.997 and np.abs(ps_e - ps_r).max() < 0.02                # measured 0.9988 / 7e-3
     with pytest.raises(RuntimeError, match="set_volume"):
         SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0").segment_volume(0, [], (3, 8, 8))
+
+
+def test_reference_script_assertions_shape_dtype_and_reset(video_case):
+    """What the reference's own adapter test script asserts (saber/adapters/sam3/tests/test_tomogram_predictor.py:75-81,139-142,150-169,
+    written for the SAM3 adapter against the same BaseAdapter contract): the loaded state counts Z frames, segment_volume returns
+    (Z,H,W) uint16, reset_state clears the prompts."""
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.predictor import SAM2Adapter
+    cfg, W, vp, tomo, seed = video_case
+    ad = SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0")
+    ad._video_predictor = vp
+    ad.set_volume(tomo)
+    assert ad.inference_state.num_frames == tomo.shape[0] and tuple(ad.inference_state.images.shape) == (tomo.shape[0], 1024, 1024)
+    vol = ad.segment_volume(3, masks=[seed], max_frame_num_to_track=2, min_presence_score=0.0)
+    assert vol.shape == tomo.shape and vol.dtype == np.uint16
+    assert not vol[0].any() and not vol[6].any()                 # max_frame_num_to_track = 2: frames 1..5 only
+    ad.add_new_mask(frame_idx=0, obj_id=99, mask=np.ones((128, 128), dtype=np.float32) * 0.5)
+    assert 99 in ad.inference_state.obj_ids
+    ad.reset_state()
+    assert len(ad.inference_state.obj_ids) == 0 and not ad.inference_state.out
+    st = ad.inference_state                                      # an object without any prompt: upstream's preflight error
+    st.obj_ids.append(1); st.out[1] = {"cond": {}, "non_cond": {}}; st.temp[1] = {}
+    with pytest.raises(RuntimeError, match="No input points or masks"):
+        list(ad.propagate_in_video(0))
+    ad.reset_state()
