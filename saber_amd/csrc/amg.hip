@@ -120,10 +120,12 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     if (e->amg_prompts_cap < max_prompts) {
         TRY(eng_regrow(e, &e->amg_pts, max_pts * 2, s));
         TRY(eng_regrow(e, &e->amg_pts2, max_prompts * 2, s));
-        TRY(eng_regrow(e, &e->amg_low1, max_prompts * 65536, s));
+        // the decoder leaves all 4 low-res planes of a prompt in place (no selection copies): first pass max_pts x 4, m2m pass max_prompts x 4
+        TRY(eng_regrow(e, &e->amg_low1, max_pts * 4 * 65536, s));
         TRY(eng_regrow(e, &e->amg_iou1, max_prompts, s));
-        TRY(eng_regrow(e, &e->amg_low2, max_prompts * 65536, s));
+        TRY(eng_regrow(e, &e->amg_low2, max_prompts * 4 * 65536, s));
         TRY(eng_regrow(e, &e->amg_iou2, max_prompts, s));
+        TRY(eng_regrow(e, &e->amg_sel, max_prompts, s));
         e->amg_prompts_cap = max_prompts;
     }
     if (e->amg_stats_cap < max_prompts) {
@@ -156,7 +158,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     };
     std::vector<float> h_iou;
     std::vector<MaskStats> h_stats;
-    std::vector<int> h_idx;
+    std::vector<int> h_idx, h_plane;
     std::vector<float> h_pts, h_pts2;
 
     // engine-owned copy of the image: the encoder pass below is replayed from a hipGraph whose launches hold its address
@@ -187,6 +189,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             const int gn = grid_n[layer];
             const int np = gn * gn;                 // points per crop
             const int nm = np * M;                  // masks per crop
+            const int first_raw = prm->multimask_output ? 1 : 0;     // the multimask first pass leaves its 4 planes per prompt in place (read through index maps)
             h_pts.resize((size_t)G * np * 2);
             std::vector<float> crop_pts_all((size_t)G * np * 2);
             for (int g = 0; g < G; ++g) {
@@ -203,23 +206,27 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             }
             ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * G * np, hipMemcpyHostToDevice, s));
             TRY(eng_graphed(e, "dec1," + key_of({ci, np, (long long)(uintptr_t)e->amg_pts, G * np, prm->multimask_output, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_iou1}), s,
-                            [&]() { return eng_decode(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, 0.f, e->amg_low1, e->amg_iou1, nullptr, s); }));
+                            [&]() { return eng_decode_ex(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, 0, 0.f, e->amg_low1, first_raw, e->amg_iou1, nullptr, nullptr, s); }));
             for (int g = 0; g < G; ++g) e->slot_shared_valid[ci + g] = 1;      // (bookkeeping of the first-pass decode, for replays)
             const float* masks = e->amg_low1;
             const float* ious = e->amg_iou1;
+            int plane_mode = first_raw ? 1 : 0;                   // where K8 finds candidate k: 0 plane k, 1 plane 4 (k / 3) + 1 + k % 3, 2 plane 4 k + sel[k]
             if (prm->use_m2m) {
                 // the predictor's clamp of the returned low-res logits to +-32 is applied where they are read back as the mask prompt
                 h_pts2.resize((size_t)G * nm * 2);
                 for (size_t k = 0; k < (size_t)G * np; ++k)
                     for (int m = 0; m < M; ++m) { h_pts2[2 * (k * M + m)] = h_pts[2 * k]; h_pts2[2 * (k * M + m) + 1] = h_pts[2 * k + 1]; }
                 ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * G * nm, hipMemcpyHostToDevice, s));
-                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)e->amg_pts2, G * nm, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_low2, (long long)(uintptr_t)e->amg_iou2}), s,
-                                [&]() { return eng_decode(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, 32.0f, e->amg_low2, e->amg_iou2, nullptr, s); }));
+                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)e->amg_pts2, G * nm, first_raw, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_low2, (long long)(uintptr_t)e->amg_iou2, (long long)(uintptr_t)e->amg_sel}), s,
+                                [&]() { return eng_decode_ex(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, first_raw, 32.0f, e->amg_low2, 1, e->amg_iou2, nullptr, e->amg_sel, s); }));
                 masks = e->amg_low2;
                 ious = e->amg_iou2;
+                plane_mode = 2;
             }
             std::vector<float> h_iou_all((size_t)G * nm);
+            std::vector<int> h_sel;
             ENG_HIP(e, hipMemcpyAsync(h_iou_all.data(), ious, sizeof(float) * G * nm, hipMemcpyDeviceToHost, s));
+            if (plane_mode == 2) { h_sel.resize((size_t)G * nm); ENG_HIP(e, hipMemcpyAsync(h_sel.data(), e->amg_sel, sizeof(int) * G * nm, hipMemcpyDeviceToHost, s)); }
             { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }                                   // sync 1 of 2 per decoded group
             // pred_iou filter of every crop of the group on the host, then K8 for ALL of them (one launch per crop, no host round trip in
             // between) into one scratch, ONE copy of the per-mask scalars back: 2 host synchronisations per group of crops instead of
@@ -235,7 +242,11 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             const int ns_all = (int)h_idx.size();
             if (ns_all == 0) continue;
             TRY(crop_reserve((size_t)ns_all));
-            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_idx.data(), sizeof(int) * ns_all, hipMemcpyHostToDevice, s));
+            // K8 reads the chosen plane in place: candidate k of the group lives at plane 4 (k / 3) + 1 + k % 3 (multimask pass) or
+            // 4 k + sel[k] (single-mask pass) of the 4-plane buffer
+            h_plane.resize(ns_all);
+            for (int j = 0; j < ns_all; ++j) { const int k = h_idx[j]; h_plane[j] = plane_mode == 1 ? 4 * (k / 3) + 1 + k % 3 : plane_mode == 2 ? 4 * k + h_sel[k] : k; }
+            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_plane.data(), sizeof(int) * ns_all, hipMemcpyHostToDevice, s));
             for (int g = 0; g < G; ++g) {
                 const int ns = g_first[g + 1] - g_first[g];
                 if (ns == 0) continue;

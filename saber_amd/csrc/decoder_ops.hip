@@ -47,7 +47,7 @@ template <bool MFMA2>
 __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __restrict__ mask_in, int P,
                                                              const float* __restrict__ image_embed_base, XMap em, const float* __restrict__ pos,
                                                              MaskEmbedWeights w, float* __restrict__ src_f,
-                                                             bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf, float clamp_abs) {
+                                                             bf16_t* __restrict__ src_bf, bf16_t* __restrict__ srcpos_bf, float clamp_abs, int raw4_q0) {
     // one block = 64 tokens x ME_NP consecutive prompts: the image-embedding rows (fp32, shared by every prompt of the crop) are
     // read once per block instead of once per prompt
     __shared__ __attribute__((aligned(16))) float h2s[ME_NP][64][20];
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
         const int py = q >> 1, px = q & 1;
         int ty, tx;
         perm_coords(tok0 + tl, 2, &ty, &tx);
-        const float* mp = mask_in + (int64_t)p * 65536 + (int64_t)(ty * 4 + py * 2) * 256 + tx * 4 + px * 2;
+        // raw4_q0 >= 0: mask_in is the 4-plane-per-prompt output of a multimask decode, prompt q = raw4_q0 + p refines plane 1 + q % 3 of prompt q / 3
+        const int64_t plane = raw4_q0 >= 0 ? (int64_t)(raw4_q0 + p) + (raw4_q0 + p) / 3 + 1 : (int64_t)p;
+        const float* mp = mask_in + plane * 65536 + (int64_t)(ty * 4 + py * 2) * 256 + tx * 4 + px * 2;
         const float2 r0 = *reinterpret_cast<const float2*>(mp), r1 = *reinterpret_cast<const float2*>(mp + 256);
         // clamp_abs: SAM2ImagePredictor._predict clamps the low-res logits it hands back to +-32 before they are re-used as a mask
         // prompt; the AMG driver passes the raw first-pass logits and has the clamp applied here instead of in a pass of its own
@@ -221,13 +223,13 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
 }
 
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap em, const float* pos, MaskEmbedWeights w,
-                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s) {
+                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s, int raw4_q0) {
     if (P <= 0) return nullptr;
     if (em.div <= 0) return "mask_embed_src: XMap.div must be positive";
     if (!(clamp_abs > 0.f)) clamp_abs = 3.0e38f;
     const dim3 grid(((P + ME_NP - 1) / ME_NP) * 64);
-    if (!src_f && !srcpos_bf && src_bf) hipLaunchKernelGGL(mask_embed_src_kernel<true>, grid, dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs);
-    else hipLaunchKernelGGL(mask_embed_src_kernel<false>, grid, dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs);
+    if (!src_f && !srcpos_bf && src_bf) hipLaunchKernelGGL(mask_embed_src_kernel<true>, grid, dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs, raw4_q0);
+    else hipLaunchKernelGGL(mask_embed_src_kernel<false>, grid, dim3(256), 0, s, mask_in, P, image_embed, em, pos, w, src_f, src_bf, srcpos_bf, clamp_abs, raw4_q0);
     return nullptr;
 }
 
@@ -478,6 +480,49 @@ __global__ __launch_bounds__(1024) void mask_select_dynamic_kernel(const float* 
     float4* dst = reinterpret_cast<float4*>(out_masks + (int64_t)p * 65536);
 #pragma unroll 4
     for (int i = tid; i < 16384; i += 1024) dst[i] = src[i];
+}
+
+// The selection alone, for callers that read the chosen planes in place (the AMG driver: K8 takes a plane index, the m2m pass reads the
+// first pass's planes through an index map): out_iou as mask_select*, out_sel[p] = chosen plane of prompt p (single-mask mode).
+__global__ __launch_bounds__(1024) void mask_pick_kernel(const float* __restrict__ masks4, const float* __restrict__ iou4, int multimask,
+                                                         float* __restrict__ out_iou, int* __restrict__ out_sel, float delta, float thresh) {
+    __shared__ int red[2][16];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (multimask) {
+        if (tid < 3) out_iou[p * 3 + tid] = iou4[p * 4 + 1 + tid];
+        return;
+    }
+    const float4* m0 = reinterpret_cast<const float4*>(masks4 + (int64_t)p * 4 * 65536);
+    int a = 0, u = 0;
+#pragma unroll 4
+    for (int i = tid; i < 16384; i += 1024) {
+        const float4 v = m0[i];
+        a += (v.x > delta) + (v.y > delta) + (v.z > delta) + (v.w > delta);
+        u += (v.x > -delta) + (v.y > -delta) + (v.z > -delta) + (v.w > -delta);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); u += __shfl_xor(u, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = u; }
+    __syncthreads();
+    if (tid == 0) {
+        int ai = 0, au = 0;
+        for (int w = 0; w < 16; ++w) { ai += red[0][w]; au += red[1][w]; }
+        const float stab = au > 0 ? (float)ai / (float)au : 1.0f;
+        int sel = 0;
+        if (!(stab >= thresh)) {
+            sel = 1;
+            float best = iou4[p * 4 + 1];
+            if (iou4[p * 4 + 2] > best) { best = iou4[p * 4 + 2]; sel = 2; }
+            if (iou4[p * 4 + 3] > best) { best = iou4[p * 4 + 3]; sel = 3; }
+        }
+        out_iou[p] = iou4[p * 4 + sel];
+        if (out_sel) out_sel[p] = sel;
+    }
+}
+const char* launch_mask_pick(const float* masks4, const float* iou4, int P, int multimask, float* out_iou, int* out_sel, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(mask_pick_kernel, dim3(P), dim3(multimask ? 64 : 1024), 0, s, masks4, iou4, multimask, out_iou, out_sel, 0.05f, 0.98f);
+    return nullptr;
 }
 
 const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,

@@ -99,6 +99,7 @@ struct saber_engine {
 
     // AMG workspace (grown on demand)
     float *amg_prep = nullptr; size_t amg_prep_elems = 0;
+    int* amg_sel = nullptr;
     float *amg_pts = nullptr, *amg_low1 = nullptr, *amg_low2 = nullptr, *amg_iou1 = nullptr, *amg_iou2 = nullptr, *amg_pts2 = nullptr;
     size_t amg_prompts_cap = 0;
     uint32_t* amg_bits = nullptr; size_t amg_bits_words = 0;        // masks kept across crops (persistent, grown on demand)
@@ -169,6 +170,12 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
 // mask_clamp > 0: the mask prompt is clamped to +-mask_clamp as it is read (SAM2ImagePredictor clamps the logits it returns to +-32)
 int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                const float* mask_in_dev, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s);
+// out_raw4: out_lowres receives ALL 4 low-res planes of every prompt ([n][4][256*256]) and no selection copy is made: out_iou holds the
+// IoUs of planes 1-3 (multimask) or of the chosen plane, out_sel the chosen plane (single-mask mode).  mask_in_raw4: mask_in_dev is such a
+// buffer from a multimask decode and prompt q refines plane 1 + q % 3 of its prompt q / 3.
+int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
+                  const float* mask_in_dev, int mask_in_raw4, float mask_clamp, float* out_lowres, int out_raw4, float* out_iou, float* out_obj,
+                  int* out_sel, hipStream_t s);
 template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count);
 int eng_alloc_bytes(saber_engine* e, void** p, size_t bytes);
 void eng_free(saber_engine* e, void* p);

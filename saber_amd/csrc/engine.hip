@@ -945,8 +945,11 @@ static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
 
 // One chunk of P prompts.  The prompts may span several consecutive slots (crops of one AMG layer batched together): prompt p of
 // the chunk reads the features of slot slot0 + (p_base + p) / per_slot.
+// raw4_out: the chunk's 4 low-res planes per prompt are written there and stay (no selection copy: out_iou / out_sel say which to read);
+// mask_in_q0 >= 0: mask_in is the raw 4-plane output of a multimask decode, this chunk's first prompt refines global candidate mask_in_q0
 static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, int multimask,
-                        const float* mask_in, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+                        const float* mask_in, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s,
+                        float* raw4_out = nullptr, int* out_sel = nullptr, int mask_in_q0 = -1) {
     const int T = 8;
     const int PT = P * T;
     const size_t o256 = (size_t)slot0 * 4096 * 256;
@@ -965,7 +968,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         for (int sl = slot0 + p_base / per_slot; sl <= slot_last; ++sl) TRY(ensure_shared(e, sl, s));
         X = e->src0_bf + o256; xm = slots;
     } else {
-        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, slots, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, mask_clamp, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, slots, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, mask_clamp, s, mask_in_q0));
         X = e->keys_bf; xm = per_prompt;
     }
 
@@ -1045,15 +1048,24 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
            launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot0 * 16384 * 64,
-                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, e->masks4, P, s));
-    float* om = out_lowres ? out_lowres : e->dec_out_masks;
+                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, raw4_out ? raw4_out : e->masks4, P, s));
     float* oi = out_iou ? out_iou : e->dec_out_iou;
+    if (raw4_out) {
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s));
+        return SABER_OK;
+    }
+    float* om = out_lowres ? out_lowres : e->dec_out_masks;
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
     return SABER_OK;
 }
 
 int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                const float* mask_in_dev, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s) {
+    return eng_decode_ex(e, slot, per_slot, pts_dev, labels_dev, n, multimask, mask_in_dev, 0, mask_clamp, out_lowres, 0, out_iou, out_obj, nullptr, s);
+}
+int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
+                  const float* mask_in_dev, int mask_in_raw4, float mask_clamp, float* out_lowres, int out_raw4, float* out_iou, float* out_obj,
+                  int* out_sel, hipStream_t s) {
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
     if (!pts_dev || n < 0 || per_slot < 0) return eng_fail(e, SABER_ERR_INVALID, "decode: bad argument");
     if (per_slot == 0 || per_slot > n) per_slot = n > 0 ? n : 1;      // every prompt reads slot `slot`
@@ -1063,10 +1075,12 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
     const int M = multimask ? 3 : 1;
     for (int p0 = 0; p0 < n; p0 += e->max_prompts) {
         const int P = std::min(e->max_prompts, n - p0);
+        const float* min_ = !mask_in_dev ? nullptr : mask_in_raw4 ? mask_in_dev : mask_in_dev + (size_t)p0 * 65536;
         TRY(decode_chunk(e, slot, per_slot, p0, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
-                         mask_in_dev ? mask_in_dev + (size_t)p0 * 65536 : nullptr, mask_clamp,
-                         out_lowres ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
-                         out_obj ? out_obj + p0 : nullptr, s));
+                         min_, mask_clamp,
+                         out_lowres && !out_raw4 ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
+                         out_obj ? out_obj + p0 : nullptr, s, out_raw4 ? out_lowres + (size_t)p0 * 4 * 65536 : nullptr,
+                         out_sel ? out_sel + p0 : nullptr, mask_in_dev && mask_in_raw4 ? p0 : -1));
     }
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;

@@ -95,7 +95,7 @@ struct MaskEmbedWeights {
 // launch, `div` consecutive prompts per crop (slot): {slot stride, div, index of the launch's first prompt within the batch}.
 struct XMap { int64_t stride; int div; int off; };
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap emb_map, const float* pos, MaskEmbedWeights w,
-                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s);   // clamp_abs > 0: mask_in is clamped to +-clamp_abs on load
+                                  float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s, int raw4_q0 = -1);   // clamp_abs > 0: mask_in is clamped to +-clamp_abs on load
 
 // fp32 multi-head attention for the two-way transformer.  q [B][nq][heads*hd], k/v [B or 1][nk][heads*hd].
 // Output is bf16 (it always feeds the out_proj GEMM).
@@ -105,6 +105,7 @@ const char* launch_dec_attention(const float* q, const float* k, const float* v,
 // masks[p][k][y][x] = sum_c hyper[p][k][c] * up[p][perm(y,x)][c]  (up: bf16 [P][65536][32], engine token order)
 const char* launch_mask_dot(const bf16_t* up, const float* hyper, int P, float* masks4, hipStream_t s);
 // multimask: out[p][0..2] = masks4[p][1..3], iou_out = iou4[:,1:]; else dynamic single-mask selection (delta 0.05 / thr 0.98)
+const char* launch_mask_pick(const float* masks4, const float* iou4, int P, int multimask, float* out_iou, int* out_sel, hipStream_t s);
 const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,
                                int* counts_ws, hipStream_t s);
 
