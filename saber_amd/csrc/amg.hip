@@ -107,14 +107,13 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         grids[l].resize(n);
         for (int i = 0; i < n; ++i) grids[l][i] = n == 1 ? off : off + (1.0 - 2.0 * off) * (double)i / (double)(n - 1);
     }
-    // crops of one layer that were encoded together are decoded as ONE batch (per-slot feature lookup inside the kernels), so
-    // the work buffers hold the largest such group
+    // every decode of an encoder batch (up to max_images crops, all their layers) writes into one set of buffers, so they hold the
+    // largest batch's points / candidates
     size_t max_pts = 0;
-    {
-        std::vector<int> per_layer(prm->crop_n_layers + 1, 0);
-        for (int l : layers) per_layer[l]++;
-        for (int l = 0; l <= prm->crop_n_layers; ++l)
-            max_pts = std::max(max_pts, (size_t)std::min(per_layer[l], e->max_images) * grid_n[l] * grid_n[l]);
+    for (int c0 = 0; c0 < (int)crops.size(); c0 += e->max_images) {
+        size_t n = 0;
+        for (int i = c0; i < std::min((int)crops.size(), c0 + e->max_images); ++i) n += (size_t)grid_n[layers[i]] * grid_n[layers[i]];
+        max_pts = std::max(max_pts, n);
     }
     const size_t max_prompts = max_pts * M;
     if (e->amg_prompts_cap < max_prompts) {
@@ -123,10 +122,14 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         // the decoder leaves all 4 low-res planes of a prompt in place (no selection copies): first pass max_pts x 4, m2m pass max_prompts x 4
         TRY(eng_regrow(e, &e->amg_low1, max_pts * 4 * 65536, s));
         TRY(eng_regrow(e, &e->amg_iou1, max_prompts, s));
-        TRY(eng_regrow(e, &e->amg_low2, max_prompts * 4 * 65536, s));
+        TRY(eng_regrow(e, &e->amg_low2, prm->use_m2m ? max_prompts * 4 * 65536 : 4, s));
         TRY(eng_regrow(e, &e->amg_iou2, max_prompts, s));
         TRY(eng_regrow(e, &e->amg_sel, max_prompts, s));
         e->amg_prompts_cap = max_prompts;
+        e->amg_m2m_sized = prm->use_m2m != 0;
+    } else if (prm->use_m2m && !e->amg_m2m_sized) {
+        TRY(eng_regrow(e, &e->amg_low2, e->amg_prompts_cap * 4 * 65536, s));
+        e->amg_m2m_sized = true;
     }
     if (e->amg_stats_cap < max_prompts) {
         TRY(eng_regrow(e, &e->amg_stats, max_prompts, s));
@@ -183,92 +186,130 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             // host-side bookkeeping of eng_encode, which a replay does not execute
             for (int i = 0; i < ncb; ++i) { e->slot_valid[i] = 1; e->slot_shared_valid[i] = 0; }
         }
+        // ---- the crops of one layer that were encoded together are decoded as ONE batch of prompts; all groups of the encoder batch
+        // are decoded back to back WITHOUT a host round trip, then the per-candidate scalars come back once (sync 1), K8 runs for every
+        // crop, its per-mask statistics come back once (sync 2), and the filters / NMS run on the host: 3 synchronisations per slice
+        // with the final one (24 in round 1, 7 with one pair per group).
+        struct Grp { int ci, G, layer, gn, np, nm; size_t pt0, k0; int plane_mode; const float* masks; const float* ious; };
+        std::vector<Grp> groups;
+        size_t n_pts = 0;
         for (int ci = 0, G = 1; ci < ncb; ci += G) {
             const int layer = layers[c0 + ci];
             for (G = 1; ci + G < ncb && layers[c0 + ci + G] == layer; ++G) {}
-            const int gn = grid_n[layer];
-            const int np = gn * gn;                 // points per crop
-            const int nm = np * M;                  // masks per crop
-            const int first_raw = prm->multimask_output ? 1 : 0;     // the multimask first pass leaves its 4 planes per prompt in place (read through index maps)
-            h_pts.resize((size_t)G * np * 2);
-            std::vector<float> crop_pts_all((size_t)G * np * 2);
-            for (int g = 0; g < G; ++g) {
-                const auto& box = crops[c0 + ci + g];
+            Grp g{ci, G, layer, grid_n[layer], grid_n[layer] * grid_n[layer], grid_n[layer] * grid_n[layer] * M, n_pts, n_pts * M, 0, nullptr, nullptr};
+            groups.push_back(g);
+            n_pts += (size_t)G * g.np;
+        }
+        const size_t n_cand = n_pts * M;
+        const int first_raw = prm->multimask_output ? 1 : 0;     // the multimask first pass leaves its 4 planes per prompt in place (read through index maps)
+        h_pts.resize(n_pts * 2);
+        std::vector<float> crop_pts_all(n_pts * 2);
+        for (const Grp& gr : groups)
+            for (int g = 0; g < gr.G; ++g) {
+                const auto& box = crops[c0 + gr.ci + g];
                 const int cw = box[2] - box[0], chh = box[3] - box[1];
-                for (int iy = 0; iy < gn; ++iy)
-                    for (int ix = 0; ix < gn; ++ix) {
-                        const float px = (float)(grids[layer][ix] * (double)cw), py = (float)(grids[layer][iy] * (double)chh);
-                        const size_t k = (size_t)g * np + (size_t)iy * gn + ix;
+                for (int iy = 0; iy < gr.gn; ++iy)
+                    for (int ix = 0; ix < gr.gn; ++ix) {
+                        const float px = (float)(grids[gr.layer][ix] * (double)cw), py = (float)(grids[gr.layer][iy] * (double)chh);
+                        const size_t k = gr.pt0 + (size_t)g * gr.np + (size_t)iy * gr.gn + ix;
                         crop_pts_all[2 * k] = px; crop_pts_all[2 * k + 1] = py;
                         h_pts[2 * k] = (px / (float)cw) * 1024.0f;
                         h_pts[2 * k + 1] = (py / (float)chh) * 1024.0f;
                     }
             }
-            ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * G * np, hipMemcpyHostToDevice, s));
-            TRY(eng_graphed(e, "dec1," + key_of({ci, np, (long long)(uintptr_t)e->amg_pts, G * np, prm->multimask_output, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_iou1}), s,
-                            [&]() { return eng_decode_ex(e, ci, np, e->amg_pts, nullptr, G * np, prm->multimask_output, nullptr, 0, 0.f, e->amg_low1, first_raw, e->amg_iou1, nullptr, nullptr, s); }));
+        ENG_HIP(e, hipMemcpyAsync(e->amg_pts, h_pts.data(), sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, s));
+        if (prm->use_m2m) {
+            h_pts2.resize(n_cand * 2);
+            for (size_t k = 0; k < n_pts; ++k)
+                for (int m = 0; m < M; ++m) { h_pts2[2 * (k * M + m)] = h_pts[2 * k]; h_pts2[2 * (k * M + m) + 1] = h_pts[2 * k + 1]; }
+            ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * n_cand, hipMemcpyHostToDevice, s));
+        }
+        // ---- phase 1: every decode of the encoder batch
+        for (Grp& gr : groups) {
+            const int ci = gr.ci, G = gr.G, np = gr.np, nm = gr.nm;
+            float* pts1 = e->amg_pts + 2 * gr.pt0;
+            float* low1 = e->amg_low1 + gr.pt0 * (first_raw ? 4 : 1) * 65536;
+            float* iou1 = e->amg_iou1 + gr.k0;
+            TRY(eng_graphed(e, "dec1," + key_of({ci, np, (long long)(uintptr_t)pts1, G * np, prm->multimask_output, (long long)(uintptr_t)low1, (long long)(uintptr_t)iou1}), s,
+                            [&]() { return eng_decode_ex(e, ci, np, pts1, nullptr, G * np, prm->multimask_output, nullptr, 0, 0.f, low1, first_raw, iou1, nullptr, nullptr, s); }));
             for (int g = 0; g < G; ++g) e->slot_shared_valid[ci + g] = 1;      // (bookkeeping of the first-pass decode, for replays)
-            const float* masks = e->amg_low1;
-            const float* ious = e->amg_iou1;
-            int plane_mode = first_raw ? 1 : 0;                   // where K8 finds candidate k: 0 plane k, 1 plane 4 (k / 3) + 1 + k % 3, 2 plane 4 k + sel[k]
+            gr.masks = low1; gr.ious = iou1; gr.plane_mode = first_raw ? 1 : 0;   // where K8 finds candidate k: 0 plane k, 1 plane 4 (k / 3) + 1 + k % 3, 2 plane 4 k + sel[k]
             if (prm->use_m2m) {
                 // the predictor's clamp of the returned low-res logits to +-32 is applied where they are read back as the mask prompt
-                h_pts2.resize((size_t)G * nm * 2);
-                for (size_t k = 0; k < (size_t)G * np; ++k)
-                    for (int m = 0; m < M; ++m) { h_pts2[2 * (k * M + m)] = h_pts[2 * k]; h_pts2[2 * (k * M + m) + 1] = h_pts[2 * k + 1]; }
-                ENG_HIP(e, hipMemcpyAsync(e->amg_pts2, h_pts2.data(), sizeof(float) * 2 * G * nm, hipMemcpyHostToDevice, s));
-                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)e->amg_pts2, G * nm, first_raw, (long long)(uintptr_t)e->amg_low1, (long long)(uintptr_t)e->amg_low2, (long long)(uintptr_t)e->amg_iou2, (long long)(uintptr_t)e->amg_sel}), s,
-                                [&]() { return eng_decode_ex(e, ci, nm, e->amg_pts2, nullptr, G * nm, 0, e->amg_low1, first_raw, 32.0f, e->amg_low2, 1, e->amg_iou2, nullptr, e->amg_sel, s); }));
-                masks = e->amg_low2;
-                ious = e->amg_iou2;
-                plane_mode = 2;
+                float* pts2 = e->amg_pts2 + 2 * gr.k0;
+                float* low2 = e->amg_low2 + gr.k0 * 4 * 65536;
+                float* iou2 = e->amg_iou2 + gr.k0;
+                int* sel2 = e->amg_sel + gr.k0;
+                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)pts2, G * nm, first_raw, (long long)(uintptr_t)low1, (long long)(uintptr_t)low2, (long long)(uintptr_t)iou2, (long long)(uintptr_t)sel2}), s,
+                                [&]() { return eng_decode_ex(e, ci, nm, pts2, nullptr, G * nm, 0, low1, first_raw, 32.0f, low2, 1, iou2, nullptr, sel2, s); }));
+                gr.masks = low2; gr.ious = iou2; gr.plane_mode = 2;
             }
-            std::vector<float> h_iou_all((size_t)G * nm);
-            std::vector<int> h_sel;
-            ENG_HIP(e, hipMemcpyAsync(h_iou_all.data(), ious, sizeof(float) * G * nm, hipMemcpyDeviceToHost, s));
-            if (plane_mode == 2) { h_sel.resize((size_t)G * nm); ENG_HIP(e, hipMemcpyAsync(h_sel.data(), e->amg_sel, sizeof(int) * G * nm, hipMemcpyDeviceToHost, s)); }
-            { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }                                   // sync 1 of 2 per decoded group
-            // pred_iou filter of every crop of the group on the host, then K8 for ALL of them (one launch per crop, no host round trip in
-            // between) into one scratch, ONE copy of the per-mask scalars back: 2 host synchronisations per group of crops instead of
-            // 1 + one per crop (24 -> 7 per slice with the default 21-crop pyramid)
-            std::vector<int> g_first(G + 1, 0);                                    // survivors of crop g: [g_first[g], g_first[g+1]) of the group list
-            h_idx.clear();
-            for (int g = 0; g < G; ++g) {
-                const int kbase = g * nm;
-                for (int k = 0; k < nm; ++k)
-                    if (!(prm->pred_iou_thresh > 0.0f) || h_iou_all[kbase + k] > prm->pred_iou_thresh) h_idx.push_back(kbase + k);
-                g_first[g + 1] = (int)h_idx.size();
+        }
+        // ---- phase 2: per-candidate scalars of the whole batch (sync 1)
+        std::vector<float> h_iou_all(n_cand);
+        std::vector<int> h_sel;
+        ENG_HIP(e, hipMemcpyAsync(h_iou_all.data(), prm->use_m2m ? e->amg_iou2 : e->amg_iou1, sizeof(float) * n_cand, hipMemcpyDeviceToHost, s));
+        if (prm->use_m2m) { h_sel.resize(n_cand); ENG_HIP(e, hipMemcpyAsync(h_sel.data(), e->amg_sel, sizeof(int) * n_cand, hipMemcpyDeviceToHost, s)); }
+        { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
+        // pred_iou filter of every crop on the host, then K8 for ALL of them (one launch per crop) into one scratch
+        struct CropRange { int first, count; };
+        std::vector<std::vector<CropRange>> ranges(groups.size());
+        h_idx.clear();               // candidate index within the batch (k0 + local)
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp& gr = groups[gi];
+            for (int g = 0; g < gr.G; ++g) {
+                const size_t kbase = gr.k0 + (size_t)g * gr.nm;
+                const int first = (int)h_idx.size();
+                for (int k = 0; k < gr.nm; ++k)
+                    if (!(prm->pred_iou_thresh > 0.0f) || h_iou_all[kbase + k] > prm->pred_iou_thresh) h_idx.push_back((int)(kbase + k));
+                ranges[gi].push_back(CropRange{first, (int)h_idx.size() - first});
             }
-            const int ns_all = (int)h_idx.size();
-            if (ns_all == 0) continue;
-            TRY(crop_reserve((size_t)ns_all));
-            // K8 reads the chosen plane in place: candidate k of the group lives at plane 4 (k / 3) + 1 + k % 3 (multimask pass) or
-            // 4 k + sel[k] (single-mask pass) of the 4-plane buffer
-            h_plane.resize(ns_all);
-            for (int j = 0; j < ns_all; ++j) { const int k = h_idx[j]; h_plane[j] = plane_mode == 1 ? 4 * (k / 3) + 1 + k % 3 : plane_mode == 2 ? 4 * k + h_sel[k] : k; }
-            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_plane.data(), sizeof(int) * ns_all, hipMemcpyHostToDevice, s));
-            for (int g = 0; g < G; ++g) {
-                const int ns = g_first[g + 1] - g_first[g];
-                if (ns == 0) continue;
-                const auto& box = crops[c0 + ci + g];
-                ENG_KP(e, PC_MASK_POST, 0.0, (double)ns * (65536.0 * 4 + (double)mask_words * 4),
-                       launch_mask_post(masks, e->amg_idx + g_first[g], ns, box[0], box[1], box[2] - box[0], box[3] - box[1], H, W, prm->mask_threshold,
-                                        prm->stability_score_offset, e->amg_crop_bits + (size_t)g_first[g] * mask_words, e->amg_stats + g_first[g], s));
+        }
+        const int ns_all = (int)h_idx.size();
+        if (ns_all == 0) continue;
+        if (e->amg_stats_cap < (size_t)ns_all) { TRY(eng_regrow(e, &e->amg_stats, (size_t)ns_all, s)); TRY(eng_regrow(e, &e->amg_idx, (size_t)ns_all, s)); e->amg_stats_cap = ns_all; }
+        TRY(crop_reserve((size_t)ns_all));
+        // K8 reads the chosen plane in place, relative to its group's buffer
+        h_plane.resize(ns_all);
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp& gr = groups[gi];
+            for (const CropRange& r : ranges[gi])
+                for (int j = r.first; j < r.first + r.count; ++j) {
+                    const int k = h_idx[j] - (int)gr.k0;             // candidate within the group
+                    h_plane[j] = gr.plane_mode == 1 ? 4 * (k / 3) + 1 + k % 3 : gr.plane_mode == 2 ? 4 * k + h_sel[h_idx[j]] : k;
+                }
+        }
+        ENG_HIP(e, hipMemcpyAsync(e->amg_idx, h_plane.data(), sizeof(int) * ns_all, hipMemcpyHostToDevice, s));
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp& gr = groups[gi];
+            for (int g = 0; g < gr.G; ++g) {
+                const CropRange& r = ranges[gi][g];
+                if (r.count == 0) continue;
+                const auto& box = crops[c0 + gr.ci + g];
+                ENG_KP(e, PC_MASK_POST, 0.0, (double)r.count * (65536.0 * 4 + (double)mask_words * 4),
+                       launch_mask_post(gr.masks, e->amg_idx + r.first, r.count, box[0], box[1], box[2] - box[0], box[3] - box[1], H, W, prm->mask_threshold,
+                                        prm->stability_score_offset, e->amg_crop_bits + (size_t)r.first * mask_words, e->amg_stats + r.first, s));
             }
-            h_stats.resize(ns_all);
-            ENG_HIP(e, hipMemcpyAsync(h_stats.data(), e->amg_stats, sizeof(MaskStats) * ns_all, hipMemcpyDeviceToHost, s));
-            { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }                                   // sync 2 of 2
-          for (int g = 0; g < G; ++g) {            // per-crop filtering and NMS, exactly as for unbatched crops
-            const auto& box = crops[c0 + ci + g];
-            const float* crop_pts = crop_pts_all.data() + (size_t)g * np * 2;
-            const int kbase = g * nm;              // first mask of this crop in the group buffers
-            const int ns = g_first[g + 1] - g_first[g];
+        }
+        h_stats.resize(ns_all);
+        ENG_HIP(e, hipMemcpyAsync(h_stats.data(), e->amg_stats, sizeof(MaskStats) * ns_all, hipMemcpyDeviceToHost, s));
+        { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }                                       // sync 2
+        // ---- phase 3: per-crop filtering and NMS, exactly as for unbatched crops
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+          const Grp& gr = groups[gi];
+          const int M_ = M;
+          for (int g = 0; g < gr.G; ++g) {
+            const auto& box = crops[c0 + gr.ci + g];
+            const float* crop_pts = crop_pts_all.data() + (gr.pt0 + (size_t)g * gr.np) * 2;
+            const size_t kbase = gr.k0 + (size_t)g * gr.nm;              // first candidate of this crop in the batch buffers
+            const CropRange& r = ranges[gi][g];
+            const int ns = r.count;
             if (ns == 0) continue;
-            const uint32_t* crop_bits = e->amg_crop_bits + (size_t)g_first[g] * mask_words;
+            const uint32_t* crop_bits = e->amg_crop_bits + (size_t)r.first * mask_words;
             std::vector<Cand> cand;
             std::vector<int> cand_src;  // index into crop_bits
             for (int k = 0; k < ns; ++k) {
-                const MaskStats& st = h_stats[g_first[g] + k];
+                const MaskStats& st = h_stats[r.first + k];
                 const float stab = (float)st.inter / (float)st.uni;  // 0/0 -> nan fails the filter like upstream
                 if (prm->stability_score_thresh > 0.0f && !(stab >= prm->stability_score_thresh)) continue;
                 Cand cd;
@@ -283,10 +324,10 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                     near = near || (nc_ && !ni);
                 }
                 if (near) continue;
-                const int src = h_idx[g_first[g] + k] - kbase;
+                const int src = (int)((size_t)h_idx[r.first + k] - kbase);
                 cd.iou = h_iou_all[kbase + src];
                 cd.stab = stab;
-                const int pk = src / M;
+                const int pk = src / M_;
                 cd.pt[0] = crop_pts[2 * pk] + (float)box[0];
                 cd.pt[1] = crop_pts[2 * pk + 1] + (float)box[1];
                 for (int q = 0; q < 4; ++q) cd.crop[q] = box[q];

@@ -99,7 +99,7 @@ struct saber_engine {
 
     // AMG workspace (grown on demand)
     float *amg_prep = nullptr; size_t amg_prep_elems = 0;
-    int* amg_sel = nullptr;
+    int* amg_sel = nullptr; bool amg_m2m_sized = false;
     float *amg_pts = nullptr, *amg_low1 = nullptr, *amg_low2 = nullptr, *amg_iou1 = nullptr, *amg_iou2 = nullptr, *amg_pts2 = nullptr;
     size_t amg_prompts_cap = 0;
     uint32_t* amg_bits = nullptr; size_t amg_bits_words = 0;        // masks kept across crops (persistent, grown on demand)
