@@ -293,7 +293,8 @@ def main():
         # hipGraph replay A/B on the same handle (the headline above runs with replay on unless SABER_AMD_GRAPHS=0)
         ab = {}
         for name, on in (("eager", False), ("graphs", True)):
-            eng.set_graphs(on)
+            for e_ in engines:
+                e_.set_graphs(on)
             run_steps(0, 2)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -301,7 +302,7 @@ def main():
             torch.cuda.synchronize()
             ab[f"ms_per_slice_{name}"] = (time.perf_counter() - t0) / 6 * 1e3
         cap, rep = eng.graph_stats()
-        out["hipgraph"] = dict(ab, what="same step, 6 slices each, launch sequences issued eagerly vs replayed from hipGraphs (encoder pass + each decoder batch)",
+        out["hipgraph"] = dict(ab, what=f"same step, 6 slices each over the {len(engines)} engine handle(s) of the headline, launch sequences issued eagerly vs replayed from hipGraphs (encoder pass + each decoder batch)",
                                sequences_captured=cap, replays_so_far=rep, headline_uses_graphs=os.environ.get("SABER_AMD_GRAPHS", "1") != "0")
     if rank == 0 and world == 1 and not a.no_profile:
         eng.profile_begin()
