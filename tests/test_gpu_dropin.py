@@ -107,3 +107,36 @@ def test_tomo_segmenter_segment_vol_runs_the_video_path():
     assert set(seg.adapter.frame_metrics) == set(range(5))
     out2 = seg.segment_vol(vol[::-1].copy(), thickness=2, zSlice=2)      # a second volume through the same segmenter loads its own frames
     assert out2.shape == vol.shape
+
+
+def test_segment_tomogram_core_with_injected_io():
+    """saber/entry_points/inference_core.py:9-98 with the copick reader / writer replaced by in-memory stand-ins: read -> segment ->
+    device smoothing -> uint8 -> write -> state reset; a run without a tomogram returns None and writes nothing."""
+    import os
+    import types
+    os.environ["SABER_AMD_SEEDED_WEIGHTS"] = "1"
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.entry_points.inference_core import segment_tomogram_core
+    from saber_amd.segmenters.tomo import tomoSegmenter
+    amg = cfgAMG(npoints=8, crop_n_layers=0, pred_iou_thresh=0.2, stability_score_thresh=0.3, sam2_cfg="small")
+    seg = tomoSegmenter(deviceID=0, cfg=SAM2AdapterConfig(cfg="tiny", amg_cfg=amg, min_mask_area=50), min_mask_area=50)
+    seg.filter_threshold = -1.0
+    vol = _volume(Z=5, S=384)
+    written = {}
+
+    def read(run, voxel_size, algorithm=None):
+        return None if run.name == "missing" else vol
+
+    def write(run, mask, user, name=None, session_id=None, voxel_size=None):
+        written[run.name] = (mask, user, name, session_id, voxel_size)
+
+    run = types.SimpleNamespace(name="run1")
+    assert segment_tomogram_core(run, 10.0, "wbp", "organelles", "1", 2, 1, 0, False, seg, gpu_id=0, read_tomogram=read, write_segmentation=write) is None
+    mask, user, name, sid, vs = written["run1"]
+    # (the label volume itself is covered by the test above and by the smoothing fixtures: a 5-slice toy volume need not survive the z-Gaussian)
+    assert mask.shape == vol.shape and mask.dtype == np.uint8 and (user, name, sid, vs) == ("saber", "organelles", "1", 10.0)
+    assert seg.inference_state is None
+    assert segment_tomogram_core(types.SimpleNamespace(name="missing"), 10.0, "wbp", "organelles", "1", 2, 1, 0, False, seg,
+                                 read_tomogram=read, write_segmentation=write) is None
+    assert "missing" not in written
