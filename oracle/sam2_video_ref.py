@@ -251,10 +251,11 @@ class VideoPredictorRef:
 
     # ---- SAM heads on a (possibly memory-conditioned) feature map
     @torch.no_grad()
-    def _sam_heads(self, pix_feat: T, s0: T, s1: T, mask_inputs: Optional[T], multimask_output: bool):
+    def _sam_heads(self, pix_feat: T, s0: T, s1: T, mask_inputs: Optional[T], multimask_output: bool, pts: Optional[T] = None, lab: Optional[T] = None):
         S, W = self.S, self.W
-        pts = torch.zeros(1, 1, 2)
-        lab = -torch.ones(1, 1, dtype=torch.int64)
+        if pts is None:         # no point prompt: one padding point with label -1 (SAM2Base._forward_sam_heads)
+            pts = torch.zeros(1, 1, 2)
+            lab = -torch.ones(1, 1, dtype=torch.int64)
         sparse, dense = S.prompt_encoder(W, pts, lab, mask_inputs, self.image_size)
         feats = {"image_embed": pix_feat, "feat_s0": s0, "feat_s1": s1}
         low_multi, ious, obj, all_masks, all_iou, toks = S.mask_decoder(W, feats, sparse, dense, multimask_output, self._dense_pe, return_tokens=True)
@@ -314,6 +315,37 @@ class VideoPredictorRef:
             m = (m > 0).float() if m.dtype != torch.float32 else m
         pix, pos, s0, s1 = self._feats(frame_idx)
         low, high, ptr, obj = self._use_mask_as_output(pix, s0, s1, m)
+        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
+        return frame_idx, list(self.obj_ids), F.interpolate(low, size=self.video_hw, mode="bilinear", align_corners=False)
+
+    @torch.no_grad()
+    def add_new_points_or_box(self, frame_idx: int, obj_id: int, points=None, labels=None, clear_old_points: bool = True, normalize_coords: bool = True, box=None):
+        """upstream SAM2VideoPredictor.add_new_points_or_box for ONE click on a frame that has not been tracked yet (an initial conditioning
+        frame: the SAM heads run on the frame's own features + no_mem_embed, multimask output because there is a single point, the best mask by
+        predicted IoU becomes the frame's output; a previous output on the frame enters as the mask prompt, clamped to +-32)."""
+        if (points is not None) != (labels is not None):
+            raise ValueError("points and labels must be provided together")
+        if points is None and box is None:
+            raise ValueError("at least one of points or box must be provided as input")
+        if box is not None:
+            raise NotImplementedError("box prompts are not restated")
+        pts = torch.as_tensor(np.asarray(points), dtype=torch.float32).reshape(1, -1, 2)
+        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int64).reshape(1, -1)
+        if pts.shape[1] != 1:
+            raise NotImplementedError("one click per call")
+        if obj_id not in self.obj_ids:
+            self.obj_ids.append(obj_id)
+            self.out[obj_id] = {"cond": {}, "non_cond": {}}
+            self.temp[obj_id] = {}
+        if frame_idx in self.out[obj_id]["non_cond"]:
+            raise NotImplementedError("corrections of tracked frames are not restated")
+        if normalize_coords:
+            pts = pts / torch.tensor([self.video_hw[1], self.video_hw[0]], dtype=torch.float32)
+        pts = pts * self.image_size
+        prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx)
+        mask_in = torch.clamp(prev["pred_masks"], -32.0, 32.0) if prev is not None else None
+        pix, pos, s0, s1 = self._feats(frame_idx)
+        low, high, ptr, obj = self._sam_heads(pix + self.W["no_mem_embed"].view(1, -1, 1, 1), s0, s1, mask_in, multimask_output=True, pts=pts, lab=lab)
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
         return frame_idx, list(self.obj_ids), F.interpolate(low, size=self.video_hw, mode="bilinear", align_corners=False)
 

@@ -85,8 +85,13 @@ class SAM2Adapter(BaseAdapter):
         return state.add_new_mask(frame_idx, obj_id, mask)
 
     def add_new_points_or_box(self, frame_idx: int, obj_id: int, inference_state=None, **kwargs) -> Tuple:
-        raise NotImplementedError("point / box prompts of the video predictor are not built: every SABER caller seeds propagation with masks "
-                                  "(segmenters/base.py:265-280 -> segment_volume(masks=...))")
+        """predictor.py:171-180: delegates to the video predictor (points=, labels=, clear_old_points=, normalize_coords=, box=).  Built for
+        one click per call on a frame that has not been tracked yet; boxes, several clicks and corrections raise NotImplementedError
+        (no SABER caller uses them: segmenters/base.py:265-280 seeds propagation with masks)."""
+        state = inference_state or self.inference_state
+        if state is None:
+            raise RuntimeError("Call set_volume() before add_new_points_or_box().")
+        return state.add_new_points_or_box(frame_idx, obj_id, **kwargs)
 
     @torch.inference_mode()
     def propagate_in_video(self, start_frame_idx, max_frame_num_to_track=None, reverse=False, inference_state=None) -> Iterator:

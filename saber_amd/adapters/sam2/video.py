@@ -141,6 +141,7 @@ class VideoPredictor:
         self.no_obj_ptr = np.asarray(W["no_obj_ptr"], dtype=np.float32).reshape(1, 256)
         self.no_obj_spatial = np.asarray(W["no_obj_embed_spatial"], dtype=np.float32).reshape(-1)
         self.neg_no_mem = torch.from_numpy(-np.asarray(W["no_mem_embed"], dtype=np.float32).reshape(1, 256)).to(self.dev)
+        self.pos_no_mem = torch.from_numpy(np.asarray(W["no_mem_embed"], dtype=np.float32).reshape(1, 256).copy()).to(self.dev)
         self.curr_pos = torch.from_numpy(_sine_pe_2d(64, 128)).to(self.dev)                     # (4096,256)
         self.mem_pos = _sine_pe_2d(64, 32)                                                      # (4096,64)
         # spatial position + temporal encoding of a memory that is k slots away, once per model (device)
@@ -237,11 +238,13 @@ class VideoPredictor:
         return t - self._win[0]
 
     # ------------------------------------------------------------------ SAM heads on a given (4096,256) embedding
-    def _sam_heads(self, embed_tokens: torch.Tensor, mask_in: Optional[torch.Tensor], multimask: bool, slot: int = 0):
-        """returns (low (256,256) device fp32, obj logit float, obj_ptr (1,256) device fp32); slot: the engine slot that holds the frame"""
+    def _sam_heads(self, embed_tokens: torch.Tensor, mask_in: Optional[torch.Tensor], multimask: bool, slot: int = 0,
+                   point: Optional[Tuple[float, float]] = None, label: int = -1):
+        """returns (low (256,256) device fp32, obj logit float, obj_ptr (1,256) device fp32); slot: the engine slot that holds the frame;
+        point / label: one click in the model's 1024-px frame (None: upstream's padding point with label -1)"""
         self.eng._check(self.lib.saber_set_embed_tokens(self.eng.h, slot, self._p(embed_tokens), self._s()))
-        pts = torch.zeros(1, 2, device=self.dev)
-        lab = torch.full((1,), -1, dtype=torch.int32, device=self.dev)
+        pts = torch.zeros(1, 2, device=self.dev) if point is None else torch.tensor([[float(point[0]), float(point[1])]], dtype=torch.float32, device=self.dev)
+        lab = torch.full((1,), -1 if point is None else int(label), dtype=torch.int32, device=self.dev)
         low, iou, obj = self.eng.decode_points(pts, slot=slot, multimask=multimask, mask_input=mask_in, labels=lab)
         toks = self._new(8, 256)
         self.eng._check(self.lib.saber_get_decoder_tokens(self.eng.h, 1, self._p(toks), self._s()))
@@ -325,6 +328,44 @@ class VideoPredictor:
         tok_ptr = ptr if appearing else self.no_obj_ptr_dev
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": tok_ptr, "obj": 10.0 if appearing else -10.0, "mem": None, "raw": raw}
         return frame_idx, list(self.obj_ids), low
+
+    @torch.inference_mode()
+    def add_new_points_or_box(self, frame_idx: int, obj_id: int, points=None, labels=None, clear_old_points: bool = True,
+                              normalize_coords: bool = True, box=None):
+        """upstream SAM2VideoPredictor.add_new_points_or_box for ONE click on a frame that has not been tracked yet: the SAM heads run on
+        the frame's own features (+ no_mem_embed: an initial conditioning frame sees no memory) with the click as the point prompt and the
+        frame's previous output, if any, as the mask prompt (clamped to +-32); one point => multimask output, the best mask by predicted
+        IoU becomes the frame's output.  The engine decodes prompts of one point + the padding point (8 decoder tokens): boxes (two corner
+        points) and several clicks in one call are not built, nor are corrections of frames that have already been tracked."""
+        if self.images is None:
+            raise RuntimeError("call init_state() first")
+        if (points is not None) != (labels is not None):
+            raise ValueError("points and labels must be provided together")
+        if points is None and box is None:
+            raise ValueError("at least one of points or box must be provided as input")
+        if box is not None:
+            raise NotImplementedError("box prompts (two corner points + padding = 9 decoder tokens) are not built; seed with a mask or a click")
+        pts = np.asarray(points, dtype=np.float32).reshape(-1, 2)
+        lab = np.asarray(labels).reshape(-1)
+        if len(pts) != 1 or len(lab) != 1:
+            raise NotImplementedError("one click per call (several clicks need more prompt tokens than the engine's decoder batches carry)")
+        if obj_id not in self.obj_ids:
+            self.obj_ids.append(obj_id)
+            self.out[obj_id] = {"cond": {}, "non_cond": {}}
+            self.temp[obj_id] = {}
+        if frame_idx in self.out[obj_id]["non_cond"]:
+            raise NotImplementedError("correcting a frame that has already been tracked is not built")
+        Hv, Wv = self.video_hw
+        xy = pts[0] / np.array([Wv, Hv], np.float32) if normalize_coords else pts[0]
+        xy = xy * np.float32(self.image_size)
+        prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx)
+        mask_in = prev["pred_masks"].clamp(-32.0, 32.0).view(1, 256, 256).contiguous() if prev is not None else None
+        raw = self._frame(frame_idx)
+        emb = self._new(4096, 256)
+        self._ck(self.lib.saber_k_add_to_bf16(self._p(raw), self._p(self.pos_no_mem), 1, None, self._p(emb), 4096, 256, self._s()))
+        low, obj_v, ptr = self._sam_heads(emb, mask_in, multimask=True, slot=self._slot(frame_idx), point=(xy[0], xy[1]), label=int(lab[0]))
+        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": None, "raw": raw}
+        return frame_idx, list(self.obj_ids), self._resize(low, 256, 256, Hv, Wv)[None, None]
 
     def _preflight(self):
         for oid in self.obj_ids:
