@@ -254,3 +254,31 @@ def test_add_new_points_single_click_against_oracle(video_case):
     with pytest.raises(ValueError):
         vp.add_new_points_or_box(0, 2, points=[[1, 1]])
     vp.reset_state()
+
+
+def test_two_objects_segment_volume_against_oracle(video_case):
+    """two seed masks (two objects tracked independently, later object ids overwrite earlier ones where they overlap, the backward pass
+    fills only frames the forward pass left empty): SAM2Adapter.segment_volume against the oracle's, label by label"""
+    from oracle import sam2_video_ref as V
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.predictor import SAM2Adapter
+    cfg, W, vp, tomo, seed = video_case
+    yy, xx = np.mgrid[:128, :128]
+    seed2 = ((yy - 40) ** 2 + (xx - 90) ** 2 < 14 ** 2).astype(np.float32)
+    P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.init_state(V.load_tomogram_frames(tomo))
+    ref_vol, ref_metrics, ref_scores = V.segment_volume_ref(P, 2, [seed, seed2], tomo.shape, min_presence_score=0.0)
+    ad = SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0")
+    ad._video_predictor = vp
+    ad.set_volume(tomo)
+    vol = ad.segment_volume(2, masks=[seed, seed2], min_presence_score=0.0)
+    assert vol.shape == tomo.shape and vol.dtype == np.uint16 and set(np.unique(vol)) <= {0, 1, 2}
+    assert ad.frame_scores.shape == ref_scores.shape == (tomo.shape[0], 2)
+    assert np.abs(ad.frame_scores - ref_scores).max() < 0.06
+    for lab in (1, 2):
+        inter = ((vol == lab) & (ref_vol == lab)).sum()
+        uni = ((vol == lab) | (ref_vol == lab)).sum()
+        print(f"object {lab}: volume IoU {inter / max(1, uni):.4f} ({int((vol == lab).sum())} vs {int((ref_vol == lab).sum())} voxels)")
+        # object 1 survives only where object 2's (image-filling, seeded-weights) mask is absent: ~1 400 voxels whose outline is object 2's
+        # near-zero-logit boundary, so a few dozen voxels flip with the bf16 residual (measured 0.967); the large label is tight
+        assert inter / max(1, uni) > (0.995 if uni > 50000 else 0.94)
