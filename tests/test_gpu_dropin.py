@@ -50,8 +50,8 @@ def test_adapter_contract(segmenter):
         assert hasattr(ad, name)
     with pytest.raises(RuntimeError, match="set_volume"):          # reference error behaviour (predictor.py:251-257)
         ad.segment_volume(0, [], (3, 384, 384))
-    with pytest.raises(NotImplementedError):                       # point / box prompts of the video predictor: not built, loud
-        ad.add_new_points_or_box(0, 1)
+    with pytest.raises(RuntimeError, match="set_volume"):          # point prompts need a loaded volume too (tests/test_gpu_video.py covers them)
+        ad.add_new_points_or_box(0, 1, points=[[1.0, 1.0]], labels=[1])
 
 
 def test_slice_loop_device_equals_reference_shaped_loop(segmenter):
