@@ -126,7 +126,6 @@ class SAM2Adapter(BaseAdapter):
         object-score logits with a forward hook and files them under `_current_frame`, which it updates only AFTER the generator has
         yielded a frame: a frame's scores therefore land on the frame yielded before it.  Reproduced as is (it feeds the boundary fit)."""
         from saber_amd.filters.estimate_thickness import fit_organelle_boundaries
-        from saber_amd.segmenters.utils import resize_mask_nearest
         state = inference_state or self.inference_state
         if state is None:
             raise RuntimeError("Call set_volume() before segment_volume().")

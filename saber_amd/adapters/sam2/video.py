@@ -26,7 +26,6 @@ from typing import Dict, Iterator, List, Optional, Tuple
 import numpy as np
 import torch
 
-from saber_amd.model_config import IMAGE_MEAN, IMAGE_STD
 
 NO_OBJ_SCORE = -1024.0
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -11,8 +11,6 @@ import numpy as np
 import torch
 import yaml
 
-from saber_amd import _lib
-
 HEAD_PREFIXES = ("projection.", "classifier.")
 
 
