@@ -49,3 +49,24 @@ def test_graph_replay_is_bit_identical_to_eager():
         b0, m0 = _run(ref, img, p)
         assert m == m0 and np.array_equal(b, b0)
     assert eng.graph_stats()[0] > ncap
+
+
+def test_amg_result_does_not_depend_on_the_encoder_batch_size():
+    """the crops of a slice go through the encoder max_images at a time; with fewer slots than crops (two encoder batches, the second
+    one holding a single layer-1 crop) the driver must return the same masks as with all crops in one batch"""
+    from oracle import saber_ref
+    from saber_amd.engine import Engine, make_amg_params
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    w = seeded_weights(get_config("tiny"), 0)
+    params = make_amg_params(dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.0, stability_score_thresh=0.0, box_nms_thresh=1.0, crop_nms_thresh=1.0))
+    img = None
+    results = []
+    for mi in (5, 4, 2):
+        eng = Engine("tiny", weights=w, max_images=mi, max_prompts=256)
+        if img is None:
+            img = eng.prepare(torch.from_numpy(saber_ref.synthetic_slice(seed=7, size=512)).cuda())
+        results.append(_run(eng, img, params))
+        eng.close()
+    for b, m in results[1:]:
+        assert m == results[0][1] and np.array_equal(b, results[0][0])
