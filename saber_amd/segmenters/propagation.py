@@ -8,8 +8,8 @@ Two implementations with identical results:
   * slice_by_slice_device    - the device-resident, z-sharded form (saber_amd.segmenters.slice_driver): masks stay
                                bit-packed in HBM, label planes are painted by a HIP kernel and all-gathered over
                                RCCL when torch.distributed is initialised.
-The seed-and-propagate entry points (segment / single_segment / multiclass_segment) need the video predictor and
-are a 'next' row."""
+The seed-and-propagate entry points (segment / single_segment / multiclass_segment) run on the engine's video path
+ and classifier (8f-3)."""
 from typing import Optional
 
 import numpy as np
@@ -56,6 +56,37 @@ class propagationSegmenter(saber3D):
                 masks3d = (masks3d > 0).astype(np.uint8)
             np.maximum(final, masks3d, out=final)
         return utils.separate_masks(final)
+
+    @torch.inference_mode()
+    def multiclass_segment(self, volume: np.ndarray):
+        """propagation.py:119-160: per seed slice the raw 2-D masks are classified, the non-background ones propagated, and every voxel keeps
+        the class of the most confident mask that reached it.  (The reference prepares the slice and hands the prepared RGB image to
+        segment_image_2d, which prepares it again; kept.)"""
+        from saber_amd.utils import preprocessing
+        final = np.zeros(volume.shape, dtype=np.uint16)
+        best = np.zeros(volume.shape, dtype=np.float32)
+        for ii in range(2, volume.shape[0], self.ini_depth):
+            im = preprocessing.prepare(volume[ii], to_rgb=True)
+            im = im.cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            gray = im[:, :, 0] if im.ndim == 3 else im
+            raw = [m for m in self.adapter.segment_image_2d(np.repeat(gray[..., None], 3, axis=2)) if m["area"] >= self.min_mask_area]
+            if len(raw) == 0:
+                continue
+            arrays = np.array([m["segmentation"].astype(np.uint8) for m in raw])
+            predictions = self.classifier.batch_predict(gray, arrays, self.batchsize)
+            classes = np.argmax(predictions, axis=1)
+            valid = classes > 0
+            if not np.any(valid):
+                continue
+            masks3d = self.segment_3d(volume, [raw[i]["segmentation"] for i, v in enumerate(valid) if v], ann_frame_idx=ii)
+            for idx, (probs, cid) in enumerate(zip(predictions[valid], classes[valid])):
+                region = masks3d == (idx + 1)
+                if np.any(region):
+                    conf = probs[cid]
+                    upd = region & (conf > best)
+                    final[upd] = cid
+                    best[upd] = conf
+        return final
 
     @torch.inference_mode()
     def slice_by_slice(self, volume: np.ndarray, text_prompt: str = None):

@@ -62,3 +62,50 @@ class tomoSegmenter(saber3D):
         ny, nz = self.masks[0]["segmentation"].shape
         self.ann_frame_idx = zSlice if zSlice is not None else nx // 2
         return self.propagate((nx, ny, nz))
+
+
+    def generate_multi_slab(self, vol, thickness, zSlice):
+        """tomo.py:141-158 ("highly experimental"): three slab projections a third of a slab apart as the three channels of one image,
+        local contrast with a 3-sigma clip and one global min-max; kept as host glue (scipy's uniform_filter over all three axes, like
+        the reference), it only sets self.image."""
+        from scipy.ndimage import uniform_filter
+        planes = [preprocess.project_tomogram(vol, zSlice + d, thickness) for d in (-thickness / 3, 0, thickness / 3)]
+        image = np.stack(planes, axis=-1)
+        mean = uniform_filter(image, size=500)
+        var = np.clip(uniform_filter(image ** 2, size=500) - mean ** 2, a_min=0, a_max=None)
+        image = np.clip((image - mean) / (np.sqrt(var) + 1e-8), -3, 3)
+        self.image = preprocess.normalize(image, rgb=True)
+
+
+class multiDepthTomoSegmenter(tomoSegmenter):
+    """tomo.py:161-258: segment_vol seeded at num_slabs depths delta_z apart around the centre, binary union, 3-D connected components."""
+
+    def __init__(self, deviceID: int = 0, cfg: Optional[AdapterConfig] = None, amg_cfg: Optional[cfgAMG] = None, target_class: int = 1,
+                 min_mask_area: int = 100, min_rel_box_size: float = 0.025):
+        self.min_rel_box_size = min_rel_box_size
+        self.target_class = target_class
+        super().__init__(deviceID=deviceID, cfg=cfg, amg_cfg=amg_cfg, min_mask_area=min_mask_area)
+        if target_class < 1:
+            raise ValueError("Multi-Depth Tomogram Segmenter only supports Single-Class Segmentation currently.")    # (the reference prints and exits)
+
+    def segment(self, vol, thickness: int, num_slabs: int = 3, delta_z: int = 30, save_run: str = None, display: bool = False):
+        self.show_segments = display
+        if self.target_class > 0 or self.classifier is None:
+            return self.single_segment(vol, thickness, num_slabs, delta_z)
+        print("Multiclass Segmentation is not implemented yet")     # reference behaviour (tomo.py:201-203)
+
+    @torch.inference_mode()
+    def single_segment(self, vol, thickness, num_slabs, delta_z):
+        from saber_amd.segmenters import utils
+        depth = vol.shape[0]
+        combined = np.zeros(vol.shape, dtype=np.uint16)
+        for i in range(num_slabs):
+            centre = int(depth // 2 + (i - num_slabs // 2) * delta_z)
+            if centre < 0 or centre >= depth:
+                print(f"Skipping slab {i}: slab_center={centre} out of range (0-{depth - 1})")
+                continue
+            masks3d = self.segment_vol(vol, thickness, zSlice=centre, display=False)
+            if masks3d is None:
+                continue
+            np.maximum(combined, (masks3d > 0).astype(np.uint16), out=combined)
+        return utils.separate_masks(combined)
