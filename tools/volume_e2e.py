@@ -9,9 +9,10 @@ from saber_amd.weights import seeded_weights
 from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
 from oracle import saber_ref   # synthetic input recipe only
 Z = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+FMT = sys.argv[2] if len(sys.argv) > 2 else "bf16"          # "fp8": e4m3 stage-2/3 block weights (BASELINE configs[4])
 W_ = seeded_weights(get_config("large"), 0)
-eng = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024)
-eng2 = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024)   # two slices in flight per GPU, as slice_by_slice_device does
+eng = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024, weight_format=FMT)
+eng2 = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024, weight_format=FMT)   # two slices in flight per GPU, as slice_by_slice_device does
 params = make_amg_params({})
 vol = saber_ref.synthetic_volume(seed=1, depth=Z)
 dev = torch.from_numpy(vol).cuda()
@@ -21,7 +22,7 @@ t0 = time.perf_counter()
 fns = [lambda z, e=e: segment_slice_to_plane(e, dev[z], params, min_mask_area=50)[0] for e in (eng, eng2)]
 out = segment_volume_sharded(vol, fns, stitch=True, engine=eng)
 dt = time.perf_counter() - t0
-print(f"Z={Z}: {dt:.2f} s end to end = {Z / dt:.2f} slices/s (label volume {out.shape} {out.dtype}, {int(out.max())} labels)")
+print(f"Z={Z} weights={FMT} graphs={eng.graph_stats()}: {dt:.2f} s end to end = {Z / dt:.2f} slices/s (label volume {out.shape} {out.dtype}, {int(out.max())} labels)")
 t0 = time.perf_counter()
 sm = segment_volume_sharded(vol, fns, stitch=True, engine=eng, smooth_scale=0.05)      # + the post step of segment_tomogram_core on the device
 dt = time.perf_counter() - t0
