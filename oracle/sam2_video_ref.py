@@ -212,8 +212,12 @@ def _mlp(W: Dict[str, T], key: str, x: T, n: int) -> T:
 class VideoPredictorRef:
     """One model, any number of objects tracked independently (as upstream's per-object inference does)."""
 
-    def __init__(self, weights, cfg, num_maskmem: int = 2):
+    def __init__(self, weights, cfg, num_maskmem: int = 2, cond_memory_from_full_res_mask: bool = False):
+        """cond_memory_from_full_res_mask: the one step where the independent `transformers` restatement departs from upstream - it encodes
+        the memory of a mask-prompted frame from the prompt mask at full resolution, upstream (and therefore the reference and this
+        oracle's default) from the low-res output up-sampled again.  Only oracle/hf_crosscheck_tracking.py sets it, to pin everything else."""
         from oracle import sam2_ref
+        self.cond_memory_from_full_res_mask = cond_memory_from_full_res_mask
         if num_maskmem > 7:
             raise ValueError("num_maskmem must be less than 7")                 # reference predictor.py:28-29
         self.S = sam2_ref
@@ -316,6 +320,8 @@ class VideoPredictorRef:
         pix, pos, s0, s1 = self._feats(frame_idx)
         low, high, ptr, obj = self._use_mask_as_output(pix, s0, s1, m)
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
+        if self.cond_memory_from_full_res_mask:
+            self.temp[obj_id][frame_idx]["high_res_for_memory"] = high
         return frame_idx, list(self.obj_ids), F.interpolate(low, size=self.video_hw, mode="bilinear", align_corners=False)
 
     @torch.no_grad()
@@ -355,6 +361,7 @@ class VideoPredictorRef:
             for t, out in self.temp[oid].items():
                 if out["maskmem_features"] is None:
                     high = F.interpolate(out["pred_masks"], size=(self.image_size, self.image_size), mode="bilinear", align_corners=False)
+                    high = out.pop("high_res_for_memory", high)
                     pix = self._feats(t)[0]
                     out["maskmem_features"], out["maskmem_pos_enc"] = self._encode_memory(pix, high, out["object_score_logits"], is_mask_from_pts=True)
                 self.out[oid]["cond"][t] = out

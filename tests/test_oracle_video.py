@@ -41,3 +41,14 @@ def test_rope_is_a_rotation():
     q[:, :16], k[:, :16] = torch.randn(16), torch.randn(16)
     s = V.rope_rotate(q, cos, sin) @ V.rope_rotate(k, cos, sin).T
     assert torch.allclose(s[1, 3], s[2, 4], atol=1e-4) and torch.allclose(s[9, 11], s[1, 3], atol=1e-4)
+
+
+def test_tracking_loop_matches_transformers_sam2_video_model():
+    """The whole tracking loop of the oracle (mask prompt, forward + backward propagation, num_maskmem = 2: which memories and object
+    pointers a frame attends to, their temporal encodings, pointer projection, object-score gating, memory encoding) against the independent
+    `transformers` Sam2VideoModel + Sam2VideoInferenceSession with shared weights (oracle/hf_crosscheck_tracking.py).  A semantic slip
+    (wrong temporal index, a pointer too many, a missed gate) moves the logits by O(1); agreeing implementations differ by the bf16 storage
+    of the memories meeting different fp32 summation orders: measured 2e-4 of the logit scale, object scores to 2e-4 absolute."""
+    pytest.importorskip("transformers")
+    from oracle import hf_crosscheck_tracking as H
+    assert H.crosscheck("tiny", Z=4, start=1, verbose=False) < 1e-3
