@@ -405,9 +405,13 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
         return (int64_t)(wl * 8 + xcd) * 256;
     };
     // the window's K and V rows of head h, global -> LDS: 2 * NINST 1-KB pieces, NINST / 4 of each operand per wave
-    auto issue = [&](int64_t tok0, int h, char* buf) {
+    // j0 .. j1: which of this wave's (NINST + 7) / 8 piece pairs (the next task's image is issued in four parts BETWEEN the MFMA groups
+    // of the current task: an LDS-DMA issue stalls the issuing wave for 60-185 cycles, which a burst of 10 at the task's start pays in
+    // full while the matrix cores idle - behind a wave's own MFMAs in flight the stall is hidden)
+    auto issue = [&](int64_t tok0, int h, char* buf, int j0 = 0, int j1 = 1000) {
 #pragma unroll
         for (int j = 0; j < (NINST + 7) / 8; ++j) {
+            if (j < j0 || j >= j1) continue;
             const int piece = wave + 8 * j;
             if (piece < NINST) {
                 const int o = piece * 1024 + lane * 16;
@@ -456,9 +460,9 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
         const int64_t tok_c = tok0;
         const int h_c = h;
         const bool more = u + nj < ntask;
-        if (more) {                                   // next task: K/V image into the other buffer, Q fragments into registers
+        char* nbuf = smem + ((it + 1) & 1) * BUF;
+        if (more) {                                   // next task: Q fragments into registers now, the K/V image in parts inside the key loop
             tok0 = task_ptr(u + nj, &h);
-            issue(tok0, h, smem + ((it + 1) & 1) * BUF);
             q_issue(tok0, h, qraw);
         }
         float m[2], l[2];
@@ -487,6 +491,9 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
                     for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
                 }
             }
+            constexpr int NJ = (NINST + 7) / 8;
+            // (placement measured on the stage-2 shape: 125 us per launch against 140 with all pairs at the task's start; pairs 1 | 1 | 2 | rest)
+            if (more) { if (kb == 0) issue(tok0, h, nbuf, 0, 1); else issue(tok0, h, nbuf, 2, NJ > 4 ? 4 : NJ); }
             bf16x8 pf[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -519,6 +526,7 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
                     pf[t][ks] = pack8(s[t][2 * ks][0], s[t][2 * ks][1], s[t][2 * ks][2], s[t][2 * ks][3], s[t][2 * ks + 1][0],
                                       s[t][2 * ks + 1][1], s[t][2 * ks + 1][2], s[t][2 * ks + 1][3]);
             }
+            if (more) { if (kb == 0) issue(tok0, h, nbuf, 1, 2); else issue(tok0, h, nbuf, NJ > 4 ? 4 : NJ, NJ); }
             // V^T fragments through inline asm: a compiler-visible ds_read_b64_tr_b16 is ordered behind the direct-to-LDS loads
             // of the NEXT task with s_waitcnt vmcnt(0), which would serialise the prefetch with this task's PV products
             const uint32_t va = (uint32_t)(uintptr_t)(lptr_a)vbase + (4 * fg + (fi >> 2)) * ROWB + 8 * (fi & 3);
