@@ -34,6 +34,11 @@ typedef __attribute__((address_space(3))) void* lptr_r;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define RL_BK 32
+// pieces of the K-step two ahead issued at the top of a K-step | behind its first MFMA group | behind the second (measured on the
+// stage-2 shapes against all of them at the top: fc2 401 -> 376 us, proj 219 -> 211 us)
+#define RL_SPLIT 1
+#define RL_Q1 1
+#define RL_Q2 3
 __device__ __forceinline__ int rl_perm(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0, 2, 3, 1}: gemm.hip g2perm
 __device__ __forceinline__ int rl_swz(int row, int chunk) { return row * 64 + ((chunk ^ rl_perm(row)) << 4); }
 
@@ -83,12 +88,16 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wpk, 0, (int)((uint32_t)nk * (uint32_t)CF::N * 64u), 0x00020000);
     // (the voffset argument is cast explicitly: voff[] has a template-dependent bound, which makes voff[q] type-dependent, and a
     // type-dependent argument of this builtin makes the HOST instantiation of the kernel template fail silently - no host stub)
-    auto issue = [&](const __amdgpu_buffer_rsrc_t& wrs, int tile, int kt) {
+    // q0 .. q1: which of the wave's NQ pieces (the K-step two ahead is issued in three parts BETWEEN the MFMA groups of the current one:
+    // an LDS-DMA issue stalls the issuing wave 60-185 cycles, and as a burst at the K-step's start - all eight waves at once, right
+    // behind the barrier - the matrix cores idle through every one of them)
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& wrs, int tile, int kt, int q0 = 0, int q1 = 100) {
         const int arows = min(R, p.M - tile * R);
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)tile * R * p.lda), 0, (int)((uint32_t)arows * (uint32_t)p.lda * 2u), 0x00020000);
         char* st = smem + (kt % 3) * STAGE;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+            if (q < q0 || q >= q1) continue;
             if (q * 8 < RA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], kt * (RL_BK * 2), 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], (int)(kt * (CF::N * 64)), 0, 0);
         }
@@ -110,7 +119,11 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
+#if RL_SPLIT
+            if (kt + 2 < nk) issue(wrsrc, t, kt + 2, 0, RL_Q1);
+#else
             if (kt + 2 < nk) issue(wrsrc, t, kt + 2);
+#endif
             const char* sa = smem + (kt % 3) * STAGE;
             const char* sw = sa + RA * 1024;
             // fragments in three column groups of 3 tiles: 16 + 12 live operand registers instead of 52 (the kernel lives on 256 VGPRs
@@ -128,6 +141,9 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj)
                         if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+#if RL_SPLIT
+                if (kt + 2 < nk) { if (jg == 0) issue(wrsrc, t, kt + 2, RL_Q1, RL_Q2); else if (jg == 1) issue(wrsrc, t, kt + 2, RL_Q2, NQ); }
+#endif
             }
             // K-step kt + 1 has landed (this wave's pieces); the youngest (kt + 2) may stay in flight
             if (kt + 2 < nk) { if (NQ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
