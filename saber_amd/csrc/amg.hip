@@ -161,7 +161,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     };
     std::vector<float> h_iou;
     std::vector<MaskStats> h_stats;
-    std::vector<int> h_idx, h_plane;
+    std::vector<int> h_idx, h_plane, keep_src;
     std::vector<float> h_pts, h_pts2;
 
     // engine-owned copy of the image: the encoder pass below is replayed from a hipGraph whose launches hold its address
@@ -340,15 +340,22 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             std::vector<float> sc(cand.size());
             for (size_t k = 0; k < cand.size(); ++k) sc[k] = cand[k].iou;
             const std::vector<int> keep = nms_host(cand, sc, prm->box_nms_thresh);
-            TRY(acc_reserve(acc_used + keep.size()));
             for (int k : keep) {
-                ENG_HIP(e, hipMemcpyAsync(e->amg_bits + acc_used * mask_words, crop_bits + (size_t)cand_src[k] * mask_words, mask_words * 4,
-                                          hipMemcpyDeviceToDevice, s));
                 Cand cd = cand[k];
-                cd.bits_slot = acc_used++;
+                cd.bits_slot = acc_used + keep_src.size();
+                keep_src.push_back(r.first + cand_src[k]);           // position in the batch's K8 scratch
                 all.push_back(cd);
             }
           }
+        }
+        // the batch's NMS survivors move from the K8 scratch to the accumulation buffer in ONE gather launch
+        if (!keep_src.empty()) {
+            TRY(acc_reserve(acc_used + keep_src.size()));
+            ENG_HIP(e, hipMemcpyAsync(e->amg_idx, keep_src.data(), sizeof(int) * keep_src.size(), hipMemcpyHostToDevice, s));
+            ENG_KP(e, PC_MASK_POST, 0.0, (double)keep_src.size() * mask_words * 8.0,
+                   launch_gather_masks(e->amg_crop_bits, e->amg_idx, e->amg_bits + acc_used * mask_words, (int)keep_src.size(), (int64_t)mask_words, s));
+            acc_used += keep_src.size();
+            keep_src.clear();
         }
     }
     std::vector<int> final_order(all.size());
@@ -366,9 +373,15 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         *out_count = nf;
         return eng_fail(e, SABER_ERR_CAPACITY, "amg_generate: " + std::to_string(nf) + " masks exceed max_masks=" + std::to_string(max_masks));
     }
+    if (nf > 0) {       // survivors of the cross-crop NMS, in their final order, to the caller's buffer: one gather launch
+        std::vector<int> slots(nf);
+        for (int k = 0; k < nf; ++k) slots[k] = (int)all[final_order[k]].bits_slot;
+        if (e->amg_stats_cap < (size_t)nf) { TRY(eng_regrow(e, &e->amg_stats, (size_t)nf, s)); TRY(eng_regrow(e, &e->amg_idx, (size_t)nf, s)); e->amg_stats_cap = nf; }
+        ENG_HIP(e, hipMemcpyAsync(e->amg_idx, slots.data(), sizeof(int) * nf, hipMemcpyHostToDevice, s));
+        ENG_KP(e, PC_MASK_POST, 0.0, (double)nf * mask_words * 8.0, launch_gather_masks(e->amg_bits, e->amg_idx, out_bits_dev, nf, (int64_t)mask_words, s));
+    }
     for (int k = 0; k < nf; ++k) {
         const Cand& cd = all[final_order[k]];
-        ENG_HIP(e, hipMemcpyAsync(out_bits_dev + (size_t)k * mask_words, e->amg_bits + cd.bits_slot * mask_words, mask_words * 4, hipMemcpyDeviceToDevice, s));
         saber_mask_meta& m = out_meta[k];
         m.area = cd.area;
         m.bbox_xywh[0] = cd.box[0]; m.bbox_xywh[1] = cd.box[1]; m.bbox_xywh[2] = cd.box[2] - cd.box[0]; m.bbox_xywh[3] = cd.box[3] - cd.box[1];

@@ -3,6 +3,8 @@
 // point-prompt tokens, the mask_downscaling dense prompt (m2m pass), the tiny fp32
 // attentions over 8 tokens, the hypernetwork mask product, dynamic multimask selection,
 // and K8: fused bilinear upsample + threshold + stability counts + bbox + bit-packing.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -851,6 +853,30 @@ const char* launch_label_plane(const uint32_t* bits, const int* order, int n, in
     const int64_t words = (int64_t)H * ((W + 31) >> 5);
     int blocks = (int)((words + 255) / 256);
     hipLaunchKernelGGL(label_plane_kernel, dim3(blocks), dim3(256), 0, s, bits, order, n, H, W, plane);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dst[i] = src[idx[i]] for n bit-packed masks of `words` 32-bit words: the AMG driver's compaction of NMS survivors (one launch
+// instead of one hipMemcpyAsync per kept mask: ~4.5 us each, two per mask, ~500 per slice once a few hundred masks survive)
+__global__ __launch_bounds__(256) void gather_masks_kernel(const uint32_t* __restrict__ src, const int* __restrict__ idx, uint32_t* __restrict__ dst,
+                                                           int64_t words) {
+    const int i = blockIdx.y;
+    const uint32_t* s = src + (int64_t)idx[i] * words;
+    uint32_t* d = dst + (int64_t)i * words;
+    if ((words & 3) == 0) {
+        const int64_t n4 = words >> 2;
+        for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < n4; w += (int64_t)gridDim.x * 256)
+            reinterpret_cast<uint4*>(d)[w] = reinterpret_cast<const uint4*>(s)[w];
+    } else {
+        for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256) d[w] = s[w];
+    }
+}
+const char* launch_gather_masks(const uint32_t* src, const int* idx, uint32_t* dst, int n, int64_t words, hipStream_t s) {
+    if (n <= 0) return nullptr;
+    if (n > 65535) return "gather_masks: more than 65535 masks";
+    const int64_t per = ((words & 3) == 0 ? words >> 2 : words);
+    hipLaunchKernelGGL(gather_masks_kernel, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), n), dim3(256), 0, s, src, idx, dst, words);
     return nullptr;
 }
 

@@ -127,6 +127,7 @@ struct MaskStats { int area; int inter; int uni; int x0; int y0; int x1; int y1;
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
                              int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s);
 // paint label planes: plane[y][x] = max over i (in order) ... later masks overwrite earlier ones (propagation.py:185-186)
+const char* launch_gather_masks(const uint32_t* src, const int* idx, uint32_t* dst, int n, int64_t words, hipStream_t s);
 const char* launch_label_plane(const uint32_t* bits, const int* order, int n, int H, int W, uint16_t* plane, hipStream_t s);
 // inter[i][j] = popcount(mask_i & mask_j) on bit-packed masks (n x words uint32)
 const char* launch_pair_intersections(const uint32_t* bits, int n, int64_t words, int* inter, hipStream_t s);
