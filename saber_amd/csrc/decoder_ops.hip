@@ -927,9 +927,63 @@ __global__ __launch_bounds__(256) void pair_inter_kernel(const uint32_t* __restr
     }
 }
 
+// The same counts for a PT x PT tile of pairs per block: every 16-byte word of a mask is loaded once per tile row / column instead of
+// once per pair (n = 249 masks of 1024^2: 8 GB of reads become 1 GB; the slice's post-filter tail 5.3 -> 1.8 ms).  words % 4 == 0.
+#define PT 8
+__global__ __launch_bounds__(256) void pair_inter_tiled_kernel(const uint32_t* __restrict__ bits, int n, int64_t words, int* __restrict__ inter) {
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj < ti) return;                                  // the tile's mirror image is written by the tile above the diagonal
+    const int64_t nv = words >> 2;
+    const uint4* rows_a[PT];
+    const uint4* rows_b[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        rows_a[q] = reinterpret_cast<const uint4*>(bits + (int64_t)min(ti * PT + q, n - 1) * words);
+        rows_b[q] = reinterpret_cast<const uint4*>(bits + (int64_t)min(tj * PT + q, n - 1) * words);
+    }
+    int acc[PT][PT];
+#pragma unroll
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) acc[a][b] = 0;
+    for (int64_t k = threadIdx.x; k < nv; k += 256) {
+        uint4 xa[PT], xb[PT];
+#pragma unroll
+        for (int q = 0; q < PT; ++q) { xa[q] = rows_a[q][k]; xb[q] = rows_b[q][k]; }
+#pragma unroll
+        for (int a = 0; a < PT; ++a)
+#pragma unroll
+            for (int b = 0; b < PT; ++b)
+                acc[a][b] += __popc(xa[a].x & xb[b].x) + __popc(xa[a].y & xb[b].y) + __popc(xa[a].z & xb[b].z) + __popc(xa[a].w & xb[b].w);
+    }
+    __shared__ int part[PT * PT];
+    if (threadIdx.x < PT * PT) part[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) {
+            int v = acc[a][b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&part[a * PT + b], v);
+        }
+    __syncthreads();
+    if (threadIdx.x < PT * PT) {
+        const int i = ti * PT + threadIdx.x / PT, j = tj * PT + threadIdx.x % PT;
+        if (i < n && j < n) { inter[(int64_t)i * n + j] = part[threadIdx.x]; inter[(int64_t)j * n + i] = part[threadIdx.x]; }
+    }
+}
+
 const char* launch_pair_intersections(const uint32_t* bits, int n, int64_t words, int* inter, hipStream_t s) {
     if (n <= 0) return nullptr;
     if ((uintptr_t)bits & 15) return "pair_intersections: masks must be 16-byte aligned";
-    hipLaunchKernelGGL(pair_inter_kernel, dim3(n, n), dim3(256), 0, s, bits, n, words, inter);
+    extern int g_saber_debug_flags;
+    if ((words & 3) == 0 && n > PT && !(g_saber_debug_flags & 65536)) {
+        const int nt = (n + PT - 1) / PT;
+        hipLaunchKernelGGL(pair_inter_tiled_kernel, dim3(nt, nt), dim3(256), 0, s, bits, n, words, inter);
+    } else {
+        hipLaunchKernelGGL(pair_inter_kernel, dim3(n, n), dim3(256), 0, s, bits, n, words, inter);
+    }
     return nullptr;
 }

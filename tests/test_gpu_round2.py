@@ -19,7 +19,7 @@ def ptr(t):
 def test_pair_intersections_against_matmul(engine):
     """reference: remove_duplicate_masks builds IoU from flat @ flat.T counts (saber/segmenters/utils.py:21-29)"""
     rng = np.random.default_rng(5)
-    for (n, H, W) in ((1, 64, 64), (7, 96, 160), (33, 130, 75), (40, 1024, 1024)):
+    for (n, H, W) in ((1, 64, 64), (7, 96, 160), (33, 130, 75), (40, 1024, 1024), (9, 96, 160), (251, 256, 256)):     # both kernels: one block per pair; 8 x 8 pairs per block
         masks = rng.uniform(size=(n, H, W)) > rng.uniform(0.3, 0.9, size=(n, 1, 1))
         masks[0] = False                                   # an empty mask
         W32 = (W + 31) // 32
