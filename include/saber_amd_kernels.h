@@ -76,6 +76,9 @@ int saber_k_conv3x3s2_t(const float* in, int H, int W, int Cin, const float* wt,
 /* plane[y][x] = label wherever logits (Hv,Wv) > thr at the nearest source pixel of the output pixel centre; any_flag (optional, device
  * int) is OR-ed with 1 when a pixel was painted.  SAM2Adapter.segment_volume's _apply, saber/adapters/sam2/predictor.py:288-298. */
 int saber_k_paint_nearest(const float* logits, int Hv, int Wv, float thr, int label, uint16_t* plane, int H, int W, int* any_flag, void* stream);
+/* out (n,H,W) bytes, 1 where bit (x & 31) of bits[n][y][x >> 5] is set: the bool `segmentation` arrays of SAM2AutomaticMaskGenerator's
+ * dict list (saber/adapters/sam2/automask.py:50-56 hands them to the segmenters), unpacked before the copy to the host */
+int saber_k_unpack_masks(const uint32_t* bits, int n, int H, int W, uint8_t* out, void* stream);
 /* depth-wise Conv2d(k7, p3) of the memory fuser's ConvNeXt blocks; w (C,1,7,7) */
 int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream);
 /* the video predictor's mask_downsample: Conv2d(1, 1, k4, s4) */

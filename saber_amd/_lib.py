@@ -103,6 +103,7 @@ SIGNATURES = {
     "saber_k_conv3x3s2": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "saber_k_conv3x3s2_t": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "saber_k_paint_nearest": (_i, [_vp, _i, _i, _f, _i, _vp, _i, _i, _vp, _vp]),
+    "saber_k_unpack_masks": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "saber_k_dwconv7": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),

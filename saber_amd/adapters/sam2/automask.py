@@ -66,10 +66,12 @@ class EngineMaskGenerator:
 
     def generate(self, image) -> List[Dict[str, Any]]:
         from saber_amd.engine import unpack_bits
-        W = image.shape[1]
+        from saber_amd.segmenters.utils import DEVICE_ROW_KEY, DeviceMaskRows
+        H, W = image.shape[:2]
         bits, meta = self.generate_device(image)
         masks = unpack_bits(bits, W) if len(meta) else []
-        return [{"segmentation": masks[i], "area": int(m.area), "bbox": [float(v) for v in m.bbox_xywh],
+        rows = DeviceMaskRows(self.engine, bits, H, W)
+        return [{"segmentation": masks[i], DEVICE_ROW_KEY: (rows, i), "area": int(m.area), "bbox": [float(v) for v in m.bbox_xywh],
                  "predicted_iou": float(m.predicted_iou), "point_coords": [[float(m.point_xy[0]), float(m.point_xy[1])]],
                  "stability_score": float(m.stability_score), "crop_box": [float(v) for v in m.crop_box_xywh]}
                 for i, m in enumerate(meta)]

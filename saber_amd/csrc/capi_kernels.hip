@@ -133,6 +133,10 @@ extern "C" int saber_k_conv3x3s2_t(const float* in, int H, int W, int Cin, const
 extern "C" int saber_k_paint_nearest(const float* logits, int Hv, int Wv, float thr, int label, uint16_t* plane, int H, int W, int* any_flag, void* stream) {
     return kcheck(launch_paint_nearest(logits, Hv, Wv, thr, label, plane, H, W, any_flag, (hipStream_t)stream));
 }
+extern "C" int saber_k_unpack_masks(const uint32_t* bits, int n, int H, int W, uint8_t* out, void* stream) {
+    if (n > 0 && (!bits || !out)) return kcheck("unpack_masks: null pointer");
+    return kcheck(launch_unpack_masks(bits, n, H, W, out, (hipStream_t)stream));
+}
 extern "C" int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream) {
     return kcheck(launch_dwconv7(in, H, W, C, w, b, out, (hipStream_t)stream));
 }

@@ -880,6 +880,38 @@ const char* launch_gather_masks(const uint32_t* src, const int* idx, uint32_t* d
     return nullptr;
 }
 
+// out[r][x] = bit (x & 31) of bits[r][x >> 5] as a 0/1 byte, r over n*H rows: the bool arrays the reference's dict lists hold, made on
+// the device so the host receives them ready (numpy's unpackbits + bool cast of 250 masks costs seconds on the host)
+__global__ __launch_bounds__(256) void unpack_masks_kernel(const uint32_t* __restrict__ bits, int64_t rows, int W, int W32, uint8_t* __restrict__ out) {
+    const int halves = (W + 15) >> 4;                        // 16-pixel pieces per row
+    const int64_t total = rows * halves;
+    const bool vec = (W & 15) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / halves;
+        const int hx = (int)(i - r * halves);
+        const uint32_t w = bits[r * W32 + (hx >> 1)] >> ((hx & 1) * 16);
+        uint8_t* o = out + r * W + hx * 16;
+        if (vec) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = ((w >> (4 * k)) & 1u) | (((w >> (4 * k + 1)) & 1u) << 8) | (((w >> (4 * k + 2)) & 1u) << 16) | (((w >> (4 * k + 3)) & 1u) << 24);
+            *reinterpret_cast<uint4*>(o) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+            const int lim = min(16, W - hx * 16);
+            for (int k = 0; k < lim; ++k) o[k] = (uint8_t)((w >> k) & 1u);
+        }
+    }
+}
+const char* launch_unpack_masks(const uint32_t* bits, int n, int H, int W, uint8_t* out, hipStream_t s) {
+    if (n <= 0) return nullptr;
+    if (H <= 0 || W <= 0) return "unpack_masks: bad shape";
+    const int64_t rows = (int64_t)n * H;
+    const int64_t total = rows * ((W + 15) >> 4);
+    hipLaunchKernelGGL(unpack_masks_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, s, bits, rows, W, (W + 31) / 32, out);
+    return nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void unpermute_nchw_kernel(const float* __restrict__ tok, int C, int stage, float* __restrict__ out) {
     const int g = 256 >> stage;

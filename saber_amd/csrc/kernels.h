@@ -138,6 +138,7 @@ const char* launch_unpermute_nchw(const float* tok, int C, int stage, float* out
 const char* launch_rope(const float* x, int64_t rows, int n_rot, int C, int side, float theta, float* out_f, bf16_t* out_bf, hipStream_t s);
 const char* launch_softmax_rows(const float* S, int64_t lds_, int64_t rows, int n, float scale, bf16_t* P, int64_t ldp, hipStream_t s);
 const char* launch_conv3x3s2(const float* in, int H, int W, int Cin, const float* w, const float* b, int Cout, float* out, hipStream_t s);
+const char* launch_unpack_masks(const uint32_t* bits, int n, int H, int W, uint8_t* out, hipStream_t s);
 const char* launch_paint_nearest(const float* logits, int Hv, int Wv, float thr, int label, uint16_t* plane, int H, int W, int* any_flag, hipStream_t s);
 const char* launch_conv3x3s2_t(const float* in, int H, int W, int Cin, const float* wt, const float* b, int Cout, float* out, hipStream_t s);
 const char* launch_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, hipStream_t s);

@@ -251,11 +251,25 @@ class Engine:
 
 
 def unpack_bits(bits: torch.Tensor, W: int) -> np.ndarray:
-    """(n,H,W32) int32 device tensor -> (n,H,W) bool numpy (bit b of word w = pixel 32w+b)."""
-    b = bits.cpu().numpy().view(np.uint32)
-    u8 = b.view(np.uint8).reshape(b.shape[0], b.shape[1], -1)  # little-endian bytes
-    out = np.unpackbits(u8, axis=-1, bitorder="little")
-    return out[..., :W].astype(bool)
+    """(n,H,W32) int32 device tensor -> (n,H,W) bool numpy (bit b of word w = pixel 32w+b).  Unpacked on the device
+    (saber_k_unpack_masks) and copied through a pinned buffer; the caller owns the returned array."""
+    n, H = bits.shape[:2]
+    if n == 0:
+        return np.zeros((0, H, W), dtype=bool)
+    assert bits.is_cuda and bits.is_contiguous() and bits.shape[2] == (W + 31) // 32
+    lib = _lib.load()
+    out = np.empty((n, H, W), dtype=np.uint8)
+    step = max(1, (64 << 20) // (H * W))                      # masks per pass: 64 MiB of device + pinned staging
+    dev = torch.empty((min(step, n), H, W), dtype=torch.uint8, device=bits.device)
+    pin = torch.empty((min(step, n), H, W), dtype=torch.uint8, pin_memory=True)
+    for i0 in range(0, n, step):
+        k = min(step, n - i0)
+        if lib.saber_k_unpack_masks(_ptr(bits[i0:i0 + k]), k, H, W, _ptr(dev), _stream()) != 0:
+            raise _lib.SaberAmdError(lib.saber_k_last_error().decode())
+        pin[:k].copy_(dev[:k], non_blocking=True)
+        torch.cuda.current_stream(bits.device).synchronize()
+        out[i0:i0 + k] = pin[:k].numpy()
+    return out.view(np.bool_)
 
 
 def make_amg_params(amg: Optional[dict] = None) -> "_lib.AmgParams":

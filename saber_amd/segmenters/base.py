@@ -68,6 +68,7 @@ class saber2D:
         masks = [m for m in masks if m["area"] >= self.min_mask_area]
         if self.remove_repeating_masks:
             masks = utils.remove_duplicate_masks(masks)
+        utils.strip_device_rows(masks)
         if self.classifier is None:
             return sorted(masks, key=lambda m: m["area"], reverse=False)
         from saber_amd.filters import masks as filters

@@ -51,11 +51,48 @@ def duplicate_groups_from_counts(areas: Sequence[int], inter: np.ndarray, stabil
     return keep
 
 
+DEVICE_ROW_KEY = "_device_row"
+
+
+class DeviceMaskRows:
+    """The bit-packed device masks an AMG dict list was unpacked from (EngineMaskGenerator.generate).  A dict that carries
+    (rows, i) under DEVICE_ROW_KEY says "my `segmentation` is row i of rows.bits"; the holder must drop the key when it changes the
+    array (saber2D strips it before the list leaves _apply_classifier, which also lets the device buffer go)."""
+
+    def __init__(self, engine, bits, H: int, W: int):
+        self.engine, self.bits, self.H, self.W = engine, bits, H, W
+
+    def intersections(self, idx: Sequence[int]) -> np.ndarray:
+        import torch
+        sel = self.bits[torch.as_tensor(list(idx), dtype=torch.long, device=self.bits.device)].contiguous()
+        return self.engine.pair_intersections(sel, self.H, self.W).cpu().numpy().astype(np.int64)
+
+
+def _shared_device_rows(masks):
+    refs = [m.get(DEVICE_ROW_KEY) for m in masks]
+    if any(r is None for r in refs) or any(r[0] is not refs[0][0] for r in refs):
+        return None
+    return refs[0][0], [r[1] for r in refs]
+
+
+def strip_device_rows(masks):
+    for m in masks:
+        m.pop(DEVICE_ROW_KEY, None)
+    return masks
+
+
 def remove_duplicate_masks(masks: List[Dict[str, Any]], iou_threshold: float = 0.9, area_threshold: float = 0.9,
                            verbose: bool = False) -> List[Dict[str, Any]]:
-    """Drop-in for the reference function on SAM-AMG dict lists with full bool `segmentation` arrays."""
+    """Drop-in for the reference function on SAM-AMG dict lists with full bool `segmentation` arrays.  When every dict still refers to
+    its bit-packed row on the device the pixel counts come from the pair-intersection kernel (same integers, no n x HW host matrix)."""
     if len(masks) == 0:
         return []
+    shared = _shared_device_rows(masks)
+    if shared is not None:
+        inter = shared[0].intersections(shared[1])
+        keep = duplicate_groups_from_counts([m["area"] for m in masks], inter, [m.get("stability_score", 0) for m in masks],
+                                            iou_threshold, area_threshold, pixel_counts=inter.diagonal())
+        return [masks[i] for i in keep]
     flat = np.stack([np.asarray(m["segmentation"], dtype=bool).ravel() for m in masks]).astype(np.float32)
     inter = np.rint(flat @ flat.T).astype(np.int64)  # exact: counts < 2^24
     keep = duplicate_groups_from_counts([m["area"] for m in masks], inter, [m.get("stability_score", 0) for m in masks],

@@ -119,3 +119,45 @@ def test_c_abi_call_leaves_callers_device_alone(engine):
     before = cur.value
     engine.prepare(torch.zeros(64, 64, device="cuda"))
     assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == before
+
+
+@pytest.mark.parametrize("shape", [(3, 17, 1024), (5, 40, 100), (2, 9, 37), (70, 1024, 1024)])
+def test_unpack_masks_against_numpy(gpu_lib, shape):
+    """saber_k_unpack_masks (the bool arrays of the AMG dict list) against numpy.unpackbits on the same words, ragged widths included;
+    70 x 1024^2 crosses the 64 MiB staging pass of engine.unpack_bits"""
+    from saber_amd.engine import unpack_bits
+    n, H, W = shape
+    rng = np.random.default_rng(W + n)
+    W32 = (W + 31) // 32
+    words = rng.integers(0, 2 ** 32, size=(n, H, W32), dtype=np.uint64).astype(np.uint32)
+    ref = np.unpackbits(words.view(np.uint8).reshape(n, H, -1), axis=-1, bitorder="little")[..., :W].astype(bool)
+    got = unpack_bits(torch.from_numpy(words.view(np.int32)).cuda(), W)
+    assert got.dtype == bool and got.shape == (n, H, W) and np.array_equal(got, ref)
+    assert unpack_bits(torch.zeros((0, H, W32), dtype=torch.int32, device="cuda"), W).shape == (0, H, W)
+
+
+def test_remove_duplicate_masks_device_rows_equal_host(engine):
+    """utils.remove_duplicate_masks with the dicts' device rows attached (EngineMaskGenerator.generate) keeps exactly what the host form
+    keeps from the bool arrays (saber/segmenters/utils.py:5-86), subsets and reorderings included"""
+    from saber_amd.engine import unpack_bits
+    from saber_amd.segmenters import utils
+    rng = np.random.default_rng(3)
+    n, H, W = 24, 128, 160
+    base = rng.uniform(size=(8, H, W)) > 0.6
+    masks = np.stack([base[i % 8] ^ (rng.uniform(size=(H, W)) > (0.999 if i % 3 else 0.9)) for i in range(n)])   # near and far copies
+    pad = np.zeros((n, H, ((W + 31) // 32) * 32), bool)
+    pad[..., :W] = masks
+    bits = torch.from_numpy(np.packbits(pad, axis=-1, bitorder="little").view(np.int32).copy()).cuda()
+    rows = utils.DeviceMaskRows(engine, bits, H, W)
+    seg = unpack_bits(bits, W)
+    stab = rng.uniform(0.9, 1.0, n)
+    def dicts(with_rows, order):
+        return [dict(segmentation=seg[i], area=int(seg[i].sum()), stability_score=float(stab[i]), tag=i,
+                     **({utils.DEVICE_ROW_KEY: (rows, i)} if with_rows else {})) for i in order]
+    for order in (list(range(n)), list(rng.permutation(n)), list(rng.permutation(n)[:11])):
+        host = [m["tag"] for m in utils.remove_duplicate_masks(dicts(False, order))]
+        dev = [m["tag"] for m in utils.remove_duplicate_masks(dicts(True, order))]
+        assert host == dev and len(host) < len(order)
+    mixed = dicts(True, range(n))
+    mixed[3].pop(utils.DEVICE_ROW_KEY)                           # one dict without its row: the host form runs
+    assert [m["tag"] for m in utils.remove_duplicate_masks(mixed)] == [m["tag"] for m in utils.remove_duplicate_masks(dicts(False, range(n)))]
