@@ -2,9 +2,13 @@
 per copick run: read the tomogram, run the segmenter, smooth the label volume (per-label adaptive 3-D Gaussian, on the device here), cast
 to uint8, write the segmentation, reset the segmenter's inference state.
 
-On-disk formats are NOT re-implemented: the reference reads and writes through third-party `copick_utils`
+The copick project layer is NOT re-implemented: the reference reads and writes tomograms through third-party `copick_utils`
 (`readers.tomogram`, `writers.segmentation`), which is absent from this image.  The two callables are therefore parameters (defaulting to
-copick_utils' own when it is installed), so a maintainer keeps the reference's I/O and swaps only the compute."""
+copick_utils' own when it is installed), so a maintainer keeps the reference's I/O and swaps only the compute.
+
+segment_micrograph_core (inference_core.py:100-164) - the per-file body of `saber segment micrographs`: read the micrograph (MRC / TIFF),
+Fourier-crop to the target resolution, run the 2-D segmenter, write image + label stack as one run of the OME-Zarr store (SURVEY.md 8
+row f-4: saber_amd.utils.{mrc,tiff,zarr_v2,zarr_writer})."""
 import logging
 
 import numpy as np
@@ -51,3 +55,31 @@ def segment_tomogram_core(run, voxel_size: float, tomogram_algorithm: str, segme
     torch.cuda.empty_cache()
     segmenter.inference_state = None
     return
+
+
+def segment_micrograph_core(input: str, output: str, scale_factor: float, target_resolution: float, display_image: bool,
+                            use_sliding_window: bool, gpu_id, models):
+    import os
+
+    from saber_amd.filters.downsample import FourierRescale2D
+    from saber_amd.utils import io, zarr_writer
+    segmenter = models["segmenter"]
+    zwriter = zarr_writer.get_zarr_writer(output)
+    zwriter.set_dict_attr("amg", segmenter.adapter_cfg.amg_cfg.to_dict())
+    torch.cuda.set_device(gpu_id)
+    image, pixel_size = io.read_micrograph(input)
+    image = image.astype(np.float32)
+    # (the reference compares target_resolution with a pixel size that may be None for TIFF input and fails there; same here)
+    if target_resolution is not None and target_resolution > pixel_size:
+        image = FourierRescale2D.run(image, target_resolution / pixel_size)
+    elif scale_factor is not None:
+        image = FourierRescale2D.run(image, scale_factor)
+    segmenter.segment(image, target_class=models.get("target_class", -1), display=False, use_sliding_window=use_sliding_window)
+    if isinstance(pixel_size, np.ndarray):
+        pixel_size = pixel_size.item()
+    masks = mask_filters.masks_to_array(segmenter.masks)
+    pixel_size = pixel_size / 10 if pixel_size is not None else 1        # Angstrom -> nanometer (inference_core.py:144-148)
+    out_image = segmenter.image
+    if out_image.ndim == 3:
+        out_image = out_image[:, :, 0]
+    zwriter.write(run_name=os.path.splitext(os.path.basename(input))[0], image=out_image, masks=masks, pixel_size=pixel_size)

@@ -115,6 +115,21 @@ def _semantic_segmentation(masks, predictions):
     return out
 
 
+def masks_to_array(mask_list):
+    """filters/masks.py:157-182: (n, H, W) stack with mask j holding the value j + 1, in the narrowest unsigned type that holds n.  The
+    reference looks at mask_list[0] before it tests for an empty list, so an empty list raises IndexError there and here."""
+    if not isinstance(mask_list, list):
+        print("Returning None")
+        return None
+    nx, ny = mask_list[0]["segmentation"].shape
+    n = len(mask_list)
+    dtype = np.uint8 if n < 256 else (np.uint16 if n < 65536 else np.uint32)
+    out = np.zeros((n, nx, ny), dtype=dtype)
+    for j, m in enumerate(mask_list):
+        out[j] = m["segmentation"].astype(dtype) * (j + 1)
+    return out
+
+
 def masks_to_list(masks):
     """saber/filters/masks.py:188-206"""
     if isinstance(masks, list):

@@ -1,0 +1,246 @@
+"""CPU: the on-disk formats either side of the path.  The third-party packages the reference reads and writes them
+with (mrcfile, zarr / numcodecs, skimage) are absent from this image, so these tests check the files against the published layouts
+themselves (MRC2014 header offsets, Zarr v2 metadata documents, the c-blosc-1 frame header, TIFF 6.0 tags) written out by hand here,
+plus the round trips, not against those packages."""
+import json
+import os
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+
+def test_mrc_header_offsets_and_round_trip(tmp_path):
+    from saber_amd.utils.mrc import read_mrc, write_mrc
+    rng = np.random.default_rng(0)
+    for arr, vox in ((rng.normal(size=(5, 12, 20)).astype(np.float32), 13.48), (rng.integers(0, 65535, (9, 7), dtype=np.uint16), 2.5),
+                     (rng.integers(-100, 100, (3, 4, 6)).astype(np.int16), 1.0), (rng.integers(-100, 100, (3, 4, 6)).astype(np.int8), 4.0)):
+        p = str(tmp_path / "a.mrc")
+        write_mrc(p, arr, voxel_size=vox)
+        raw = open(p, "rb").read()
+        nz, ny, nx = (1, *arr.shape) if arr.ndim == 2 else arr.shape
+        assert len(raw) == 1024 + arr.nbytes
+        assert struct.unpack_from("<4i", raw, 0) == (nx, ny, nz, {np.dtype("f4"): 2, np.dtype("u2"): 6, np.dtype("i2"): 1, np.dtype("i1"): 0}[arr.dtype])
+        assert struct.unpack_from("<3i", raw, 28) == (nx, ny, nz) and struct.unpack_from("<3i", raw, 64) == (1, 2, 3)
+        assert np.allclose(struct.unpack_from("<3f", raw, 40), (nx * vox, ny * vox, nz * vox), rtol=1e-6)
+        assert raw[208:212] == b"MAP " and raw[212:214] == b"\x44\x44" and struct.unpack_from("<i", raw, 92) == (0,)
+        back, v = read_mrc(p)
+        assert back.dtype == arr.dtype and np.array_equal(back, arr) and np.allclose(v, vox, rtol=1e-6)
+
+
+def test_mrc_hand_built_big_endian_with_extended_header(tmp_path):
+    """a file assembled byte by byte from the specification: big-endian machine stamp, 80 bytes of extended header, mode 1"""
+    from saber_amd.utils.mrc import read_mrc
+    data = np.arange(2 * 3 * 4, dtype=">i2").reshape(2, 3, 4)
+    head = bytearray(1024)
+    struct.pack_into(">4i", head, 0, 4, 3, 2, 1)
+    struct.pack_into(">3i", head, 28, 4, 3, 2)
+    struct.pack_into(">3f", head, 40, 8.0, 9.0, 10.0)
+    struct.pack_into(">i", head, 92, 80)
+    head[208:212] = b"MAP "
+    head[212:216] = b"\x11\x11\x00\x00"
+    p = str(tmp_path / "be.mrc")
+    open(p, "wb").write(bytes(head) + b"\x00" * 80 + data.tobytes())
+    back, v = read_mrc(p)
+    assert back.shape == (2, 3, 4) and np.array_equal(back, data.astype(np.int16)) and v == (2.0, 3.0, 5.0)
+    open(p, "wb").write(bytes(head)[:500])
+    with pytest.raises(ValueError):
+        read_mrc(p)
+
+
+def test_tiff_round_trip_and_hand_built_big_endian(tmp_path):
+    from saber_amd.utils.tiff import imread, imsave
+    rng = np.random.default_rng(1)
+    for arr in (rng.integers(0, 255, (6, 9), dtype=np.uint8), rng.integers(0, 65535, (3, 5, 7), dtype=np.uint16),
+                rng.normal(size=(4, 4)).astype(np.float32), rng.integers(-9, 9, (2, 3, 3)).astype(np.int32)):
+        p = str(tmp_path / "a.tif")
+        imsave(p, arr)
+        back = imread(p)
+        assert back.dtype == arr.dtype and np.array_equal(back, arr)
+    # big-endian, two strips, IFD after the data
+    img = np.arange(12, dtype=">u2").reshape(3, 4)
+    d = img.tobytes()
+    ent = [(256, 3, 1, 4), (257, 3, 1, 3), (258, 3, 1, 16), (259, 3, 1, 1), (277, 3, 1, 1), (278, 3, 1, 2), (339, 3, 1, 1)]
+    ifd_off = 8 + len(d)
+    arr_off = ifd_off + 2 + 12 * 9 + 4
+    body = struct.pack(">H", 9)
+    for tag, typ, cnt, val in ent:
+        body += struct.pack(">HHI", tag, typ, cnt) + struct.pack(">HH", val, 0)
+    body += struct.pack(">HHII", 273, 4, 2, arr_off) + struct.pack(">HHII", 279, 4, 2, arr_off + 8)
+    body += struct.pack(">I", 0) + struct.pack(">II", 8, 8 + 16) + struct.pack(">II", 16, 8)
+    p = str(tmp_path / "be.tif")
+    open(p, "wb").write(b"MM" + struct.pack(">HI", 42, ifd_off) + d + body)
+    assert np.array_equal(imread(p), img.astype(np.uint16))
+    bad = bytearray(open(p, "rb").read())
+    i = bytes(bad).index(struct.pack(">HHI", 259, 3, 1))
+    bad[i + 8:i + 10] = struct.pack(">H", 5)                       # LZW
+    open(p, "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="compressed"):
+        imread(p)
+
+
+def test_blosc_frame_layout_and_round_trip():
+    from saber_amd.utils.zarr_v2 import BloscZstd
+    pa = pytest.importorskip("pyarrow")
+    codec = BloscZstd(clevel=2, shuffle=2)
+    if codec._nc is not None:
+        pytest.skip("numcodecs present: its own frames are used")
+    rng = np.random.default_rng(2)
+    img = (rng.normal(1000, 5, (700, 300))).astype(np.float32)            # 840 000 bytes: 4 blocks of 256 KiB, the last one short
+    frame = codec.encode(img)
+    ver, verlz, flags, typesize, nbytes, bs, cbytes = struct.unpack_from("<BBBBIII", frame, 0)
+    assert (ver, verlz, typesize, nbytes, cbytes) == (2, 1, 4, img.nbytes, len(frame)) and bs == 256 << 10
+    assert flags == 0x01 | 0x10 | (4 << 5) and cbytes < nbytes
+    nblocks = -(-nbytes // bs)
+    starts = struct.unpack_from(f"<{nblocks}i", frame, 16)
+    assert starts[0] == 16 + 4 * nblocks
+    # block 0 decoded by hand: [int32 length][zstd frame] of the byte-shuffled block
+    (clen,) = struct.unpack_from("<i", frame, starts[0])
+    assert starts[1] == starts[0] + 4 + clen
+    blk = np.frombuffer(pa.Codec("zstd").decompress(frame[starts[0] + 4:starts[0] + 4 + clen], decompressed_size=bs, asbytes=True), np.uint8)
+    ne = bs // 4
+    assert np.array_equal(blk.reshape(4, ne).T.ravel(), img.reshape(-1).view(np.uint8)[:bs])
+    assert codec.decode(frame) == img.tobytes()
+    labels = np.zeros((3, 500, 500), np.uint8)
+    labels[1, 100:200, 50:300] = 2
+    f2 = codec.encode(labels)
+    assert len(f2) < labels.nbytes // 50 and f2[2] == 0x10 | (4 << 5) and codec.decode(f2) == labels.tobytes()   # typesize 1: no shuffle
+    noise = rng.integers(0, 256, 5000, dtype=np.uint8)                    # incompressible: stored as a memcpyed frame
+    f3 = codec.encode(noise)
+    assert f3[2] & 0x02 and len(f3) == 5000 + 16 and codec.decode(f3) == noise.tobytes()
+    tiny = np.arange(10, dtype=np.uint16)
+    assert codec.encode(tiny)[2] & 0x02 and codec.decode(codec.encode(tiny)) == tiny.tobytes()
+    with pytest.raises(ValueError):
+        codec.decode(frame[:-1])
+
+
+def test_zarr_store_documents_and_round_trip(tmp_path):
+    from saber_amd.utils import zarr_v2
+    root = zarr_v2.open_group(str(tmp_path / "s.zarr"), mode="w")
+    assert json.load(open(tmp_path / "s.zarr" / ".zgroup")) == {"zarr_format": 2}
+    g = root.create_group("run1")
+    rng = np.random.default_rng(3)
+    img = rng.normal(size=(130, 70)).astype(np.float32)
+    a = g.create_dataset("0", data=img, compressor=zarr_v2.BloscZstd(), chunks=(64, 32))
+    meta = json.load(open(tmp_path / "s.zarr" / "run1" / "0" / ".zarray"))
+    assert meta["shape"] == [130, 70] and meta["chunks"] == [64, 32] and meta["dtype"] == "<f4" and meta["order"] == "C"
+    assert meta["zarr_format"] == 2 and meta["filters"] is None and meta["fill_value"] == 0.0 and meta["dimension_separator"] == "/"
+    assert meta["compressor"]["id"] == "blosc" and meta["compressor"]["cname"] == "zstd" and meta["compressor"]["clevel"] == 2
+    for i in range(3):
+        for j in range(3):
+            assert os.path.isfile(tmp_path / "s.zarr" / "run1" / "0" / str(i) / str(j))      # nested chunk keys
+    edge = zarr_v2.BloscZstd().decode(open(tmp_path / "s.zarr" / "run1" / "0" / "2" / "2", "rb").read())
+    e = np.frombuffer(edge, np.float32).reshape(64, 32)                   # edge chunks are stored whole, padded with fill_value
+    assert np.array_equal(e[:2, :6], img[128:, 64:]) and not e[2:].any() and not e[:, 6:].any()
+    assert np.array_equal(a[:], img) and np.array_equal(root["run1"]["0"][10:20, 5:9], img[10:20, 5:9])
+    vol = rng.integers(0, 4, (40, 300, 300)).astype(np.uint8)
+    b = g.create_group("labels").create_dataset("0", data=vol, compressor=zarr_v2.BloscZstd())
+    assert np.prod(b.chunks) <= vol.size and np.array_equal(b[:], vol)
+    with pytest.raises(ValueError):
+        root.create_group("run1")
+    g.attrs["k"] = [1, 2]
+    g.attrs.update({"m": {"a": 1}})
+    assert json.load(open(tmp_path / "s.zarr" / "run1" / ".zattrs")) == {"k": [1, 2], "m": {"a": 1}}
+    assert zarr_v2.open_group(str(tmp_path / "s.zarr"))["run1"].attrs["k"] == [1, 2] and root.keys() == ["run1"]
+    assert zarr_v2.guess_chunks((1024, 1024), 4) == (256, 512) and zarr_v2.guess_chunks((100,), 1) == (100,)
+
+
+def test_parallel_zarr_writer_contract(tmp_path):
+    """saber/utils/zarr_writer.py: run groups with "0" and "labels/0", multiscales attributes (2-D on the run, 3-D on labels), root
+    attributes, thread-safe run indices"""
+    from saber_amd.utils import io, zarr_v2, zarr_writer
+    w = zarr_writer.ParallelZarrWriter(str(tmp_path / "out.zarr"))
+    w.set_dict_attr("amg", {"npoints": np.int64(32), "thr": np.float32(0.5), "arr": np.arange(3), "obj": object})
+    w.set_dict_attr("amg", {"npoints": 64, "extra": 1}, merge_missing=True)
+    rng = np.random.default_rng(4)
+    idx = []
+
+    def work(i):
+        img = rng.normal(size=(64, 48)).astype(np.float32)
+        masks = (rng.uniform(size=(3, 64, 48)) > 0.5).astype(np.uint8) * np.arange(1, 4, dtype=np.uint8)[:, None, None]
+        idx.append(w.write(f"run{i}", img, masks, pixel_size=0.5 if i % 2 else None, metadata={"i": i}))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    w.finalize()
+    assert sorted(idx) == list(range(8))
+    root = zarr_v2.open_group(str(tmp_path / "out.zarr"))
+    amg = root.attrs["amg"]
+    assert amg["npoints"] == 32 and amg["extra"] == 1 and amg["arr"] == [0, 1, 2] and abs(amg["thr"] - 0.5) < 1e-7 and isinstance(amg["obj"], str)
+    assert root.attrs["total_runs"] == 8 and root.attrs["creation_complete"] is True and root.keys() == [f"run{i}" for i in range(8)]
+    r = root["run3"]
+    ms = r.attrs["multiscales"][0]
+    assert [a["name"] for a in ms["axes"]] == ["y", "x"] and all(a == {"name": a["name"], "type": "space", "unit": "nanometer"} for a in ms["axes"])
+    assert ms["datasets"] == [{"coordinateTransformations": [{"scale": [0.5, 0.5], "type": "scale"}], "path": "0"}]
+    assert ms["name"] == "/" and ms["version"] == "0.4" and r.attrs["i"] == 3
+    ml = r["labels"].attrs["multiscales"][0]
+    assert [a["name"] for a in ml["axes"]] == ["z", "y", "x"] and ml["datasets"][0]["coordinateTransformations"][0]["scale"] == [1.0, 0.5, 0.5]
+    assert root["run0"].attrs["multiscales"][0]["datasets"][0]["coordinateTransformations"][0]["scale"] == [1.0, 1.0]
+    assert r["0"][:].shape == (64, 48) and r["labels"]["0"][:].dtype == np.uint8 and r["labels"]["0"][:].max() == 3
+    with pytest.raises(ValueError):
+        w.write("run3", np.zeros((2, 2), np.float32), np.zeros((1, 2, 2), np.uint8))
+    root.attrs["labels"] = ["background", "organelle"]
+    assert io.get_metadata(str(tmp_path / "out.zarr")) == ({0: "background", 1: "organelle"}, amg)
+
+
+def test_fourier_rescale_against_numpy():
+    """saber/filters/downsample.py:151-204 restated with numpy.fft: sizes, crop offsets (odd inputs), un-normalised transforms"""
+    import torch
+    from saber_amd.filters.downsample import FourierRescale2D, FourierRescale3D
+    rng = np.random.default_rng(5)
+    for shape, s in (((64, 96), 2.0), ((65, 97), 1.7), ((50, 50), 1.0)):
+        img = rng.normal(size=shape)
+        h, w = shape
+        hn, wn = int(h / s), int(w / s)
+        hn, wn = hn - hn % 2, wn - wn % 2
+        h0, w0 = (h - hn) // 2 + h % 2, (w - wn) // 2 + w % 2
+        ref = np.abs(np.fft.ifft2(np.fft.ifftshift(np.fft.fftshift(np.fft.fft2(img))[h0:h0 + hn, w0:w0 + wn])))
+        got = FourierRescale2D.run(img, s, device=torch.device("cpu"))
+        assert isinstance(got, np.ndarray) and got.shape == (hn, wn) and np.allclose(got, ref, atol=1e-9)
+    with pytest.raises(ValueError):
+        FourierRescale2D.run(img, 0.5)
+    with pytest.raises(ValueError):
+        FourierRescale2D.run_resolution(img, 10.0, 5.0)
+    assert FourierRescale2D.run_resolution(np.ones((8, 8)), 1.0, 2.0, device=torch.device("cpu")).shape == (4, 4)
+    vol = rng.normal(size=(9, 16, 20))
+    f = FourierRescale3D(5.0, (10.0, 10.0, 7.5))
+    f.device = torch.device("cpu")
+    out = f.run(vol)
+    assert f.calculate_cropping(torch.from_numpy(vol)) == (3, 4, 4, 4, 8, 12) and out.shape == (4, 8, 12)
+    spec = np.fft.fftshift(np.fft.fftn(vol, norm="ortho"))[3:7, 4:12, 4:16]
+    assert np.allclose(out, np.fft.ifftn(np.fft.ifftshift(spec), norm="ortho").real, atol=1e-9)
+    with pytest.raises(ValueError):
+        FourierRescale3D(10.0, 5.0)
+
+
+def test_read_micrograph_and_masks_to_array(tmp_path):
+    from saber_amd.filters.masks import masks_to_array
+    from saber_amd.utils import io
+    from saber_amd.utils.mrc import write_mrc
+    from saber_amd.utils.tiff import imsave
+    img = np.random.default_rng(6).normal(size=(20, 30)).astype(np.float32)
+    write_mrc(str(tmp_path / "m.mrc"), img, voxel_size=3.3)
+    d, px = io.read_micrograph(str(tmp_path / "m.mrc"))
+    assert np.array_equal(d, img) and abs(px - 3.3) < 1e-5
+    imsave(str(tmp_path / "m.tiff"), img)
+    d, px = io.read_micrograph(str(tmp_path / "m.tiff"))
+    assert np.array_equal(d, img) and px is None
+    with pytest.raises(ValueError, match="Unsupported file type"):
+        io.read_micrograph("a.png")
+    with pytest.raises(ValueError, match="Hyperspy"):
+        io.read_micrograph("a.dm4")
+    io.mask3D_to_tiff((np.arange(24).reshape(2, 3, 4) % 3).astype(np.uint8), str(tmp_path / "l.tif"))
+    assert io.read_movie(str(tmp_path / "l.tif"), 1).dtype == np.float32
+    segs = [{"segmentation": np.eye(4, dtype=bool)}, {"segmentation": np.ones((4, 4), bool)}]
+    arr = masks_to_array(segs)
+    assert arr.dtype == np.uint8 and arr.shape == (2, 4, 4) and arr[0].max() == 1 and (arr[1] == 2).all()
+    assert masks_to_array(segs * 130).dtype == np.uint16 and masks_to_array(np.zeros(3)) is None
+    with pytest.raises(IndexError):
+        masks_to_array([])
+
+    class Cfg:
+        class config:
+            overlay_root = "local://" + str(tmp_path / "ov")
+    io.save_copick_metadata(Cfg, {"a": [1, 2, 3], "b": {"c": "x"}}, "run.yaml")
+    assert open(tmp_path / "ov" / "logs" / "run.yaml").read() == "a: [1, 2, 3]\nb:\n  c: x\n"

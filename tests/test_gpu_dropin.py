@@ -173,3 +173,37 @@ def test_multi_depth_and_multiclass_entry_points():
     ps.filter_threshold = -1.0
     mc = ps.multiclass_segment(vol)
     assert mc.shape == vol.shape and mc.dtype == np.uint16 and set(np.unique(mc)) <= {0, 1, 2}
+
+
+def test_segment_micrograph_core_mrc_in_zarr_out(tmp_path):
+    """saber/entry_points/inference_core.py:100-164: MRC micrograph -> Fourier crop to the target resolution -> 2-D segmenter -> one run
+    of the OME-Zarr store (image "0", label stack "labels/0", pixel size in nanometer, AMG parameters as a root attribute)."""
+    import os
+    os.environ["SABER_AMD_SEEDED_WEIGHTS"] = "1"
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.entry_points.inference_core import segment_micrograph_core
+    from saber_amd.filters.downsample import FourierRescale2D
+    from saber_amd.segmenters.micro import cryoMicroSegmenter
+    from saber_amd.utils import zarr_v2, zarr_writer
+    from saber_amd.utils.mrc import write_mrc
+    amg = cfgAMG(npoints=8, crop_n_layers=0, pred_iou_thresh=0.2, stability_score_thresh=0.3, sam2_cfg="small")
+    seg = cryoMicroSegmenter(deviceID=0, cfg=SAM2AdapterConfig(cfg="tiny", amg_cfg=amg, min_mask_area=50), min_mask_area=50)
+    img = _volume(Z=1, S=768)[0]
+    write_mrc(str(tmp_path / "mic_001.mrc"), img, voxel_size=2.0)
+    zarr_writer._zarr_writer = None
+    out = str(tmp_path / "out.zarr")
+    segment_micrograph_core(str(tmp_path / "mic_001.mrc"), out, None, 4.0, False, False, 0, {"segmenter": seg})
+    zarr_writer.get_zarr_writer(out).finalize()
+    zarr_writer._zarr_writer = None
+    root = zarr_v2.open_group(out)
+    assert root.attrs["amg"]["npoints"] == 8 and root.attrs["total_runs"] == 1 and root.keys() == ["mic_001"]
+    run = root["mic_001"]
+    small = FourierRescale2D.run(img, 2.0)
+    assert run["0"].shape == (384, 384) and np.allclose(run["0"][:], small, rtol=1e-4, atol=1e-2 * np.abs(small).max())
+    lab = run["labels"]["0"][:]
+    assert lab.ndim == 3 and lab.shape[1:] == (384, 384) and lab.shape[0] == len(seg.masks) > 0 and lab.dtype == np.uint8
+    for j, m in enumerate(seg.masks):
+        assert np.array_equal(lab[j] == j + 1, m["segmentation"]) and "_device_row" not in m
+    scale = run.attrs["multiscales"][0]["datasets"][0]["coordinateTransformations"][0]["scale"]
+    assert np.allclose(scale, [0.2, 0.2])      # the reference records the file's pixel size / 10, not the resampled one (inference_core.py:144-148)
