@@ -125,6 +125,14 @@ int saber_get_embed_tokens(saber_engine* e, int slot, float* out_tokens_dev, voi
 int saber_set_embed_tokens(saber_engine* e, int slot, const float* tokens_dev, void* stream);
 int saber_get_decoder_tokens(saber_engine* e, int n, float* out_dev, void* stream);
 
+/* Slot state in and out of a handle (SURVEY.md 8e "Propagation path": the per-frame image encodes of one tomogram are independent and
+ * shard over ranks; the tracking chain that consumes them is sequential.  Upstream keeps these per-frame features in
+ * inference_state["cached_features"], sam2_video_predictor.py).  n consecutive slots from slot0, each as three fp32 device arrays in the
+ * engine's token order: image_embed 4096 x 256, feat_s1 16384 x 64, feat_s0 65536 x 32.  import marks the slots as encoded; only
+ * meaningful between handles built from the same model configuration and weights. */
+int saber_export_slots(saber_engine* e, int slot0, int n, float* emb_dev, float* fs1_dev, float* fs0_dev, void* stream);
+int saber_import_slots(saber_engine* e, int slot0, int n, const float* emb_dev, const float* fs1_dev, const float* fs0_dev, void* stream);
+
 /* Decode n point prompts against a slot.  pts_dev: (n,2) in model pixels (0..1024); labels_dev: (n) or NULL (=1).
  * mask_in_dev: (n,256,256) low-res logits or NULL.  multimask: 3 masks per prompt, else 1 (dynamic selection).
  * Outputs: lowres (n,M,256,256), iou (n,M), obj (n) - any may be NULL. */

@@ -61,6 +61,8 @@ SIGNATURES = {
     "saber_get_features": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "saber_get_embed_tokens": (_i, [_vp, _i, _vp, _vp]),
     "saber_set_embed_tokens": (_i, [_vp, _i, _vp, _vp]),
+    "saber_export_slots": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "saber_import_slots": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_get_decoder_tokens": (_i, [_vp, _i, _vp, _vp]),
     "saber_decode_points": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),

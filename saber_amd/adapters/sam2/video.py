@@ -21,6 +21,7 @@ predictor.py:28-34); the optional hole-filling CUDA extension of upstream is tre
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -57,6 +58,13 @@ def _sine_pe_1d(pos: np.ndarray, dim: int) -> np.ndarray:
     dim_t = np.float32(10000.0) ** (2 * np.floor(np.arange(pe_dim, dtype=np.float32) / 2) / np.float32(pe_dim))
     e = pos.astype(np.float32)[:, None] / dim_t
     return np.concatenate([np.sin(e), np.cos(e)], -1).astype(np.float32)
+
+
+def window_shares(k: int, world: int) -> List[Tuple[int, int]]:
+    """[a, b) of the k frames of a window for each of `world` ranks: contiguous, ceil(k / world) frames each until the frames run out
+    (the trailing ranks of a short window get nothing)."""
+    per = -(-k // world) if k > 0 else 0
+    return [(min(k, r * per), min(k, (r + 1) * per)) for r in range(world)]
 
 
 def load_tomogram_frames(tomogram: np.ndarray, image_size: int = 1024, light_modality: bool = False) -> np.ndarray:
@@ -119,6 +127,7 @@ class VideoPredictor:
             raise RuntimeError(self.lib.saber_k_last_error().decode())
         self.num_maskmem = num_maskmem
         self.image_size = 1024
+        self.shard_encodes = os.environ.get("SABER_AMD_VIDEO_SHARD", "1") != "0"
         self._keep: List[torch.Tensor] = []
         W = weights
         missing = [k for k in ("memory_attention.norm.weight", "memory_encoder.out_proj.weight", "obj_ptr_proj.layers.0.weight", "maskmem_tpos_enc") if k not in W]
@@ -221,8 +230,12 @@ class VideoPredictor:
             self._frames_dev = (self.images.to(self.dev, dtype=torch.float32).contiguous() if isinstance(self.images, torch.Tensor) else
                                 torch.from_numpy(np.ascontiguousarray(self.images, dtype=np.float32)).to(self.dev))
         k = t1 - t0
-        self.eng.encode(self._frames_dev[t0:t1].view(k * 1024, 1024), crop_boxes=[[0, i * 1024, 1024, (i + 1) * 1024] for i in range(k)],
-                        slot0=0, normalised_grey=True)
+        world, rank = self._ranks()
+        if world > 1:
+            self._encode_window_sharded(t0, t1, world, rank)
+        else:
+            self.eng.encode(self._frames_dev[t0:t1].view(k * 1024, 1024), crop_boxes=[[0, i * 1024, 1024, (i + 1) * 1024] for i in range(k)],
+                            slot0=0, normalised_grey=True)
         self._raw, self._win = {}, (t0, t1)
         for i in range(k):
             emb = self._new(4096, 256)
@@ -231,6 +244,44 @@ class VideoPredictor:
             self._ck(self.lib.saber_k_add_to_bf16(self._p(emb), self._p(self.neg_no_mem), 1, None, self._p(raw), 4096, 256, self._s()))
             self._raw[t0 + i] = raw
         return self._raw[t]
+
+    def _ranks(self) -> Tuple[int, int]:
+        """(world size, rank) the window encodes shard over: the default process group when one is initialised with more than one rank and
+        sharding is not switched off (shard_encodes=False / SABER_AMD_VIDEO_SHARD=0).  Every rank must then run the same tracking calls on
+        the same volume: the chain itself is replicated, only the Hiera passes are divided."""
+        import torch.distributed as dist
+        if not self.shard_encodes or not dist.is_available() or not dist.is_initialized():
+            return 1, 0
+        return dist.get_world_size(), dist.get_rank()
+
+    def _encode_window_sharded(self, t0: int, t1: int, world: int, rank: int):
+        """the frames of a window are dealt to the ranks in contiguous shares (window_shares), each rank encodes its
+        share into slots 0.., exports them, one all-gather per feature array (RCCL; staged through host memory under gloo) brings every
+        frame to every rank, and the gathered features are imported into slots 0..k-1 - bit-identical to encoding all k here, because the
+        encoder's per-image results do not depend on the batch they ran in (tests/test_gpu_graphs.py)."""
+        import torch.distributed as dist
+        k = t1 - t0
+        shares = window_shares(k, world)
+        per = shares[0][1] - shares[0][0]
+        a, b = shares[rank]
+        n = b - a
+        if n > 0:
+            self.eng.encode(self._frames_dev[t0 + a:t0 + b].view(n * 1024, 1024), crop_boxes=[[0, i * 1024, 1024, (i + 1) * 1024] for i in range(n)],
+                            slot0=0, normalised_grey=True)
+        sizes = (4096 * 256, 16384 * 64, 65536 * 32)
+        mine = [torch.zeros((per, sz), dtype=torch.float32, device=self.dev) for sz in sizes]
+        self.eng._check(self.lib.saber_export_slots(self.eng.h, 0, n, self._p(mine[0]), self._p(mine[1]), self._p(mine[2]), self._s()))
+        every = [torch.empty((world * per, sz), dtype=torch.float32, device=self.dev) for sz in sizes]
+        on_device = dist.get_backend() == "nccl"
+        for src, dst in zip(mine, every):
+            if on_device:
+                dist.all_gather_into_tensor(dst, src)
+            else:
+                host = torch.empty(dst.shape, dtype=torch.float32)
+                dist.all_gather_into_tensor(host, src.cpu())
+                dst.copy_(host)
+        # rank r's share sits at rows [r * per, r * per + its length) = frames [r * per, ...) of the window: already in slot order
+        self.eng._check(self.lib.saber_import_slots(self.eng.h, 0, k, self._p(every[0]), self._p(every[1]), self._p(every[2]), self._s()))
 
     def _slot(self, t: int) -> int:
         assert self._win[0] <= t < self._win[1]

@@ -922,6 +922,37 @@ extern "C" int saber_set_embed_tokens(saber_engine* e, int slot, const float* to
     e->slot_shared_valid[slot] = 0;        // image_embed + no_mask_embed of this slot must be rebuilt
     return SABER_OK;
 }
+// Slot state across engine handles / ranks (propagation path: the per-frame encodes of a tomogram shard over ranks and are
+// all-gathered).  A slot is three fp32 arrays in the engine's own token order: image_embed 4096 x 256, feat_s1 16384 x 64, feat_s0
+// 65536 x 32 (16 MiB); export / import are plain device copies, so a slot imported from another handle of the same model decodes
+// bit-identically to one encoded here.
+extern "C" int saber_export_slots(saber_engine* e, int slot0, int n, float* emb_dev, float* fs1_dev, float* fs0_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (n < 0 || slot0 < 0 || slot0 + n > e->max_images || (n > 0 && (!emb_dev || !fs1_dev || !fs0_dev))) return eng_fail(e, SABER_ERR_INVALID, "export_slots: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!e->slot_valid[slot0 + i]) return eng_fail(e, SABER_ERR_STATE, "export_slots: slot holds no encoded image; call saber_encode first");
+    ENG_DEVICE(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return SABER_OK;
+    ENG_HIP(e, hipMemcpyAsync(emb_dev, e->emb + (size_t)slot0 * 4096 * 256, (size_t)n * 4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ENG_HIP(e, hipMemcpyAsync(fs1_dev, e->fs1 + (size_t)slot0 * 16384 * 64, (size_t)n * 16384 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ENG_HIP(e, hipMemcpyAsync(fs0_dev, e->fs0 + (size_t)slot0 * 65536 * 32, (size_t)n * 65536 * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SABER_OK;
+}
+extern "C" int saber_import_slots(saber_engine* e, int slot0, int n, const float* emb_dev, const float* fs1_dev, const float* fs0_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
+    if (n < 0 || slot0 < 0 || slot0 + n > e->max_images || (n > 0 && (!emb_dev || !fs1_dev || !fs0_dev))) return eng_fail(e, SABER_ERR_INVALID, "import_slots: bad argument");
+    ENG_DEVICE(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return SABER_OK;
+    ENG_HIP(e, hipMemcpyAsync(e->emb + (size_t)slot0 * 4096 * 256, emb_dev, (size_t)n * 4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ENG_HIP(e, hipMemcpyAsync(e->fs1 + (size_t)slot0 * 16384 * 64, fs1_dev, (size_t)n * 16384 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ENG_HIP(e, hipMemcpyAsync(e->fs0 + (size_t)slot0 * 65536 * 32, fs0_dev, (size_t)n * 65536 * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
+    return SABER_OK;
+}
 // the 8 tokens of the first n prompts of the LAST decode call after the two-way transformer ([obj, iou, mask0..3, point, pad] x 256 fp32):
 // the video path projects one mask token to the object pointer (upstream obj_ptr_proj(sam_output_token))
 extern "C" int saber_get_decoder_tokens(saber_engine* e, int n, float* out_dev, void* stream) {

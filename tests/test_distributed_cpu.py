@@ -56,3 +56,20 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == Z
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_video_window_shares_partition_the_window():
+    """adapters/sam2/video.py: window_shares - contiguous, in order, ceil(k / world) each until the frames run out (rank r's share starts at
+    r * per, which is what lets the all-gathered rows be imported as slots 0..k-1 without reordering)"""
+    pytest.importorskip("torch")
+    try:
+        from saber_amd.adapters.sam2.video import window_shares
+    except Exception as ex:            # the module binds the HIP library at import; without it this host check cannot run
+        pytest.skip(str(ex)[:80])
+    for k in range(0, 22):
+        for world in (1, 2, 3, 4, 8):
+            sh = window_shares(k, world)
+            per = -(-k // world) if k else 0
+            assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == k
+            assert all(a <= b and b - a <= per for a, b in sh) and all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+            assert all(a == r * per for r, (a, b) in enumerate(sh) if b > a)

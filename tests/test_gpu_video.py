@@ -282,3 +282,28 @@ def test_two_objects_segment_volume_against_oracle(video_case):
         # object 1 survives only where object 2's (image-filling, seeded-weights) mask is absent: ~1 400 voxels whose outline is object 2's
         # near-zero-logit boundary, so a few dozen voxels flip with the bf16 residual (measured 0.967); the large label is tight
         assert inter / max(1, uni) > (0.995 if uni > 50000 else 0.94)
+
+
+def test_window_encodes_sharded_over_ranks(tmp_path):
+    """SURVEY.md 8e (propagation path): the per-frame Hiera passes of a window shard over the ranks of the process group and are
+    all-gathered (saber_export_slots / saber_import_slots); the replicated tracking chain must then give every rank exactly what one
+    process gives.  Two gloo ranks on this one GPU (RCCL needs a GPU per rank), 7 frames in windows of 3: shares of 2 + 1 frames and a
+    last window whose second rank has nothing to encode."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "video_shard_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base = str(tmp_path / "one.npz")
+    subprocess.run([sys.executable, worker, base], check=True, env=env, timeout=300)
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path / f"r{r}.npz")], env=e))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    one = np.load(base)
+    assert int(one["sharded"]) == 1 and (one["vol"] > 0).sum() > 0
+    for r in range(2):
+        got = np.load(str(tmp_path / f"r{r}.npz"))
+        assert int(got["sharded"]) == 2
+        assert np.array_equal(got["vol"], one["vol"]) and np.array_equal(got["scores"], one["scores"]), r
