@@ -21,6 +21,10 @@ def main():
         shapes += [(f"s{stage + 1} qkv", M, 3 * dim, dim, 0), (f"s{stage + 1} fc1", M, 4 * dim, dim, 1), (f"s{stage + 1} fc2", M, dim, 4 * dim, 0),
                    (f"s{stage + 1} proj", M, dim, dim, 0)]
     p = lambda t: C.c_void_p(t.data_ptr())
+    warm = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
+    for _ in range(50):
+        warm @ warm
+    torch.cuda.synchronize()
     print(f"{'shape':10s} {'M':>8s} {'N':>5s} {'K':>5s} | {'ours us':>9s} {'TF/s':>7s} | {'library us':>10s} {'TF/s':>7s}")
     for name, M, N, K, act in shapes:
         A = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
@@ -28,9 +32,13 @@ def main():
         b = torch.randn(N, device="cuda")
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
 
+        Kp = (K + 63) // 64 * 64                      # the engine keeps W rows zero-padded to a multiple of 64 in K (w_kpad)
+        Wp = torch.zeros(N, Kp, dtype=torch.bfloat16, device="cuda")
+        Wp[:, :K] = W
+
         def ours():
-            st = lib.saber_k_gemm(p(A.view(torch.uint16)), p(W.view(torch.uint16)), p(b), None, None, p(out.view(torch.uint16)), M, N, K, act, 0, 0, 0, 0,
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            st = lib.saber_k_gemm_ld(p(A.view(torch.uint16)), K, p(Wp.view(torch.uint16)), Kp, 1, p(b), None, None, p(out.view(torch.uint16)), M, N, K, act,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
             assert st == 0, lib.saber_k_last_error()
         bb = b.to(torch.bfloat16)
 
@@ -41,8 +49,9 @@ def main():
         def vendor_mm():            # the GEMM alone (GELU is a second kernel in the library path)
             return torch.nn.functional.linear(A, W, bb)
 
-        def t(f, reps=5):
-            f()
+        def t(f, reps=40):
+            for _ in range(10):                       # clocks ramp over tens of milliseconds: an unwarmed 5-launch sample reads up to 2x slow
+                f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -52,6 +61,7 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps * 1e3
         to, tv = t(ours), t(vendor_mm)
+        to, tv = min(to, t(ours)), min(tv, t(vendor_mm))
         fl = 2.0 * M * N * K
         ref = vendor().float()
         err = ((out.float() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
