@@ -20,6 +20,7 @@ extern "C" int saber_k_init(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return kfail("hipSetDevice failed");
     const char* m = gemm_init_device();
     if (!m) m = gemm_rowln_init_device();
+    if (!m) m = gemm_w1_init_device();
     if (!m) m = hiera_attention_init_device();
     if (!m) m = image_ops_init_device();
     if (!m) m = decoder_fused_init_device();

@@ -910,6 +910,9 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1 && (p.act == ACT_NONE || p.act == ACT_GELU);
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    // opt-in (development flag 131072; + 262144: also for problems of fewer than 256 tiles): the one-wave-per-SIMD kernel of gemm_w1.hip.
+    // Parity-green, level with the kernels below on the fc2-like shapes and 4-12 % behind on qkv / fc1: not the default.
+    if ((p.dbg & 131072) && bf16_only && (tiles_p2 >= 256 || (p.dbg & 262144)) && gemm_w1_supported(p)) return launch_gemm_w1(p, stream);
     if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);

@@ -38,6 +38,10 @@ const char* gemm_init_device();
 bool gemm_rowln_supported(const GemmParams& p);
 const char* launch_gemm_rowln(const GemmParams& p, hipStream_t stream);
 const char* gemm_rowln_init_device();
+// one wave per SIMD, 128x128 wave tiles (gemm_w1.hip): bf16-output GEMMs with K % 32 == 0
+bool gemm_w1_supported(const GemmParams& p);
+const char* launch_gemm_w1(const GemmParams& p, hipStream_t stream);
+const char* gemm_w1_init_device();
 // W [N][ldw] (rows zero-padded) -> Wpk[ceil(K/32)][N][32] with the LDS chunk permutation of the row-owner kernel applied
 size_t gemm_rowln_packed_elems(int N, int K);
 const char* launch_pack_w_kstep(const bf16_t* W, int ldw, int N, int K, bf16_t* out, hipStream_t s);
