@@ -207,3 +207,33 @@ def test_segment_micrograph_core_mrc_in_zarr_out(tmp_path):
         assert np.array_equal(lab[j] == j + 1, m["segmentation"]) and "_device_row" not in m
     scale = run.attrs["multiscales"][0]["datasets"][0]["coordinateTransformations"][0]["scale"]
     assert np.allclose(scale, [0.2, 0.2])      # the reference records the file's pixel size / 10, not the resampled one (inference_core.py:144-148)
+
+
+def test_sliding_window_branch_rasterises_window_masks():
+    """saber2D.segment_image(use_sliding_window=True) (reference base.py:103-150): each window is segmented on its own, masks stay
+    window-sized with an offset until rasterize_masks pastes them into full-size arrays; the result is the concatenation of what the
+    per-window path gives, in window order (duplicate removal runs per window, here from the device rows of each window's masks)."""
+    import os
+    os.environ["SABER_AMD_SEEDED_WEIGHTS"] = "1"
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.segmenters.micro import cryoMicroSegmenter
+    amg = cfgAMG(npoints=8, crop_n_layers=0, pred_iou_thresh=0.2, stability_score_thresh=0.3, sam2_cfg="small")
+    seg = cryoMicroSegmenter(deviceID=0, cfg=SAM2AdapterConfig(cfg="tiny", amg_cfg=amg, min_mask_area=50), min_mask_area=50,
+                             window_size=256, overlap_ratio=0.25)
+    img = _volume(Z=1, S=448)[0]
+    wins = seg.get_sliding_windows(img.shape)
+    assert len(wins) > 1
+    masks = seg.segment(img, display=False, use_sliding_window=True)
+    expect = []
+    for (y1, x1, y2, x2) in wins:
+        found = [m for m in seg.adapter.segment_image_2d(img[y1:y2, x1:x2]) if m["area"] >= 50]
+        for m in seg._apply_classifier(img[y1:y2, x1:x2], found):
+            full = np.zeros(img.shape, bool)
+            full[y1:y2, x1:x2] = m["segmentation"]
+            expect.append((full, (y1, x1), [m["bbox"][0] + x1, m["bbox"][1] + y1, m["bbox"][2], m["bbox"][3]], m["area"]))
+    assert len(masks) == len(expect) > 0
+    for m, (full, off, bbox, area) in zip(masks, expect):
+        assert m["segmentation"].shape == img.shape and np.array_equal(m["segmentation"], full)
+        assert tuple(m["offset"]) == off and list(m["bbox"]) == bbox and m["area"] == area == int(full.sum())
+        assert "_device_row" not in m
