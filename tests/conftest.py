@@ -48,3 +48,14 @@ def oracle_large(large_weights):
     from oracle import sam2_ref
     cfg, W = large_weights
     return cfg, sam2_ref.to_torch(W)
+
+
+def amg_case(name):
+    """Masks of one oracle AMG case from tests/golden/amg_cases_large_seed0.npz (oracle/make_golden_amg_cases.py): the quarter-resolution
+    samples [2::4, 2::4] of every mask, list of {"segmentation": bool array}; compare with the same samples of the engine's masks"""
+    import os
+    import numpy as np
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "amg_cases_large_seed0.npz"))
+    W = int(G[name + "_width"])
+    seg = np.unpackbits(G[name + "_bits"], axis=-1)[..., :W].astype(bool)
+    return [{"segmentation": m} for m in seg]

@@ -121,14 +121,14 @@ def _match_masks(a, b):
 
 
 @pytest.mark.parametrize("layers,nms", [(0, 1.0), (1, 0.95)])
-def test_amg_parity(engine, image, oracle_large, large_weights, layers, nms):
-    from oracle.sam2_ref import ImagePredictorRef
-    from oracle.amg_ref import amg_from_saber_cfg
+def test_amg_parity(engine, image, layers, nms):
+    """engine AMG against the fp32 oracle's (oracle/sam2_ref + oracle/amg_ref on the same seeded weights and image; the oracle side is
+    the committed result of oracle/make_golden_amg_cases.py - it costs 30-100 s of host time per case on the GPU box)"""
+    from conftest import amg_case
     from saber_amd.engine import make_amg_params, unpack_bits
-    cfg, Wnp = large_weights
     # nms 1.0 disables box suppression (IoU > 1 never holds): every mask that passes the score filters is compared
     amg = dict(npoints=6, crop_n_layers=layers, box_nms_thresh=nms, pred_iou_thresh=0.5, stability_score_thresh=0.8)
-    ref = amg_from_saber_cfg(ImagePredictorRef(Wnp, cfg), amg).generate(np.repeat(image[..., None], 3, 2))
+    ref = amg_case(f"fp32_l{layers}")
     bits, meta = engine.amg_generate(torch.from_numpy(image).cuda(), make_amg_params(amg), max_masks=512)
     got = unpack_bits(bits, 1024)
     print(f"AMG layers={layers}: oracle {len(ref)} masks, engine {len(meta)} masks")
@@ -136,7 +136,7 @@ def test_amg_parity(engine, image, oracle_large, large_weights, layers, nms):
     # bf16 vs fp32 logits can flip a borderline filter decision (the emulating-oracle test is the tight one): the sets must agree
     # up to 5 % (measured: same count) and matched masks must coincide (measured median IoU 0.994)
     assert abs(len(ref) - len(meta)) <= max(2, int(0.05 * len(ref)))
-    ious = _match_masks(list(got), [r["segmentation"] for r in ref])
+    ious = _match_masks(list(got[:, 2::4, 2::4]), [r["segmentation"] for r in ref])      # quarter-resolution samples of both sides
     good = np.mean(np.array(ious) > 0.97)
     print("matched IoU: median", float(np.median(ious)), "fraction>0.97", float(good))
     assert good >= 0.9 and np.median(ious) >= 0.988
@@ -146,13 +146,11 @@ def test_amg_parity(engine, image, oracle_large, large_weights, layers, nms):
         assert [m.bbox_xywh[0], m.bbox_xywh[1], m.bbox_xywh[2], m.bbox_xywh[3]] == [xs.min(), ys.min(), xs.max() - xs.min(), ys.max() - ys.min()]
 
 
-def test_amg_parity_non_square_image(engine, large_weights):
+def test_amg_parity_non_square_image(engine):
     """ragged input: a 600 x 840 image (crop boxes, point grids, bilinear up-sampling to a non-square crop, bit rows that are not a
     multiple of 32 wide)"""
-    from oracle.sam2_ref import ImagePredictorRef
-    from oracle.amg_ref import amg_from_saber_cfg
+    from conftest import amg_case
     from saber_amd.engine import make_amg_params, unpack_bits
-    cfg, Wnp = large_weights
     rng = np.random.default_rng(21)
     H, W = 600, 840
     img = rng.uniform(0, 1, (H, W)).astype(np.float32)
@@ -161,13 +159,13 @@ def test_amg_parity_non_square_image(engine, large_weights):
         cy, cx, r = rng.integers(60, H - 60), rng.integers(60, W - 60), rng.integers(25, 90)
         img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
     amg = dict(npoints=6, crop_n_layers=0, box_nms_thresh=1.0, pred_iou_thresh=0.5, stability_score_thresh=0.8)
-    ref = amg_from_saber_cfg(ImagePredictorRef(Wnp, cfg), amg).generate(np.repeat(img[..., None], 3, 2))
+    ref = amg_case("fp32_ragged")          # the fp32 oracle's AMG on this image (oracle/make_golden_amg_cases.py)
     bits, meta = engine.amg_generate(torch.from_numpy(img).cuda(), make_amg_params(amg), max_masks=512)
     got = unpack_bits(bits, W)
     print(f"non-square AMG: oracle {len(ref)} masks, engine {len(meta)} masks")
     assert len(ref) >= 5 and got.shape[1:] == (H, W)
     assert abs(len(ref) - len(meta)) <= max(2, int(0.05 * len(ref)))
-    ious = _match_masks(list(got), [r["segmentation"] for r in ref])
+    ious = _match_masks(list(got[:, 2::4, 2::4]), [r["segmentation"] for r in ref])      # quarter-resolution samples of both sides
     print("non-square matched IoU: median", float(np.median(ious)), "fraction>0.97", float(np.mean(np.array(ious) > 0.97)))
     assert np.mean(np.array(ious) > 0.97) >= 0.9
     for m, g in zip(meta, got):

@@ -179,18 +179,16 @@ def test_end_to_end_vs_bf16_emulating_oracle(engine, image, emul_feats, oracle_l
     assert float((1 - miou).median()) < 2.8e-3 and float((1 - miou).max()) < 1e-2   # measured 1.4e-3 / 4.9e-3
 
 
-def test_amg_masks_vs_bf16_emulating_oracle(engine, image, oracle_large):
+def test_amg_masks_vs_bf16_emulating_oracle(engine, image):
     """AMG mask sets: the emulating predictor under the oracle's AMG driver vs the engine's AMG.  Same count, and |IoU - 1| per
     matched mask within 2x of what was measured (the north star's |IoU - 1| < 1e-3 is met per decoder pass on identical inputs, not
     after encoder + two decoder passes of independent bf16 evaluations: see the module docstring, REALISATION SPREAD)."""
-    from oracle import sam2_bf16_emul as E
-    from oracle.amg_ref import amg_from_saber_cfg
+    from conftest import amg_case
     from saber_amd.engine import make_amg_params, unpack_bits
-    cfg, W = oracle_large
     # one crop layer (with more, the seeded model's image-sized masks fall to the cross-crop NMS and a single mask is left to compare);
     # box NMS off so that every mask that passes the score filters is compared
     amg = dict(npoints=6, crop_n_layers=0, box_nms_thresh=1.0, pred_iou_thresh=0.5, stability_score_thresh=0.8)
-    ref = amg_from_saber_cfg(E.ImagePredictorEmul(W, cfg), amg).generate(np.repeat(image[..., None], 3, 2))
+    ref = amg_case("emul_l0")          # the emulating predictor under the oracle's AMG driver: oracle/make_golden_amg_cases.py (60 s of host time)
     bits, meta = engine.amg_generate(torch.from_numpy(image).cuda(), make_amg_params(amg), max_masks=512)
     got = unpack_bits(bits, 1024)
     print(f"AMG vs emul: oracle {len(ref)} masks, engine {len(meta)} masks")
@@ -200,7 +198,7 @@ def test_amg_masks_vs_bf16_emulating_oracle(engine, image, oracle_large):
     for r in ref:
         mb = r["segmentation"]
         best = 0.0
-        for ma in got:
+        for ma in got[:, 2::4, 2::4]:                 # quarter-resolution samples of both sides
             uni = np.logical_or(ma, mb).sum()
             best = max(best, np.logical_and(ma, mb).sum() / uni if uni else 1.0)
         ious.append(best)
