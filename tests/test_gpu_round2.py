@@ -161,3 +161,25 @@ def test_remove_duplicate_masks_device_rows_equal_host(engine):
     mixed = dicts(True, range(n))
     mixed[3].pop(utils.DEVICE_ROW_KEY)                           # one dict without its row: the host form runs
     assert [m["tag"] for m in utils.remove_duplicate_masks(mixed)] == [m["tag"] for m in utils.remove_duplicate_masks(dicts(False, range(n)))]
+
+
+def test_flat_slices_through_prepare_and_the_slice_step(engine):
+    """Edge inputs of prep.prepare (saber/utils/preprocessing.py:4-37): a constant slice has zero local variance everywhere, and the
+    reference's epsilons turn it into an all-zero image ((x - mean) / (0 + 1e-8) = 0, then (0 - 0) / (0 + 1e-8) = 0); a slice with a flat
+    half keeps exact zeros there.  The engine's K0 must give the same images (no 1e8-amplified rounding residue), and the slice step must
+    come back with a label plane, not an error."""
+    from oracle import saber_ref
+    from saber_amd.engine import make_amg_params
+    from saber_amd.segmenters.slice_driver import segment_slice_to_plane
+    rng = np.random.default_rng(12)
+    const = np.full((1024, 1024), 32768, dtype=np.uint16)
+    half = const.copy()
+    half[:, 512:] = np.clip(rng.normal(32768, 3000, (1024, 512)), 0, 65535).astype(np.uint16)
+    for name, sl in (("constant", const), ("flat half", half)):
+        ref = saber_ref.prepare(sl.astype(np.float32))
+        got = engine.prepare(torch.from_numpy(sl).cuda()).cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(got - ref).max() < 2e-4, (name, float(np.abs(got - ref).max()))
+        if name == "constant":
+            assert not ref.any() and not got.any()
+        plane, n = segment_slice_to_plane(engine, torch.from_numpy(sl).cuda(), make_amg_params(dict(npoints=4, crop_n_layers=0)), min_mask_area=50)
+        assert plane.shape == (1024, 1024) and plane.dtype == torch.uint16 and int(plane.cpu().numpy().max()) <= n
