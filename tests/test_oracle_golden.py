@@ -260,3 +260,26 @@ def test_product_classifier_resolution_matches_reference():
     sem = fm.convert_predictions_to_masks(G["pred"], list(dicts), 0, 32)
     assert np.array_equal(np.stack([np.asarray(m["segmentation"]) for m in sem]).astype(np.uint8), G["sem_seg"])
     assert [m["area"] for m in sem] == G["sem_area"].tolist()
+
+
+def test_amg_case_fixture_is_what_the_oracle_produces():
+    """tests/golden/amg_cases_large_seed0.npz (the oracle side of the large-trunk AMG parity tests on the GPU) is regenerated for its
+    cheapest case - fp32 oracle, one crop layer, 36 grid prompts + 108 m2m refinements - and compared mask by mask, so a change of the
+    oracle cannot leave a stale fixture behind unnoticed."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import make_golden_amg_cases as M
+    from conftest import amg_case
+    from oracle.amg_ref import amg_from_saber_cfg
+    from oracle.sam2_ref import ImagePredictorRef
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    cfg = get_config("large")
+    amg = dict(npoints=6, box_nms_thresh=1.0, pred_iou_thresh=0.5, stability_score_thresh=0.8, crop_n_layers=0)
+    fresh = amg_from_saber_cfg(ImagePredictorRef(seeded_weights(cfg, 0), cfg), amg).generate(np.repeat(M.image_1024()[..., None], 3, 2))
+    stored = amg_case("fp32_l0")
+    assert len(fresh) == len(stored) > 50
+    for f, s in zip(fresh, stored):
+        a, b = f["segmentation"][2::4, 2::4], s["segmentation"]
+        assert (a & b).sum() / max(1, (a | b).sum()) > 0.999
