@@ -321,7 +321,10 @@ def main():
                            "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
                            "algorithmic_gflop_per_launch": g["flops"] / max(1, g["launches"]) / 1e9,
                            "kernel_ms_per_slice": g["ms"], "share_of_kernel_time": g["ms"] / total_ms if total_ms else None,
-                           "measured_on": "one single-handle step after the timed region (with two slices in flight the kernels of the two streams overlap and stretch each other)"}
+                           "measured_on": "one single-handle step after the timed region (with two slices in flight the kernels of the two streams overlap and stretch each other)",
+                           # round-to-round comparable form: since round 2 the class's time contains the LayerNorm work that round 1 ran as
+                           # separate layernorm-class launches (same FLOPs); FLOPs over (gemm + layernorm) class time: r01 0.204, see DESIGN.md 4
+                           "frac_with_layernorm_class": (g["flops"] / ((g["ms"] + prof["layernorm"]["ms"]) * 1e-3) / 1e12 / 2500.0) if g["ms"] > 0 else None}
         out["kernel_classes_ms_per_slice"] = {k: round(v["ms"], 3) for k, v in prof.items()}
         out["kernel_classes_launches"] = {k: v["launches"] for k, v in prof.items()}
         mp = prof["mask_post"]
