@@ -572,8 +572,8 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(o0), "=&v"(o1) : "v"(oscr_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4)) : "memory");
         bf16_t* orow = Xo + (int64_t)(tp * I2T_ROWS + 16 * rt + (lane >> 3)) * DC + 64 * qr + 8 * (lane & 7);
-        *reinterpret_cast<u32x4*>(orow) = o0;
-        *reinterpret_cast<u32x4*>(orow + 8 * DC) = o1;
+        __builtin_nontemporal_store(o0, reinterpret_cast<u32x4*>(orow));
+        __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(orow + 8 * DC));       // streamed: the 2 MB per prompt are read back by the next kernel long after they left the caches
     };
 
     issue(0); issue(1); issue(2);

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
             for (int j = 0; j < 8; ++j) {
                 const int row = 2 * j + (lane >> 5), chunk = lane & 31;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(my + row * 512 + ((chunk ^ (row & 15)) << 4));
-                *reinterpret_cast<u32x4*>(dst + row * DEC_C + chunk * 8) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + row * DEC_C + chunk * 8));       // streamed: the 2 MB per prompt are read back by the next kernel long after they left the caches
             }
             __builtin_amdgcn_wave_barrier();
         }
