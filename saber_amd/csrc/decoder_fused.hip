@@ -19,6 +19,12 @@
 #include "common.h"
 #include "kernels.h"
 
+// cache policy of dec_i2t's read of a prompt's image-token state, its LAST use (2 = nontemporal: same-box A/B 20.55 -> 19.86 ms per slice;
+// the same hint on dec_upscale's reads cost it 0.5 ms)
+#ifndef I2T_X_AUX
+#define I2T_X_AUX 2
+#endif
+
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 typedef unsigned int u32x2_d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x4 tr_read_d(const char* p) {
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t off = (int64_t)(t * I2T_ROWS + srow[i]) * DC + schunk[i] * 8;
-            __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 2 + i) * 1024), 16, 0, I2T_X_AUX);
         }
         __builtin_amdgcn_global_load_lds((gptr_d)(pep + (int64_t)(t * I2T_ROWS + prow) * 128 + pchunk * 8), (lptr_d)(sx + I2T_ROWS * ROW_B + wave * 1024), 16, 0, 0);
     };
