@@ -450,6 +450,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
     if (!tile_map(blockIdx.x, tiles_m, tiles_n, &tm, &tn)) return;
+    if (p.rev) tm = tiles_m - 1 - tm;
     const int m0 = tm * 256, n0 = tn * BN;
     const int64_t z = blockIdx.z;
     const bf16_t* __restrict__ A = p.A + z * p.strideA;
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     }
     auto next_tile = [&](int L, int* tm, int* tn) {
         while (L < padded && !tile_map(L, tiles_m, tiles_n, tm, tn)) L += gridDim.x;
+        if (p.rev && L < padded) *tm = tiles_m - 1 - *tm;
         return L;
     };
     int Li, tmi = 0, tni = 0, kti = 0, si = 0;

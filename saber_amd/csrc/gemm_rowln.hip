@@ -104,11 +104,13 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
     };
     static_assert(NQ == 6 || NQ == 5, "piece counts handled: 5 or 6 per wave");
 
-    int t = blockIdx.x;
-    if (t >= tiles) return;
-    issue(wrsrc, t, 0);
-    if (nk > 1) issue(wrsrc, t, 1);
-    for (; t < tiles; t += gridDim.x) {
+    int tl = blockIdx.x;                                   // position in this workgroup's walk; t = the tile (reversed walk: p.rev)
+    if (tl >= tiles) return;
+    auto tile_of = [&](int l) { return p.rev ? tiles - 1 - l : l; };
+    issue(wrsrc, tile_of(tl), 0);
+    if (nk > 1) issue(wrsrc, tile_of(tl), 1);
+    for (; tl < tiles; tl += gridDim.x) {
+        const int t = tile_of(tl);
         const int m0 = t * R;
         f32x4 acc[4][9];
 #pragma unroll
@@ -231,9 +233,9 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         }
         // every wave is past its last fragment read (the K loop's final barrier): the ring is free.  The next tile's first K-steps go in
         // flight now, under the LayerNorm statistics, the bf16 stores and the drain of this tile's stores.
-        if (t + (int)gridDim.x < tiles) {
-            issue(wrsrc, t + gridDim.x, 0);
-            if (nk > 1) issue(wrsrc, t + gridDim.x, 1);
+        if (tl + (int)gridDim.x < tiles) {
+            issue(wrsrc, tile_of(tl + gridDim.x), 0);
+            if (nk > 1) issue(wrsrc, tile_of(tl + gridDim.x), 1);
         }
         // mean / variance over the N columns of each row: the partial sums of the WN waves of a row meet in LDS.  LDS traffic and the
         // barrier are inline asm / raw: a visible ds access or __syncthreads() would drain the direct-to-LDS loads and all stores (vmcnt(0)).

@@ -26,6 +26,7 @@ struct GemmParams {
     int batch = 1;
     int dbg = 0;         // development flags (saber_k_set_debug), 0 in production
     unsigned long long* stamps = nullptr;   // development: in-kernel cycle stamps (tools/gemm_stamps.py)
+    int rev = 0;         // walk the M tiles from the last to the first (see Finalizer / eng_gemm: consecutive GEMMs of the encoder alternate)
     int w_kpad = 0;      // W rows are zero-padded to a multiple of 64 in K (ldw >= padded K): enables the direct-to-LDS kernel
     // row-owner GEMM + LayerNorm (gemm_rowln.hip): ln_out = bf16(LayerNorm(Cf row) * ln_gamma + ln_beta)
     const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-6f;
