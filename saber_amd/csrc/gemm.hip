@@ -816,7 +816,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
             for (int it = 0; it < 2; ++it) {
                 const int row = it * 8 + (lane >> 3), chunk = lane & 7;
                 const int m = m0 + wm * 128 + i * 16 + row, n = n0 + wn * 64 + chunk * 8;
-                if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n) = it ? val1 : val0;
+                if (m < p.M && n < p.N) {
+                    // nontemporal: the qkv / hidden tensors of a 21-crop pass (297 / 396 MB in stage 3) are larger than the Infinity Cache;
+                    // written normally they push the fp32 residual stream out of it before the row-owner GEMMs read it back
+                    // (same-box A/B: GEMM class 66.85 -> 63.87 ms, Hiera attention 11.04 -> 10.67 ms per slice; fc1 alone: no change)
+                    __builtin_nontemporal_store(it ? val1 : val0, reinterpret_cast<u32x4*>(Cb + (int64_t)m * p.ldcb + n));
+                }
             }
         }
         ktc = 0;
