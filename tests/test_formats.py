@@ -244,3 +244,37 @@ def test_read_micrograph_and_masks_to_array(tmp_path):
             overlay_root = "local://" + str(tmp_path / "ov")
     io.save_copick_metadata(Cfg, {"a": [1, 2, 3], "b": {"c": "x"}}, "run.yaml")
     assert open(tmp_path / "ov" / "logs" / "run.yaml").read() == "a: [1, 2, 3]\nb:\n  c: x\n"
+
+
+def test_io_glue_against_the_imported_reference():
+    """tests/golden/saber_io_glue.npz was written by the reference's own functions (oracle/make_golden_io.py): Fourier-crop rescaling
+    (2-D odd / even, by resolution, 3-D), the OME-NGFF attribute documents of add_attributes, _to_jsonable, masks_to_array."""
+    import torch
+    from saber_amd.filters.downsample import FourierRescale2D, FourierRescale3D
+    from saber_amd.filters.masks import masks_to_array
+    from saber_amd.utils import zarr_writer as zw
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "saber_io_glue.npz"))
+    cpu = torch.device("cpu")
+    for got, ref in ((FourierRescale2D.run(G["img_even"], 2.0, device=cpu), G["r2_even_2"]),
+                     (FourierRescale2D.run(G["img_odd"], 1.7, device=cpu), G["r2_odd_1p7"]),
+                     (FourierRescale2D.run_resolution(G["img_even"], 1.5, 4.0, device=cpu), G["r2_res_even"])):
+        assert got.shape == ref.shape and got.dtype == ref.dtype and np.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    f3 = FourierRescale3D(5.0, (10.0, 10.0, 7.5))
+    f3.device = cpu
+    r3 = f3.run(G["vol"])
+    assert r3.shape == G["r3"].shape and r3.dtype == G["r3"].dtype and np.allclose(r3, G["r3"], rtol=1e-5, atol=1e-6)
+    doc = json.loads(str(G["json"]))
+
+    class Grp:
+        def __init__(self):
+            self.attrs = {}
+    g2, g3 = Grp(), Grp()
+    zw.add_attributes(g2, 0.5)
+    zw.add_attributes(g3, 0.5, True, 1.25)
+    assert g2.attrs == doc["attrs2d"] and g3.attrs == doc["attrs3d"]
+    sample = {"a": np.int64(3), "b": np.float32(0.5), "c": np.arange(3), "d": (1, 2), "e": {"k": np.bool_(True)}, 7: None, "s": "x"}
+    assert json.loads(json.dumps(zw._to_jsonable(sample), sort_keys=True)) == doc["jsonable"]
+    segs = [{"segmentation": m} for m in G["m2a_in"]]
+    out = masks_to_array(segs)
+    assert out.dtype == G["m2a_out"].dtype and np.array_equal(out, G["m2a_out"])
+    assert str(masks_to_array(segs * 60).dtype) == str(G["m2a_out_300_dtype"])
