@@ -156,6 +156,18 @@ int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int 
 #define SABER_WEIGHTS_FP8_E4M3 1
 int saber_engine_set_weight_format(saber_engine* e, int format);
 
+/* Arithmetic precision of the model (encoder + prompt / mask decoder; everything around them is fp32 or integer in either mode).
+ * SABER_PRECISION_BF16 (default, the production path): bf16 MFMA operands, fp32 accumulation, fp32 residual stream and statistics -
+ *   3-8e-3 rel-RMS from the reference's fp32 arithmetic after 48 Hiera blocks.
+ * SABER_PRECISION_EXACT: every operand, stored activation and statistic in fp32 (GEMMs on the fp32-input MFMA, exact-erf GELU, the mask
+ *   decoder as the unfolded composition upstream executes): the reference's own precision (saber/utils/io.py:127-132 runs fp32, autocast
+ *   commented out), ~1e-5 from the fp32 CPU oracle; tens of times slower - a verification mode, never the default.
+ * Call it with EXACT once BEFORE saber_engine_finalize (the fp32 weight copies are kept only then: +0.9 GB for Hiera-L); afterwards the
+ * mode can be switched back and forth between calls on the same handle.  hipGraph replay is bypassed in exact mode. */
+#define SABER_PRECISION_BF16 0
+#define SABER_PRECISION_EXACT 1
+int saber_engine_set_precision(saber_engine* e, int precision);
+
 /* hipGraph replay of saber_amg_generate's launch sequences (BASELINE configs[4]: "hipGraph-captured per-slice encode+decode"): the batched
  * encoder pass and each decoder batch are run eagerly the first time their shapes are seen on a handle, captured the second time and
  * replayed from then on (needs a non-default stream; on by default, SABER_AMD_GRAPHS=0 or saber_engine_set_graphs(e, 0) turns it off).

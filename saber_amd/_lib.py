@@ -69,6 +69,7 @@ SIGNATURES = {
     "saber_amg_last_syncs": (_i, [_vp]),
     "saber_engine_set_graphs": (_i, [_vp, _i]),
     "saber_engine_set_weight_format": (_i, [_vp, _i]),
+    "saber_engine_set_precision": (_i, [_vp, _i]),
     "saber_engine_graph_stats": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "saber_label_plane": (_i, [_vp, _vp, C.POINTER(_i), _i, _i, _i, _vp, _vp]),
     "saber_mask_pair_intersections": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

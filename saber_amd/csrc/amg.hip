@@ -115,8 +115,13 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         for (int i = c0; i < std::min((int)crops.size(), c0 + e->max_images); ++i) n += (size_t)grid_n[layers[i]] * grid_n[layers[i]];
         max_pts = std::max(max_pts, n);
     }
-    const size_t max_prompts = max_pts * M;
-    if (e->amg_prompts_cap < max_prompts) {
+    size_t max_prompts = max_pts * M;
+    // two capacities: the point-indexed buffers (amg_pts, amg_low1) follow the number of grid points, the candidate-indexed ones the number
+    // of prompts (points x masks per point); a later call with fewer masks per point but a denser grid must regrow the former
+    if (e->amg_prompts_cap < max_prompts || e->amg_pts_cap < max_pts) {
+        max_pts = std::max(max_pts, e->amg_pts_cap);
+        max_prompts = std::max(max_prompts, e->amg_prompts_cap);
+        eng_graphs_flush(e);                   // captured launches hold the addresses of the buffers released below
         TRY(eng_regrow(e, &e->amg_pts, max_pts * 2, s));
         TRY(eng_regrow(e, &e->amg_pts2, max_prompts * 2, s));
         // the decoder leaves all 4 low-res planes of a prompt in place (no selection copies): first pass max_pts x 4, m2m pass max_prompts x 4
@@ -126,8 +131,10 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         TRY(eng_regrow(e, &e->amg_iou2, max_prompts, s));
         TRY(eng_regrow(e, &e->amg_sel, max_prompts, s));
         e->amg_prompts_cap = max_prompts;
+        e->amg_pts_cap = max_pts;
         e->amg_m2m_sized = prm->use_m2m != 0;
     } else if (prm->use_m2m && !e->amg_m2m_sized) {
+        eng_graphs_flush(e);
         TRY(eng_regrow(e, &e->amg_low2, e->amg_prompts_cap * 4 * 65536, s));
         e->amg_m2m_sized = true;
     }
@@ -167,7 +174,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     // engine-owned copy of the image: the encoder pass below is replayed from a hipGraph whose launches hold its address
     {
         const size_t need = (size_t)H * W * channels;
-        if (e->amg_img_elems < need) { TRY(eng_regrow(e, &e->amg_img, need, s)); e->amg_img_elems = need; }
+        if (e->amg_img_elems < need) { eng_graphs_flush(e); TRY(eng_regrow(e, &e->amg_img, need, s)); e->amg_img_elems = need; }
         ENG_HIP(e, hipMemcpyAsync(e->amg_img, img_dev, need * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     auto key_of = [](std::initializer_list<long long> v) { std::string k; for (long long x : v) { k += std::to_string(x); k += ','; } return k; };

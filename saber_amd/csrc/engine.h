@@ -14,7 +14,7 @@ struct BlockSpec { int din, dout, heads, window, q_stride; };
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
-struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; };   // wpk: K-step-packed copy (gemm_rowln.hip)  // rows zero-padded to ldw = ceil(in/64)*64
+struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; const float* wf = nullptr; };   // wf: dense fp32 [out][in] copy, kept only when the exact-precision mode was requested before finalize (exact.hip)   // wpk: K-step-packed copy (gemm_rowln.hip)  // rows zero-padded to ldw = ceil(in/64)*64
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
 
 struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
@@ -32,6 +32,9 @@ struct saber_engine {
     std::string err;
     bool finalized = false;
     int weight_format = 0;          // SABER_WEIGHTS_*
+    int precision = 0;              // SABER_PRECISION_*: the mode compute calls run in
+    bool keep_f32 = false;          // fp32 weight copies were requested before finalize (exact mode available)
+    void* exact_ws = nullptr;       // exact.hip's workspaces (allocated on first use)
 
     // model description (tiny / small / base+ / large)
     int embed_dim = 0;
@@ -101,7 +104,7 @@ struct saber_engine {
     float *amg_prep = nullptr; size_t amg_prep_elems = 0;
     int* amg_sel = nullptr; bool amg_m2m_sized = false;
     float *amg_pts = nullptr, *amg_low1 = nullptr, *amg_low2 = nullptr, *amg_iou1 = nullptr, *amg_iou2 = nullptr, *amg_pts2 = nullptr;
-    size_t amg_prompts_cap = 0;
+    size_t amg_prompts_cap = 0, amg_pts_cap = 0;
     uint32_t* amg_bits = nullptr; size_t amg_bits_words = 0;        // masks kept across crops (persistent, grown on demand)
     uint32_t* amg_crop_bits = nullptr; size_t amg_crop_words = 0;   // one crop's pred_iou survivors
     MaskStats* amg_stats = nullptr; int* amg_idx = nullptr; size_t amg_stats_cap = 0;
@@ -163,6 +166,8 @@ struct DeviceGuard {
 
 // hipGraph replay of a fixed launch sequence (engine.hip)
 int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const std::function<int()>& body);
+// drops every captured sequence (their launches hold addresses of workspaces that are about to be released)
+void eng_graphs_flush(saber_engine* e);
 // internal entry points used by amg.hip
 int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crops_host, int n, int slot0, hipStream_t s);
 // per_slot > 0: the prompts span consecutive slots, per_slot prompts each (crops of one AMG layer decoded in one batch);
@@ -176,6 +181,12 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
 int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                   const float* mask_in_dev, int mask_in_raw4, float mask_clamp, float* out_lowres, int out_raw4, float* out_iou, float* out_obj,
                   int* out_sel, hipStream_t s);
+// exact-precision mode (exact.hip): the Hiera blocks + neck of n images already patch-embedded in e->xa; one chunk of the decoder
+int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s);
+int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, const float* mask_in,
+                      float mask_clamp, int mask_in_q0, float* out_obj, float* masks4, hipStream_t s);
+int exact_chunk_prompts(const saber_engine* e);
+void exact_release(saber_engine* e);
 template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count);
 int eng_alloc_bytes(saber_engine* e, void** p, size_t bytes);
 void eng_free(saber_engine* e, void* p);

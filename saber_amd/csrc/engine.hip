@@ -94,7 +94,7 @@ static const char* hiera_spec(saber_engine* e, const TrunkSpec& t) {
 // size baked into its launches.  First sight: eager (lazy one-time setup inside launchers happens here); second: captured + launched;
 // afterwards: one hipGraphLaunch.  Anything that goes wrong while capturing marks the key bad and the sequence stays eager.
 int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const std::function<int()>& body) {
-    if (!e->graphs_on || e->prof_on || s == nullptr || e->graph_bad.count(key)) return body();
+    if (!e->graphs_on || e->prof_on || s == nullptr || e->precision != SABER_PRECISION_BF16 || e->graph_bad.count(key)) return body();
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) {
         ENG_HIP(e, hipGraphLaunch(it->second, s));
@@ -122,11 +122,26 @@ int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const st
     ENG_HIP(e, hipGraphLaunch(exec, s));
     return SABER_OK;
 }
+void eng_graphs_flush(saber_engine* e) {
+    if (e->graphs.empty() && e->graph_seen.empty()) return;
+    (void)hipDeviceSynchronize();                 // a replay may still be running
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    e->graphs.clear(); e->graph_seen.clear(); e->graph_bad.clear();
+}
 extern "C" int saber_engine_set_weight_format(saber_engine* e, int format) {
     if (!e) return SABER_ERR_INVALID;
     if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "set_weight_format after finalize");
     if (format != SABER_WEIGHTS_BF16 && format != SABER_WEIGHTS_FP8_E4M3) return eng_fail(e, SABER_ERR_INVALID, "set_weight_format: unknown format");
     e->weight_format = format;
+    return SABER_OK;
+}
+extern "C" int saber_engine_set_precision(saber_engine* e, int precision) {
+    if (!e) return SABER_ERR_INVALID;
+    if (precision != SABER_PRECISION_BF16 && precision != SABER_PRECISION_EXACT) return eng_fail(e, SABER_ERR_INVALID, "set_precision: unknown precision");
+    if (!e->finalized) { if (precision == SABER_PRECISION_EXACT) e->keep_f32 = true; }
+    else if (precision == SABER_PRECISION_EXACT && !e->keep_f32)
+        return eng_fail(e, SABER_ERR_STATE, "set_precision: the exact mode needs the fp32 weight copies; request it once before saber_engine_finalize");
+    e->precision = precision;
     return SABER_OK;
 }
 extern "C" int saber_engine_set_graphs(saber_engine* e, int enable) {
@@ -182,6 +197,7 @@ extern "C" void saber_engine_destroy(saber_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    exact_release(e);
     if (e->crops_pin) (void)hipHostFree(e->crops_pin);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
@@ -273,6 +289,7 @@ struct Finalizer {
         std::vector<float> padded((size_t)rows * ld, 0.0f);
         for (int r = 0; r < rows; ++r) std::copy(w.begin() + (size_t)r * cols, w.begin() + (size_t)(r + 1) * cols, padded.begin() + (size_t)r * ld);
         l->w = up_bf16(padded);
+        if (e->keep_f32) l->wf = up_f32(w);       // (of the quantised values when the e4m3 weight format is on)
         l->out = rows; l->in = cols; l->ldw = ld;
     }
     LinW lin(const std::string& prefix, int out, int in) {
@@ -761,6 +778,11 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
     ENG_HIP(e, hipMemcpyAsync(e->crops_dev, e->crops_pin, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_resize_normalize(img_dev, H, W, channels, e->crops_dev, n, e->pix, 1024, s));
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
+    if (e->precision == SABER_PRECISION_EXACT) {
+        TRY(exact_encode_blocks(e, n, slot0, s));
+        for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
+        return SABER_OK;
+    }
     float* x = e->xa;
     float* xalt = e->xb;
     int tokens = 65536;  // per image, current stage
@@ -991,6 +1013,15 @@ static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
 static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, int multimask,
                         const float* mask_in, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s,
                         float* raw4_out = nullptr, int* out_sel = nullptr, int mask_in_q0 = -1) {
+    if (e->precision == SABER_PRECISION_EXACT) {
+        float* m4 = raw4_out ? raw4_out : e->masks4;
+        TRY(exact_decode_core(e, slot0, per_slot, p_base, pts, labels, P, mask_in, mask_clamp, mask_in_q0, out_obj, m4, s));
+        float* oi = out_iou ? out_iou : e->dec_out_iou;
+        if (raw4_out) { ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s)); return SABER_OK; }
+        float* om = out_lowres ? out_lowres : e->dec_out_masks;
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
+        return SABER_OK;
+    }
     const int T = 8;
     const int PT = P * T;
     const size_t o256 = (size_t)slot0 * 4096 * 256;
@@ -1114,8 +1145,9 @@ int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev,
     for (int sl = slot; sl < slot + nslots; ++sl)
         if (sl < 0 || sl >= e->max_images || !e->slot_valid[sl]) return eng_fail(e, SABER_ERR_STATE, "decode: slot holds no encoded image; call saber_encode first");
     const int M = multimask ? 3 : 1;
-    for (int p0 = 0; p0 < n; p0 += e->max_prompts) {
-        const int P = std::min(e->max_prompts, n - p0);
+    const int chunk = e->precision == SABER_PRECISION_EXACT ? exact_chunk_prompts(e) : e->max_prompts;
+    for (int p0 = 0; p0 < n; p0 += chunk) {
+        const int P = std::min(chunk, n - p0);
         const float* min_ = !mask_in_dev ? nullptr : mask_in_raw4 ? mask_in_dev : mask_in_dev + (size_t)p0 * 65536;
         TRY(decode_chunk(e, slot, per_slot, p0, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
                          min_, mask_clamp,

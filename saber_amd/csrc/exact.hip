@@ -1,0 +1,649 @@
+// Exact-precision mode of the engine (saber_engine_set_precision(e, SABER_PRECISION_EXACT)).
+//
+// The reference runs the SAM2 image model in fp32 (saber/utils/io.py:127-132: TF32 allowed, autocast commented out) and the north star
+// asks for logits within 1e-3 rel of it.  The production path rounds every GEMM / attention operand to bf16, which costs 3-8e-3 end to
+// end.  This file is the mode that meets the tolerance: the same engine, the same token order, slots, weights and
+// C-ABI, but every operand, every stored activation and every statistic in fp32:
+//   * GEMMs on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bit for bit an fmaf chain, MI355X_MICROARCH.md "Matrix cores"),
+//   * attention, LayerNorm, GELU (libm erff, not the fitted form), softmax (expf) on the vector ALU,
+//   * the mask decoder as the UNFOLDED composition upstream executes (k/v/q projections of the image tokens per prompt, 8-head
+//     attention, out projection, residual, LayerNorm; two ConvTranspose2d as GEMMs, LayerNorm2d, GELU, hypernetwork product), so it
+//     also checks the production kernels' folded t2i / i2t algebra and their fused upscaling against an independent formulation.
+// Speed is not a goal (a default-grid AMG slice takes seconds); simple tiles, no pipelining.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+#define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
+
+// ------------------------------------------------------------------------------------------------ fp32 GEMM
+// C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+ res) ; 128 x 64 tile per 256-thread workgroup, 16-deep K steps through LDS,
+// wave w owns rows 32w..32w+31 of the tile as 2 x 4 MFMA tiles of 16 x 16.
+struct XGemm {
+    const float* A = nullptr; int64_t lda = 0; int64_t sA = 0;
+    const float* W = nullptr; int64_t ldw = 0; int64_t sW = 0;
+    const float* bias = nullptr; int64_t sBias = 0;
+    const float* res = nullptr; int64_t ldres = 0; int res_shift = 0; int64_t res_mod = 0;
+    float* C = nullptr; int64_t ldc = 0; int64_t sC = 0;
+    int M = 0, N = 0, K = 0, act = ACT_NONE, act_last = 0, pool4 = 0, batch = 1;
+};
+
+__device__ __forceinline__ float x_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float x_act(float v, int act) {
+    if (act == ACT_GELU) return x_gelu(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+#define XG_BM 128
+#define XG_BN 64
+#define XG_BK 16
+__global__ __launch_bounds__(256) void xg_gemm_kernel(XGemm p) {
+    __shared__ float As[XG_BK][XG_BM + 16];
+    __shared__ float Bs[XG_BK][XG_BN + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.y * XG_BM;
+    const int n0 = blockIdx.x * XG_BN;
+    const int b = blockIdx.z;
+    const float* A = p.A + b * p.sA;
+    const float* W = p.W + b * p.sW;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int arow = tid & 127, akh = tid >> 7;        // A: row of the tile, 8-float half of the K step
+    const int wrow = tid & 63, wkq = tid >> 6;         // W: row (n) of the tile, 4-float quarter of the K step
+    const bool a_ok = m0 + arow < p.M, w_ok = n0 + wrow < p.N;
+    const float* ap = A + (m0 + arow) * p.lda + akh * 8;
+    const float* wp = W + (int64_t)(n0 + wrow) * p.ldw + wkq * 4;
+    for (int k0 = 0; k0 < p.K; k0 += XG_BK) {
+        float av[8], wv[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = (a_ok && k0 + akh * 8 + j < p.K) ? ap[k0 + j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = (w_ok && k0 + wkq * 4 + j < p.K) ? wp[k0 + j] : 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) As[akh * 8 + j][arow] = av[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[wkq * 4 + j][wrow] = wv[j];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < XG_BK; kk += 4) {
+            float a[2], bb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[kk + (lane >> 4)][wave * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = Bs[kk + (lane >> 4)][j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* C = p.C + b * p.sC;
+    const float* bias = p.bias ? p.bias + b * p.sBias : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + j * 16 + (lane & 15);
+            if (n >= p.N) continue;
+            const float bv = bias ? bias[n] : 0.0f;
+            const int64_t r0 = m0 + wave * 32 + i * 16 + (lane >> 4) * 4;
+            if (p.pool4) {   // rows 4q..4q+3 (the lane's four registers) -> output row q
+                if (r0 < p.M) {
+                    float v = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])) + bv;
+                    C[(r0 >> 2) * p.ldc + n] = x_act(v, p.act);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r0 + r;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (!p.act_last) v = x_act(v, p.act);
+                if (p.res) {
+                    int64_t rr = row >> p.res_shift;
+                    if (p.res_mod > 0) rr %= p.res_mod;
+                    v += p.res[rr * p.ldres + n];
+                }
+                if (p.act_last) v = x_act(v, p.act);
+                C[row * p.ldc + n] = v;
+            }
+        }
+}
+static const char* xg_gemm(const XGemm& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return nullptr;
+    if (!p.A || !p.W || !p.C || p.K <= 0) return "exact gemm: bad argument";
+    if (p.pool4 && (p.M % 4)) return "exact gemm: pool4 needs M % 4 == 0";
+    const int64_t gy = ((int64_t)p.M + XG_BM - 1) / XG_BM;
+    if (gy > 65535 * 32) return "exact gemm: M too large";
+    // gridDim.y is limited to 65535: large M is split into row slabs
+    const int64_t slab = 65535;
+    for (int64_t y0 = 0; y0 < gy; y0 += slab) {
+        XGemm q = p;
+        const int64_t rows0 = y0 * XG_BM;
+        const int64_t ny = std::min(slab, gy - y0);
+        q.A = p.A + rows0 * p.lda;
+        q.C = p.C + (p.pool4 ? rows0 / 4 : rows0) * p.ldc;
+        q.M = (int)std::min<int64_t>((int64_t)p.M - rows0, ny * XG_BM);
+        if (p.res) {
+            if (p.res_mod > 0 || p.res_shift) { if (y0 > 0) return "exact gemm: residual mapping with M beyond one slab"; }
+            else q.res = p.res + rows0 * p.ldres;
+        }
+        hipLaunchKernelGGL(xg_gemm_kernel, dim3((p.N + XG_BN - 1) / XG_BN, (unsigned)ny, p.batch), dim3(256), 0, s, q);
+    }
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (fp32 in / out)
+// one wave per row; two-pass statistics; rows flagged invalid (window padding of the 14 x 14 trunks) are written as zeros
+__global__ __launch_bounds__(256) void xg_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
+                                                          float eps, float* __restrict__ out, int64_t rows, int C, int act,
+                                                          const uint8_t* __restrict__ row_valid, int valid_mod) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float* o = out + row * C;
+    if (row_valid && !row_valid[row % valid_mod]) {
+        for (int c = lane; c < C; c += 64) o[c] = 0.0f;
+        return;
+    }
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += xr[c];
+    const float mu = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; sq += d * d; }
+    const float var = wave_sum(sq) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int c = lane; c < C; c += 64) o[c] = x_act((xr[c] - mu) * rstd * g[c] + be[c], act);
+}
+static const char* xg_layernorm(const float* x, const LnW& w, float eps, float* out, int64_t rows, int C, int act, hipStream_t s,
+                                const uint8_t* row_valid = nullptr, int valid_mod = 0) {
+    if (rows <= 0) return nullptr;
+    hipLaunchKernelGGL(xg_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+// out[r][c] = x[r][c] + y[(ymod ? r % ymod : r)][c]
+__global__ __launch_bounds__(256) void xg_add_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t ymod, float* __restrict__ out,
+                                                    int64_t rows, int C) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        out[i] = x[i] + y[(ymod ? r % ymod : r) * C + c];
+    }
+}
+static void xg_add(const float* x, const float* y, int64_t ymod, float* out, int64_t rows, int C, hipStream_t s) {
+    if (rows <= 0) return;
+    const int64_t total = rows * C;
+    hipLaunchKernelGGL(xg_add_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536 * 8)), dim3(256), 0, s, x, y, ymod, out, rows, C);
+}
+// per-prompt tensors against per-slot tables: out[p][r][c] = act((in ? in[p][r][c] : 0) + tab[((p + off) / div) * stride + r * C + c] + (vec ? vec[c] : 0))
+__global__ __launch_bounds__(256) void xg_add_slot_kernel(const float* __restrict__ in, const float* __restrict__ tab, XMap m, const float* __restrict__ vec,
+                                                         float* __restrict__ out, int64_t rows_per, int C, int P, int act) {
+    const int64_t per = rows_per * C, total = per * P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i / per);
+        const int64_t j = i - (int64_t)p * per;
+        float v = tab[(int64_t)((p + m.off) / m.div) * m.stride + j];
+        if (in) v += in[i];
+        if (vec) v += vec[j % C];
+        out[i] = x_act(v, act);
+    }
+}
+static void xg_add_slot(const float* in, const float* tab, XMap m, const float* vec, float* out, int64_t rows_per, int C, int P, int act, hipStream_t s) {
+    if (P <= 0) return;
+    const int64_t total = rows_per * C * P;
+    hipLaunchKernelGGL(xg_add_slot_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536 * 8)), dim3(256), 0, s, in, tab, m, vec, out, rows_per, C, P, act);
+}
+
+// ------------------------------------------------------------------------------------------------ attention (fp32)
+// out[b][i][h*HD + d] = softmax_j(scale q_i . k_j) v_j for one (batch, head); one thread per query, K / V tiles of 32 keys through LDS.
+// qpool: query i is the element-wise maximum of q rows 4i .. 4i+3 (Hiera's 2 x 2 max-pooled queries: a pooling group is 4 consecutive
+// rows in the engine's token order).  kmask: one byte per key (shared by every batch), 0 = the key takes no part.
+#define XA_TK 32
+template <int HD>
+__global__ __launch_bounds__(128) void xg_attn_kernel(const float* __restrict__ q, int64_t q_bs, int ldq, const float* __restrict__ k, int64_t k_bs, int ldk,
+                                                     const float* __restrict__ v, int64_t v_bs, int ldv, float* __restrict__ o, int64_t o_bs, int ldo,
+                                                     int nq, int nk, int qpool, const uint8_t* __restrict__ kmask, float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[XA_TK][HD];
+    __shared__ __attribute__((aligned(16))) float Vs[XA_TK][HD];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, h = blockIdx.z;
+    const int i = blockIdx.x * 128 + tid;
+    const bool live = i < nq;
+    float qv[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { qv[d] = 0.f; acc[d] = 0.f; }
+    if (live) {
+        const float* qp = q + b * q_bs + h * HD;
+        if (qpool) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                const float a0 = qp[(int64_t)(4 * i) * ldq + d], a1 = qp[(int64_t)(4 * i + 1) * ldq + d];
+                const float a2 = qp[(int64_t)(4 * i + 2) * ldq + d], a3 = qp[(int64_t)(4 * i + 3) * ldq + d];
+                qv[d] = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) qv[d] = qp[(int64_t)i * ldq + d];
+        }
+    }
+    float mrun = -INFINITY, lrun = 0.f;
+    const float* kb = k + b * k_bs + h * HD;
+    const float* vb = v + b * v_bs + h * HD;
+    for (int j0 = 0; j0 < nk; j0 += XA_TK) {
+        const int tk = min(XA_TK, nk - j0);
+        __syncthreads();
+        for (int idx = tid; idx < XA_TK * HD; idx += 128) {
+            const int j = idx / HD, d = idx - j * HD;
+            const bool in = j < tk;
+            Ks[j][d] = in ? kb[(int64_t)(j0 + j) * ldk + d] : 0.0f;
+            Vs[j][d] = in ? vb[(int64_t)(j0 + j) * ldv + d] : 0.0f;
+        }
+        __syncthreads();
+        float sc[XA_TK];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < XA_TK; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a = fmaf(qv[d], Ks[j][d], a);
+            a *= scale;
+            const bool ok = j < tk && (!kmask || kmask[j0 + j]);
+            sc[j] = ok ? a : -INFINITY;
+            mt = fmaxf(mt, sc[j]);
+        }
+        if (mt == -INFINITY) continue;              // every key of the tile is masked (uniform across the block's live threads or harmless)
+        const float mnew = fmaxf(mrun, mt);
+        const float corr = expf(mrun - mnew);       // exp(-inf) = 0 on the first tile
+        lrun *= corr;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] *= corr;
+#pragma unroll
+        for (int j = 0; j < XA_TK; ++j) {
+            const float pj = expf(sc[j] - mnew);    // masked: exp(-inf) = 0
+            lrun += pj;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(pj, Vs[j][d], acc[d]);
+        }
+        mrun = mnew;
+    }
+    if (live) {
+        const float inv = 1.0f / lrun;
+        float* op = o + b * o_bs + (int64_t)i * ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+    }
+}
+static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const float* k, int64_t k_bs, int ldk, const float* v, int64_t v_bs, int ldv,
+                           float* o, int64_t o_bs, int ldo, int nq, int nk, int batch, int heads, int qpool, const uint8_t* kmask, float scale, hipStream_t s) {
+    if (batch <= 0 || nq <= 0) return nullptr;
+    const dim3 grid((nq + 127) / 128, 1, heads), block(128);
+    // gridDim.y <= 65535
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = std::min(65535, batch - b0);
+        dim3 g2(grid.x, nb, heads);
+#define XA_LAUNCH(HDIM) hipLaunchKernelGGL(xg_attn_kernel<HDIM>, g2, block, 0, s, q + b0 * q_bs, q_bs, ldq, k + b0 * k_bs, k_bs, ldk, v + b0 * v_bs, v_bs, ldv, \
+                                          o + b0 * o_bs, o_bs, ldo, nq, nk, qpool, kmask, scale)
+        switch (hd) {
+            case 16: XA_LAUNCH(16); break;
+            case 32: XA_LAUNCH(32); break;
+            case 56: XA_LAUNCH(56); break;
+            case 72: XA_LAUNCH(72); break;
+            case 96: XA_LAUNCH(96); break;
+            default: return "exact attention: unsupported head dimension";
+        }
+#undef XA_LAUNCH
+    }
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ mask prompt embedding (first two stages)
+// h2[p][tok][16] = GELU(LN2d(conv k2s2 4->16 (GELU(LN2d(conv k2s2 1->4 (mask))))))  for the 4 x 4 logit patch of token tok; the 1 x 1 conv to
+// 256 channels that follows is a GEMM.  One thread per (prompt, token).
+__global__ __launch_bounds__(256) void xg_mask_hidden_kernel(const float* __restrict__ mask_in, int P, MaskEmbedWeights w, float clamp_abs, int raw4_q0,
+                                                            float* __restrict__ h2out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)P * 4096) return;
+    const int p = (int)(idx >> 12), tok = (int)(idx & 4095);
+    int ty, tx;
+    perm_coords(tok, 2, &ty, &tx);
+    const int64_t plane = raw4_q0 >= 0 ? (int64_t)(raw4_q0 + p) + (raw4_q0 + p) / 3 + 1 : (int64_t)p;
+    const float* mp = mask_in + plane * 65536 + (int64_t)(ty * 4) * 256 + tx * 4;
+    float h1[4][4];       // [position ky*2+kx of the second conv][channel]
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+        const int py = pos >> 1, px = pos & 1;
+        float in[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float t = mp[(py * 2 + (kk >> 1)) * 256 + px * 2 + (kk & 1)];
+            if (clamp_abs > 0.0f) t = fminf(fmaxf(t, -clamp_abs), clamp_abs);
+            in[kk] = t;
+        }
+        float vv[4], mu = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = w.b1[c];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a += w.w1[c * 4 + kk] * in[kk];
+            vv[c] = a; mu += a;
+        }
+        mu *= 0.25f;
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) var += (vv[c] - mu) * (vv[c] - mu);
+        const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h1[pos][c] = x_gelu((vv[c] - mu) * rstd * w.g1[c] + w.be1[c]);
+    }
+    float h2[16], mu = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float a = w.b2[c];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a += w.w2[(c * 4 + ci) * 4 + kk] * h1[kk][ci];
+        h2[c] = a; mu += a;
+    }
+    mu *= (1.0f / 16.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) var += (h2[c] - mu) * (h2[c] - mu);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
+    float* o = h2out + idx * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = x_gelu((h2[c] - mu) * rstd * w.g2[c] + w.be2[c]);
+}
+
+// masks[p][k][y][x] = sum_c hyper[p][k][c] * up[p][perm(y,x)][c]   (up: fp32 [P][65536][32], engine token order; hyper: [P][128])
+__global__ __launch_bounds__(256) void xg_mask_dot_kernel(const float* __restrict__ up, const float* __restrict__ hyper, int P, float* __restrict__ masks4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)P * 65536) return;
+    const int p = (int)(idx >> 16), pix = (int)(idx & 65535);
+    const int y = pix >> 8, x = pix & 255;
+    const float* u = up + ((int64_t)p * 65536 + perm_index256(y, x)) * 32;
+    const float* hp = hyper + (int64_t)p * 128;
+    float uv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) uv[c] = u[c];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) a = fmaf(hp[kq * 32 + c], uv[c], a);
+        masks4[((int64_t)p * 4 + kq) * 65536 + pix] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ workspaces
+struct ExactWs {
+    // encoder (one image at a time)
+    float *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *sb[4] = {nullptr, nullptr, nullptr, nullptr}, *lat3 = nullptr;
+    // decoder (chunks of pc prompts)
+    int pc = 0;
+    float *keys = nullptr, *kpe = nullptr, *p0 = nullptr, *p1 = nullptr, *patt = nullptr, *up1 = nullptr, *up2 = nullptr, *h2 = nullptr;
+    float *t0 = nullptr, *t1 = nullptr, *tq = nullptr, *tk = nullptr, *tv = nullptr, *ta = nullptr, *thid = nullptr, *hd0 = nullptr, *hd1 = nullptr;
+};
+static ExactWs* ws_of(saber_engine* e) { return reinterpret_cast<ExactWs*>(e->exact_ws); }
+
+int exact_chunk_prompts(const saber_engine* e) { return std::min(e->max_prompts, 128); }
+
+static int ensure_ws(saber_engine* e) {
+    if (e->exact_ws) return SABER_OK;
+    ExactWs* w = new ExactWs();
+    e->exact_ws = w;
+    const size_t C0 = (size_t)e->embed_dim;
+    TRY(eng_alloc(e, &w->xn, 65536 * C0));
+    TRY(eng_alloc(e, &w->qkv, 65536 * 6 * C0));
+    TRY(eng_alloc(e, &w->att, 65536 * C0));
+    TRY(eng_alloc(e, &w->hid, 65536 * 4 * C0));
+    for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &w->sb[s], (size_t)e->tok_rows[s] * (C0 << s)));
+    TRY(eng_alloc(e, &w->lat3, (size_t)e->tok_rows[3] * 256));
+    const size_t P = w->pc = exact_chunk_prompts(e);
+    TRY(eng_alloc(e, &w->keys, P * 4096 * 256));
+    TRY(eng_alloc(e, &w->kpe, P * 4096 * 256));
+    TRY(eng_alloc(e, &w->p0, P * 4096 * 128));
+    TRY(eng_alloc(e, &w->p1, P * 4096 * 128));
+    TRY(eng_alloc(e, &w->patt, P * 4096 * 128));
+    TRY(eng_alloc(e, &w->up1, P * 16384 * 64));
+    TRY(eng_alloc(e, &w->up2, P * 65536 * 32));
+    TRY(eng_alloc(e, &w->h2, P * 4096 * 16));
+    TRY(eng_alloc(e, &w->t0, P * 8 * 256));
+    TRY(eng_alloc(e, &w->t1, P * 8 * 256));
+    TRY(eng_alloc(e, &w->tq, P * 8 * 256));
+    TRY(eng_alloc(e, &w->tk, P * 8 * 256));
+    TRY(eng_alloc(e, &w->tv, P * 8 * 256));
+    TRY(eng_alloc(e, &w->ta, P * 8 * 256));
+    TRY(eng_alloc(e, &w->thid, P * 8 * 2048));
+    TRY(eng_alloc(e, &w->hd0, 4 * P * 256));
+    TRY(eng_alloc(e, &w->hd1, 4 * P * 256));
+    return SABER_OK;
+}
+void exact_release(saber_engine* e) {
+    delete ws_of(e);        // the device buffers are in e->allocs
+    e->exact_ws = nullptr;
+}
+
+static XGemm mkx(const float* A, int64_t lda, int M, const LinW& w) {
+    XGemm p;
+    p.A = A; p.lda = lda; p.W = w.wf; p.ldw = w.in; p.bias = w.b; p.M = M; p.N = w.out; p.K = w.in;
+    return p;
+}
+#define XK(call) do { const char* _m = (call); if (_m) return eng_fail(e, SABER_ERR_INVALID, _m); } while (0)
+
+// ------------------------------------------------------------------------------------------------ encoder
+// Continues eng_encode after the (fp32) resize + normalise and patch embedding: e->xa holds n images x 65536 tokens x C0.
+int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s) {
+    TRY(ensure_ws(e));
+    ExactWs* w = ws_of(e);
+    for (const BlockW& bw : e->bw) if (!bw.qkv.wf) return eng_fail(e, SABER_ERR_STATE, "exact mode: the engine was finalized without fp32 weights (set the precision before finalize)");
+    const int C0 = e->embed_dim;
+    const size_t nblocks = e->blocks.size();
+    const float hscale = 1.0f / sqrtf((float)e->head_dim);
+    for (int img = 0; img < n; ++img) {
+        float* x = e->xa + (size_t)img * 65536 * C0;
+        float* xalt = e->xb + (size_t)img * 65536 * C0;
+        int tokens = 65536, stage = 0;
+        XK(xg_layernorm(x, e->bw[0].n1, 1e-6f, w->xn, tokens, e->blocks[0].din, ACT_NONE, s, e->valid[0], tokens));
+        for (size_t i = 0; i < nblocks; ++i) {
+            const BlockSpec& bs = e->blocks[i];
+            const BlockW& b = e->bw[i];
+            const int N = tokens;
+            float* xres = x;
+            int Nq = N;
+            if (bs.din != bs.dout) {     // shortcut = 2 x 2 max-pool of proj(norm1(x))
+                XGemm g = mkx(w->xn, bs.din, N, b.sc);
+                g.C = xalt; g.ldc = bs.dout; g.pool4 = 1;
+                XK(xg_gemm(g, s));
+                xres = xalt; Nq = N / 4;
+            }
+            {
+                XGemm g = mkx(w->xn, bs.din, N, b.qkv);
+                g.C = w->qkv; g.ldc = 3 * bs.dout;
+                XK(xg_gemm(g, s));
+            }
+            const int nk = bs.window > 0 ? bs.window * bs.window : tokens;
+            const uint8_t* kmask = (bs.window == 0 && e->valid[stage]) ? e->kmask2 : nullptr;
+            const int C = bs.dout, qp = bs.q_stride > 1;
+            XK(xg_attn(e->head_dim, w->qkv, (int64_t)nk * 3 * C, 3 * C, w->qkv + C, (int64_t)nk * 3 * C, 3 * C, w->qkv + 2 * C, (int64_t)nk * 3 * C, 3 * C,
+                       w->att, (int64_t)(qp ? nk / 4 : nk) * C, C, qp ? nk / 4 : nk, nk, N / nk, bs.heads, qp, kmask, hscale, s));
+            {
+                XGemm g = mkx(w->att, bs.dout, Nq, b.proj);
+                g.C = xres; g.ldc = bs.dout; g.res = xres; g.ldres = bs.dout;
+                XK(xg_gemm(g, s));
+            }
+            if (bs.din != bs.dout) { std::swap(x, xalt); tokens /= 4; ++stage; }
+            XK(xg_layernorm(x, b.n2, 1e-6f, w->xn, Nq, bs.dout, ACT_NONE, s));
+            {
+                XGemm g = mkx(w->xn, bs.dout, Nq, b.fc1);
+                g.C = w->hid; g.ldc = 4 * bs.dout; g.act = ACT_GELU;
+                XK(xg_gemm(g, s));
+            }
+            {
+                XGemm g = mkx(w->hid, 4 * bs.dout, Nq, b.fc2);
+                g.C = x; g.ldc = bs.dout; g.res = x; g.ldres = bs.dout;
+                XK(xg_gemm(g, s));
+            }
+            if ((int)i == e->stage_ends[stage])
+                ENG_HIP(e, hipMemcpyAsync(w->sb[stage], x, sizeof(float) * (size_t)Nq * bs.dout, hipMemcpyDeviceToDevice, s));
+            if (e->padded && bs.din != bs.dout && stage == 2) {
+                XK(launch_gather_rows(x, 4096, xalt, e->tok_rows[2], e->pack_idx, bs.dout, 1, s));
+                std::swap(x, xalt);
+                tokens = e->tok_rows[2];
+            }
+            if (i + 1 < nblocks) XK(xg_layernorm(x, e->bw[i + 1].n1, 1e-6f, w->xn, tokens, bs.dout, ACT_NONE, s, e->valid[stage], tokens));
+        }
+        // neck + conv_s0 / conv_s1 (composed with their lateral convs at finalize, in double)
+        const int slot = slot0 + img;
+        {
+            XGemm g = mkx(w->sb[3], e->stage_dims[3], e->tok_rows[3], e->neck3);
+            g.C = w->lat3; g.ldc = 256;
+            XK(xg_gemm(g, s));
+        }
+        {
+            float* emb_slot = e->emb + (size_t)slot * 4096 * 256;
+            XGemm g = mkx(w->sb[2], e->stage_dims[2], e->tok_rows[2], e->neck2);
+            g.C = e->padded ? w->hid : emb_slot; g.ldc = 256; g.res = w->lat3; g.ldres = 256; g.res_shift = 2;
+            XK(xg_gemm(g, s));
+            if (e->padded) XK(launch_gather_rows(w->hid, e->tok_rows[2], emb_slot, 4096, e->unpack_idx, 256, 1, s));
+        }
+        {
+            XGemm g = mkx(w->sb[1], e->stage_dims[1], 16384, e->s1);
+            g.C = e->fs1 + (size_t)slot * 16384 * 64; g.ldc = 64;
+            XK(xg_gemm(g, s));
+        }
+        {
+            XGemm g = mkx(w->sb[0], e->stage_dims[0], 65536, e->s0);
+            g.C = e->fs0 + (size_t)slot * 65536 * 32; g.ldc = 32;
+            XK(xg_gemm(g, s));
+        }
+    }
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+// One chunk of P <= exact_chunk_prompts() prompts through the prompt encoder's dense branch, the two-way transformer, the heads and the
+// upscaling.  Leaves: e->queries (the 8 output tokens per prompt), e->iou4 [P][4], out_obj [P] (optional), masks4 [P][4][256 x 256]
+// (row-major pixels); the caller applies the same mask selection as the production path.
+int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, const float* mask_in,
+                      float mask_clamp, int mask_in_q0, float* out_obj, float* masks4, hipStream_t s) {
+    TRY(ensure_ws(e));
+    ExactWs* w = ws_of(e);
+    if (P > w->pc) return eng_fail(e, SABER_ERR_INVALID, "exact decode: chunk larger than the exact-mode workspace");
+    if (!e->dl[0].t2i.q.wf) return eng_fail(e, SABER_ERR_STATE, "exact mode: the engine was finalized without fp32 weights (set the precision before finalize)");
+    const int T = 8, PT = P * T;
+    const XMap slots{(int64_t)4096 * 256, per_slot, p_base};
+    const float* emb0 = e->emb + (size_t)slot0 * 4096 * 256;
+    XK(launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
+    ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
+    // src = image_embed + dense prompt embedding
+    if (!mask_in) {
+        xg_add_slot(nullptr, emb0, slots, e->no_mask_embed, w->keys, 4096, 256, P, ACT_NONE, s);
+    } else {
+        hipLaunchKernelGGL(xg_mask_hidden_kernel, dim3((unsigned)(((int64_t)P * 4096 + 255) / 256)), dim3(256), 0, s, mask_in, P, e->mw, mask_clamp, mask_in_q0, w->h2);
+        XGemm g;
+        g.A = w->h2; g.lda = 16; g.W = e->mw.w3; g.ldw = 16; g.bias = e->mw.b3; g.M = P * 4096; g.N = 256; g.K = 16; g.C = w->keys; g.ldc = 256;
+        XK(xg_gemm(g, s));
+        xg_add_slot(w->keys, emb0, slots, nullptr, w->keys, 4096, 256, P, ACT_NONE, s);
+    }
+    float* queries = e->queries;
+    const float* tokpe = e->tok_pe;
+    const int64_t NI = (int64_t)P * 4096;
+
+    auto lin = [&](const float* A, int64_t lda, int64_t M, const LinW& L, float* C, int64_t ldc, const float* res = nullptr, int act = ACT_NONE) -> const char* {
+        XGemm g = mkx(A, lda, (int)M, L);
+        g.C = C; g.ldc = ldc; g.act = act;
+        if (res) { g.res = res; g.ldres = ldc; }
+        return xg_gemm(g, s);
+    };
+    // tokens -> image cross attention: queries += out_proj(attn(q_proj(queries + pe), k_proj(keys + pos), v_proj(keys))), then LayerNorm
+    auto t2i = [&](const AttnW& a, const LnW& ln) -> int {
+        xg_add(queries, tokpe, 0, w->t0, PT, 256, s);
+        XK(lin(w->t0, 256, PT, a.q, w->tq, 128));
+        xg_add(w->keys, e->dense_pe, 4096, w->kpe, NI, 256, s);
+        XK(lin(w->kpe, 256, NI, a.k, w->p0, 128));
+        XK(lin(w->keys, 256, NI, a.v, w->p1, 128));
+        XK(xg_attn(16, w->tq, (int64_t)T * 128, 128, w->p0, (int64_t)4096 * 128, 128, w->p1, (int64_t)4096 * 128, 128, w->ta, (int64_t)T * 128, 128, T, 4096, P, 8, 0,
+                   nullptr, 0.25f, s));
+        XK(lin(w->ta, 128, PT, a.o, queries, 256, queries));
+        XK(xg_layernorm(queries, ln, 1e-5f, queries, PT, 256, ACT_NONE, s));
+        return SABER_OK;
+    };
+    for (int l = 0; l < 2; ++l) {
+        const DecLayerW& d = e->dl[l];
+        // (1) self attention of the tokens (layer 0: no positional term, no residual)
+        const float* qk_in = queries;
+        if (l > 0) { xg_add(queries, tokpe, 0, w->t0, PT, 256, s); qk_in = w->t0; }
+        XK(lin(qk_in, 256, PT, d.self_attn.q, w->tq, 256));
+        XK(lin(qk_in, 256, PT, d.self_attn.k, w->tk, 256));
+        XK(lin(queries, 256, PT, d.self_attn.v, w->tv, 256));
+        XK(xg_attn(32, w->tq, (int64_t)T * 256, 256, w->tk, (int64_t)T * 256, 256, w->tv, (int64_t)T * 256, 256, w->ta, (int64_t)T * 256, 256, T, T, P, 8, 0, nullptr,
+                   1.0f / sqrtf(32.0f), s));
+        XK(lin(w->ta, 256, PT, d.self_attn.o, queries, 256, l > 0 ? queries : nullptr));
+        XK(xg_layernorm(queries, d.n1, 1e-5f, queries, PT, 256, ACT_NONE, s));
+        // (2) tokens -> image
+        TRY(t2i(d.t2i, d.n2));
+        // (3) MLP
+        XK(lin(queries, 256, PT, d.mlp1, w->thid, 2048, nullptr, ACT_RELU));
+        XK(lin(w->thid, 2048, PT, d.mlp2, queries, 256, queries));
+        XK(xg_layernorm(queries, d.n3, 1e-5f, queries, PT, 256, ACT_NONE, s));
+        // (4) image -> tokens: keys = LN(keys + out_proj(attn(q_proj(keys + pos), k_proj(queries + pe), v_proj(queries))))
+        xg_add(queries, tokpe, 0, w->t0, PT, 256, s);
+        XK(lin(w->t0, 256, PT, d.i2t.k, w->tk, 128));
+        XK(lin(queries, 256, PT, d.i2t.v, w->tv, 128));
+        xg_add(w->keys, e->dense_pe, 4096, w->kpe, NI, 256, s);
+        XK(lin(w->kpe, 256, NI, d.i2t.q, w->p0, 128));
+        XK(xg_attn(16, w->p0, (int64_t)4096 * 128, 128, w->tk, (int64_t)T * 128, 128, w->tv, (int64_t)T * 128, 128, w->patt, (int64_t)4096 * 128, 128, 4096, T, P, 8, 0,
+                   nullptr, 0.25f, s));
+        XK(lin(w->patt, 128, NI, d.i2t.o, w->kpe, 256, w->keys));
+        XK(xg_layernorm(w->kpe, d.n4, 1e-5f, w->keys, NI, 256, ACT_NONE, s));
+    }
+    TRY(t2i(e->final_attn, e->final_ln));
+
+    // heads: token 0 = object score, 1 = IoU, 2..5 = mask tokens
+    auto mlp3 = [&](const LinW* L, const float* A, int last_act, float* outf, int ldo) -> int {
+        XK(lin(A, (int64_t)T * 256, P, L[0], w->hd0, 256, nullptr, ACT_RELU));
+        XK(lin(w->hd0, 256, P, L[1], w->hd1, 256, nullptr, ACT_RELU));
+        XK(lin(w->hd1, 256, P, L[2], outf, ldo, nullptr, last_act));
+        return SABER_OK;
+    };
+    TRY(mlp3(e->iou_head, queries + 256, ACT_SIGMOID, e->iou4, 4));
+    if (out_obj) TRY(mlp3(e->obj_head, queries, ACT_NONE, out_obj, 1));
+    {   // the 4 hypernetwork MLPs, batched over the mask token
+        XGemm g = mkx(queries + 2 * 256, (int64_t)T * 256, P, e->hyper[0]);
+        g.batch = 4; g.sA = 256; g.sW = 256 * 256; g.sBias = 256; g.C = w->hd0; g.ldc = 256; g.sC = (int64_t)P * 256; g.act = ACT_RELU;
+        XK(xg_gemm(g, s));
+        g = mkx(w->hd0, 256, P, e->hyper[1]);
+        g.batch = 4; g.sA = (int64_t)P * 256; g.sW = 256 * 256; g.sBias = 256; g.C = w->hd1; g.ldc = 256; g.sC = (int64_t)P * 256; g.act = ACT_RELU;
+        XK(xg_gemm(g, s));
+        g = mkx(w->hd1, 256, P, e->hyper[2]);
+        g.batch = 4; g.sA = (int64_t)P * 256; g.sW = 32 * 256; g.sBias = 32; g.C = e->hyper_out; g.ldc = 128; g.sC = 32;
+        XK(xg_gemm(g, s));
+    }
+    // upscaling: ConvTranspose2d(256 -> 64, k2 s2) as a GEMM whose N index is (ky*2+kx)*64 + co: row t of the 64^2 grid becomes rows
+    // 4t .. 4t+3 of the 128^2 grid in the engine's token order; + feat_s1; LayerNorm2d; GELU; the same for 64 -> 32 with feat_s0; GELU
+    XK(lin(w->keys, 256, NI, e->dc1, w->up1, 256));
+    xg_add_slot(w->up1, e->fs1 + (size_t)slot0 * 16384 * 64, XMap{(int64_t)16384 * 64, per_slot, p_base}, nullptr, w->up1, 16384, 64, P, ACT_NONE, s);
+    XK(xg_layernorm(w->up1, e->up_ln, 1e-6f, w->up1, (int64_t)P * 16384, 64, ACT_GELU, s));
+    XK(lin(w->up1, 64, (int64_t)P * 16384, e->dc2, w->up2, 128));
+    xg_add_slot(w->up2, e->fs0 + (size_t)slot0 * 65536 * 32, XMap{(int64_t)65536 * 32, per_slot, p_base}, nullptr, w->up2, 65536, 32, P, ACT_GELU, s);
+    hipLaunchKernelGGL(xg_mask_dot_kernel, dim3((unsigned)(((int64_t)P * 65536 + 255) / 256)), dim3(256), 0, s, w->up2, e->hyper_out, P, masks4);
+    ENG_HIP(e, hipGetLastError());
+    return SABER_OK;
+}

@@ -30,7 +30,7 @@ class Engine:
     """One engine handle bound to one device (reference threading contract: one caller per device)."""
 
     def __init__(self, trunk: str = "large", device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
-                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64, weight_format: str = "bf16"):
+                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64, weight_format: str = "bf16", precision: str = "bf16"):
         self.lib = _lib.load()
         self.cfg = get_config(trunk)  # ValueError for unknown names, like the reference
         if not torch.cuda.is_available():
@@ -49,6 +49,11 @@ class Engine:
         self.weight_format = weight_format
         if weight_format == "fp8":       # e4m3 stage-2/3 block weights (include/saber_amd.h: saber_engine_set_weight_format)
             self._check(self.lib.saber_engine_set_weight_format(self.h, 1))
+        if precision not in ("bf16", "exact"):
+            raise ValueError(f"precision must be 'bf16' or 'exact', got '{precision}'")
+        self.precision = precision
+        if precision == "exact":         # fp32 operands everywhere (include/saber_amd.h: saber_engine_set_precision); keeps fp32 weight copies
+            self._check(self.lib.saber_engine_set_precision(self.h, 1))
         if weights is None:
             weights = load_checkpoint(checkpoint, self.cfg) if checkpoint else seeded_weights(self.cfg, seed)
         for name, arr in weights.items():
@@ -224,6 +229,14 @@ class Engine:
         out = torch.empty((Z, H, W), dtype=torch.float32, device=mask.device)
         self._check(self.lib.saber_gaussian_smoothing_3d(self.h, _ptr(mask), Z, H, W, float(sigma), _ptr(out), _stream()))
         return out
+
+    def set_precision(self, precision: str):
+        """Switch between the bf16 production arithmetic and the fp32 exact mode (only on a handle created with precision="exact",
+        which keeps the fp32 weight copies)."""
+        if precision not in ("bf16", "exact"):
+            raise ValueError(f"precision must be 'bf16' or 'exact', got '{precision}'")
+        self._check(self.lib.saber_engine_set_precision(self.h, 1 if precision == "exact" else 0))
+        self.precision = precision
 
     def set_graphs(self, enable: bool):
         """hipGraph replay of the AMG launch sequences (include/saber_amd.h: saber_engine_set_graphs)."""
