@@ -18,7 +18,7 @@ from saber_amd.utils import preprocessing as prep
 class SAM2Adapter(BaseAdapter):
     def __init__(self, config: SAM2AdapterConfig, device="cuda"):
         if config.num_maskmem > 7:
-            raise ValueError("num_maskmem must be less than 7")
+            raise ValueError("num_maskmem must be at most 7")
         self._config = config
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         # the reference builds its video predictor from config.cfg here; that model belongs to the propagation path
@@ -193,6 +193,25 @@ class SAM2Adapter(BaseAdapter):
                     if ps < min_presence_score:
                         vol_masks[fidx][vol_masks[fidx] == obj_id] = 0
         return vol_masks.astype(np.uint16)
+
+    def clear_all_prompts_in_frame(self, *args, inference_state=None, **kwargs):
+        """predictor.py:360-362: delegates to the video predictor (frame_idx, obj_id, need_output=True).  The reference passes upstream's
+        inference_state as the first positional argument; here the state IS the predictor, so a leading state object is dropped."""
+        state = inference_state or self.inference_state
+        if args and hasattr(args[0], "clear_all_prompts_in_frame"):
+            state, args = args[0], args[1:]
+        if state is None:
+            raise RuntimeError("Call set_volume() before clear_all_prompts_in_frame().")
+        return state.clear_all_prompts_in_frame(*args, **kwargs)
+
+    def remove_object(self, *args, inference_state=None, **kwargs):
+        """predictor.py:364-366: delegates to the video predictor (obj_id, strict=False, need_output=True)."""
+        state = inference_state or self.inference_state
+        if args and hasattr(args[0], "remove_object"):
+            state, args = args[0], args[1:]
+        if state is None:
+            raise RuntimeError("Call set_volume() before remove_object().")
+        return state.remove_object(*args, **kwargs)
 
     def reset_state(self, inference_state=None) -> None:
         state = inference_state or self.inference_state

@@ -121,7 +121,7 @@ class VideoPredictor:
 
     def __init__(self, engine, weights: Dict[str, np.ndarray], num_maskmem: int = 2):
         if num_maskmem > 7:
-            raise ValueError("num_maskmem must be less than 7")
+            raise ValueError("num_maskmem must be at most 7")
         self.eng, self.lib, self.dev = engine, engine.lib, engine.device
         if self.lib.saber_k_init(engine.device_index) != 0:
             raise RuntimeError(self.lib.saber_k_last_error().decode())
@@ -416,6 +416,52 @@ class VideoPredictor:
         low, obj_v, ptr = self._sam_heads(emb, mask_in, multimask=True, slot=self._slot(frame_idx), point=(xy[0], xy[1]), label=int(lab[0]))
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": None, "raw": raw}
         return frame_idx, list(self.obj_ids), self._resize(low, 256, 256, Hv, Wv)[None, None]
+
+    NO_OBJ_SCORE = -1024.0
+
+    def _frame_output(self, frame_idx: int):
+        """(frame_idx, obj_ids, video-resolution mask logits (n_obj,1,Hv,Wv)) of the frame as the state holds it now: an object without an
+        output on the frame reads NO_OBJ_SCORE, like upstream's consolidated outputs."""
+        Hv, Wv = self.video_hw
+        outs = []
+        for oid in self.obj_ids:
+            o = self.temp[oid].get(frame_idx) or self.out[oid]["cond"].get(frame_idx) or self.out[oid]["non_cond"].get(frame_idx)
+            if o is None:
+                outs.append(torch.full((Hv, Wv), self.NO_OBJ_SCORE, dtype=torch.float32, device=self.dev))
+            else:
+                outs.append(self._resize(o["pred_masks"], 256, 256, Hv, Wv))
+        masks = torch.stack(outs, 0)[:, None] if outs else torch.empty((0, 1, Hv, Wv), dtype=torch.float32, device=self.dev)
+        return frame_idx, list(self.obj_ids), masks
+
+    @torch.inference_mode()
+    def clear_all_prompts_in_frame(self, frame_idx: int, obj_id: int, need_output: bool = True):
+        """upstream SAM2VideoPredictor.clear_all_prompts_in_frame: the object's inputs on the frame go; if the frame was a conditioning frame
+        its output is kept as a plain tracked (non-conditioning) output, since it no longer receives inputs."""
+        if obj_id not in self.obj_ids:
+            raise RuntimeError(f"Cannot clear prompts for object id {obj_id}: it does not exist. All existing object ids: {self.obj_ids}.")
+        self.temp[obj_id].pop(frame_idx, None)
+        out = self.out[obj_id]["cond"].pop(frame_idx, None)
+        if out is not None:
+            self.out[obj_id]["non_cond"][frame_idx] = out
+        if not need_output:
+            return None
+        return self._frame_output(frame_idx)
+
+    @torch.inference_mode()
+    def remove_object(self, obj_id: int, strict: bool = False, need_output: bool = True):
+        """upstream SAM2VideoPredictor.remove_object: the object leaves the tracking state at any time.  Returns (remaining object ids,
+        [(frame_idx, video-resolution masks of the remaining objects) for every frame the removed object had received inputs on])."""
+        if obj_id not in self.obj_ids:
+            if not strict:
+                return list(self.obj_ids), []
+            raise RuntimeError(f"Cannot remove object id {obj_id}: it does not exist. All existing object ids: {self.obj_ids}.")
+        input_frames = sorted(set(self.temp[obj_id]) | set(self.out[obj_id]["cond"]))
+        self.obj_ids.remove(obj_id)
+        self.out.pop(obj_id, None)
+        self.temp.pop(obj_id, None)
+        if not need_output or not self.obj_ids:
+            return list(self.obj_ids), []
+        return list(self.obj_ids), [(t, self._frame_output(t)[2]) for t in input_frames]
 
     def _preflight(self):
         for oid in self.obj_ids:

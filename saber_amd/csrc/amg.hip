@@ -191,7 +191,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             TRY(eng_graphed(e, "enc," + key_of({(long long)(uintptr_t)img, H, W, channels, ncb, c0, prm->crop_n_layers, (long long)(prm->crop_overlap_ratio * 1e6)}), s,
                             [&]() { return eng_encode(e, img, H, W, channels, e->crops_pin, ncb, 0, s); }));
             // host-side bookkeeping of eng_encode, which a replay does not execute
-            for (int i = 0; i < ncb; ++i) { e->slot_valid[i] = 1; e->slot_shared_valid[i] = 0; }
+            for (int i = 0; i < ncb; ++i) { e->slot_valid[i] = 1; e->slot_shared_valid[i] = 0; e->slot_embb_valid[i] = 0; }
         }
         // ---- the crops of one layer that were encoded together are decoded as ONE batch of prompts; all groups of the encoder batch
         // are decoded back to back WITHOUT a host round trip, then the per-candidate scalars come back once (sync 1), K8 runs for every
@@ -249,6 +249,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                 int* sel2 = e->amg_sel + gr.k0;
                 TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)pts2, G * nm, first_raw, (long long)(uintptr_t)low1, (long long)(uintptr_t)low2, (long long)(uintptr_t)iou2, (long long)(uintptr_t)sel2}), s,
                                 [&]() { return eng_decode_ex(e, ci, nm, pts2, nullptr, G * nm, 0, low1, first_raw, 32.0f, low2, 1, iou2, nullptr, sel2, s); }));
+                for (int g = 0; g < G; ++g) e->slot_embb_valid[ci + g] = 1;       // (bookkeeping of the m2m decode, for replays)
                 gr.masks = low2; gr.ious = iou2; gr.plane_mode = 2;
             }
         }

@@ -168,13 +168,19 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t lo, uint32
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <int NW, bool STAMPS>
+// BUILD: the X tile of a key block is not copied from HBM but assembled by the waves themselves as bf16(embb + h2 . W3^T) (XBuild in
+// kernels.h: the m2m prompts' src = image_embed + mask-prompt embedding, which then never exists in memory).  Wave w owns channels
+// 32 w .. 32 w + 31 of all 64 keys: 2 x 4 MFMAs (k = 16 zero-padded to 32) whose C operand is the fp32 embb tile, loaded into registers at
+// the top of the iteration for the NEXT block and written (bf16, the tile's swizzle) after this block's PV products.
+template <int NW, bool STAMPS, bool BUILD>
 __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off,
                                                       const bf16_t* __restrict__ pek, const bf16_t* __restrict__ Qt,
                                                       const float* __restrict__ tq, float qscale,
                                                       float* __restrict__ Opart, float* __restrict__ ML, int split,
                                                       const bf16_t* __restrict__ Wv, const float* __restrict__ bv, bf16_t* __restrict__ out,
-                                                      unsigned long long* __restrict__ stamps) {
+                                                      unsigned long long* __restrict__ stamps, const float* __restrict__ embb, const bf16_t* __restrict__ h2,
+                                                      const float* __restrict__ w3) {
+    static_assert(!BUILD || NW == 8, "the tile builder is written for the 8-wave form");
     constexpr int T2I_KB = T2ICfg<NW>::KB, T2I_STAGE = T2ICfg<NW>::STAGE, NST = T2ICfg<NW>::NST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // development only (stamps != nullptr), see tools/dec_stamps.py
@@ -185,8 +191,47 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     const int fi = lane & 15, fg = lane >> 4;
     const int p = blockIdx.x / split, sp = blockIdx.x - p * split;
     const int nkeys = 4096 / split, key0 = sp * nkeys, nkb = nkeys / T2I_KB;
-    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs + (int64_t)key0 * DC;   // image tokens of prompt p (see kernels.h XMap)
+    const bf16_t* Xp = X + (BUILD ? 0 : (int64_t)((p + x_off) / x_div) * x_bs + (int64_t)key0 * DC);   // image tokens of prompt p (see kernels.h XMap)
     const bf16_t* Pp = pek + (int64_t)key0 * 128;
+    // BUILD: embb rows of the prompt's slot (x_bs / x_div / x_off describe the slot map then), this wave's channels; h2 rows of the prompt
+    const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + ((int64_t)key0 + fi) * DC + 32 * wave + 4 * fg : nullptr;
+    const bf16_t* Hp = BUILD ? h2 + ((int64_t)p * 4096 + key0 + fi) * 16 + 8 * (fg & 1) : nullptr;
+    bf16x8 w3f[2];
+    if (BUILD) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (fg < 2) {
+                const float* wr = w3 + (32 * wave + 16 * ct + fi) * 16 + 8 * fg;
+                const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            }
+            w3f[ct] = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+    }
+    f32x4 eb[2][4];
+    u32x4 hb[4];
+    auto load_regs = [&](int kb) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int64_t r = (int64_t)(kb * T2I_KB + 16 * tt);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) eb[ct][tt] = *reinterpret_cast<const f32x4*>(Ep + r * DC + 16 * ct);
+            hb[tt] = *reinterpret_cast<const u32x4*>(Hp + r * 16);
+        }
+    };
+    auto build_write = [&](int stage) {
+        const uint32_t sx = (uint32_t)(uintptr_t)(lptr_d)(smem + stage * T2I_STAGE);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const bf16x8 hf = __builtin_bit_cast(bf16x8, fg < 2 ? hb[tt] : (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ct], hf, eb[ct][tt], 0, 0, 0);     // a[r] = X0[key 16 tt + fi][channel 32 wave + 16 ct + 4 fg + r]
+                lds_write_b64(sx + (16 * tt + fi) * ROW_B + (((4 * wave + 2 * ct + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8, pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+            }
+        }
+    };
 
     bf16x8 qf[8], pq;
     {
@@ -221,6 +266,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     }
     auto issue = [&](int kb, int stage) {
         char* sx = smem + stage * T2I_STAGE;
+        if (!BUILD)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t off = (int64_t)(kb * T2I_KB + srow[i]) * DC + schunk[i] * 8;
@@ -242,6 +288,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
 
     // NST - 1 tiles in flight; a tile = 6 operations per wave (4 X pieces + 2 PEK pieces)
     issue(0, 0);
+    if (BUILD) { load_regs(0); build_write(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     if (NST == 3 && nkb > 1) { issue(1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -250,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     for (int kb = 0; kb < nkb; ++kb) {
         {
             const int kn = kb + NST - 1;                    // the stage it goes into was read in the previous iteration
-            if (kn < nkb) issue(kn, kn % NST);
+            if (kn < nkb) { issue(kn, kn % NST); if (BUILD) load_regs(kn); }
         }
         T2I_STAMP(0);
         const char* xs = smem + stage * T2I_STAGE + kh * 32 * ROW_B;     // this wave's 32 keys
@@ -317,6 +364,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
             }
         }
         T2I_STAMP(3);
+        if (BUILD && kb + 1 < nkb) build_write((kb + 1) % NST);      // (the compiler waits for the registers loaded at the top)
         // next block landed (this wave's part); with 3 stages the one after it stays in flight
         if (NST == 3 && kb + 2 < nkb) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,20 +478,25 @@ __global__ __launch_bounds__(256) void dec_t2i_finish_kernel(const float* __rest
 }
 
 const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, float* Opart, float* ML,
-                           int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
+                           int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s, const XBuild* build) {
     if (P <= 0) return nullptr;
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
     if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
     extern int g_saber_debug_flags;
-    if (!(g_saber_debug_flags & 4)) {  // 4-wave workgroups (two per CU, no key-half merge) measure the same as one 8-wave workgroup: kept as an option
+    const float* nf = nullptr; const bf16_t* nb = nullptr;
+    if (build) {
+        if (!build->embb || !build->h2 || !build->w3 || build->map.div <= 0) return "dec_t2i: incomplete XBuild";
+        hipLaunchKernelGGL((dec_t2i_kernel<8, false, true>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, (const bf16_t*)nullptr, build->map.stride, build->map.div, build->map.off,
+                           pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, (unsigned long long*)nullptr, build->embb, build->h2, build->w3);
+    } else if (!(g_saber_debug_flags & 4)) {  // 4-wave workgroups (two per CU, no key-half merge) measure the same as one 8-wave workgroup: kept as an option
         if (g_saber_stamp_buf)
-            hipLaunchKernelGGL((dec_t2i_kernel<8, true>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+            hipLaunchKernelGGL((dec_t2i_kernel<8, true, false>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf, nf, nb, nf);
         else
-            hipLaunchKernelGGL((dec_t2i_kernel<8, false>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+            hipLaunchKernelGGL((dec_t2i_kernel<8, false, false>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf, nf, nb, nf);
     }
     else
-        hipLaunchKernelGGL((dec_t2i_kernel<4, false>), dim3(P * split), dim3(256), T2ICfg<4>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf);
+        hipLaunchKernelGGL((dec_t2i_kernel<4, false, false>), dim3(P * split), dim3(256), T2ICfg<4>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf, nf, nb, nf);
     if (split > 1) hipLaunchKernelGGL(dec_t2i_finish_kernel, dim3(P * 8), dim3(256), 0, s, (const float*)Opart, (const float*)ML, split, Wv, bv, out);
     return nullptr;
 }
@@ -474,12 +527,18 @@ template <int RT> struct I2TCfg {
     static constexpr int LDS = I2T_NSTAGE * STAGE + 2 * PBUF_B + 2 * STAT_B + OSCR_B;
 };
 
-template <int RT, bool STAMPS>
+// BUILD (RT = 1): the X tile is assembled by the waves as bf16(embb + h2 . W3^T) instead of being copied from HBM (see dec_t2i_kernel):
+// wave qr owns channels 64 qr .. 64 qr + 63 of the 16 rows (the channels it later reads back as the residual): 4 MFMAs per tile.  The
+// registers of tile t + 3 are loaded right after the barrier of iteration t, tile t + 2 is written from the registers loaded one
+// iteration earlier; it becomes visible with the barrier of iteration t + 1 and is consumed in iteration t + 2.
+template <int RT, bool STAMPS, bool BUILD>
 __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
                                                       const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
                                                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                      bf16_t* __restrict__ Xout, int nsplit, int dbg, unsigned long long* __restrict__ stamps) {
+                                                      bf16_t* __restrict__ Xout, int nsplit, int dbg, unsigned long long* __restrict__ stamps,
+                                                      const float* __restrict__ embb, const bf16_t* __restrict__ h2, const float* __restrict__ w3) {
+    static_assert(!BUILD || RT == 1, "the tile builder is written for the 4-wave form");
     using CF = I2TCfg<RT>;
     constexpr int I2T_ROWS = CF::ROWS, I2T_STAGE = CF::STAGE, I2T_PBUF_B = CF::PBUF_B, I2T_STAT_B = CF::STAT_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -495,8 +554,30 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     const int p = blockIdx.x / nsplit;
     const int NT = (4096 / I2T_ROWS) / nsplit;                  // tiles of this block
     const int64_t row0 = (int64_t)(blockIdx.x % nsplit) * NT * I2T_ROWS;
-    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs + row0 * DC;
+    const bf16_t* Xp = X + (BUILD ? 0 : (int64_t)((p + x_off) / x_div) * x_bs + row0 * DC);
     const bf16_t* pep = peq + row0 * 128;
+    const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + (row0 + fi) * DC + 64 * qr + 4 * fg : nullptr;
+    const bf16_t* Hp = BUILD ? h2 + ((int64_t)p * 4096 + row0 + fi) * 16 + 8 * (fg & 1) : nullptr;
+    bf16x8 w3f[4];
+    if (BUILD) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (fg < 2) {
+                const float* wr = w3 + (64 * qr + 16 * ct + fi) * 16 + 8 * fg;
+                const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            }
+            w3f[ct] = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+    }
+    f32x4 eb[4];
+    u32x4 hb;
+    auto load_regs = [&](int t) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) eb[ct] = *reinterpret_cast<const f32x4*>(Ep + (int64_t)t * I2T_ROWS * DC + 16 * ct);
+        hb = *reinterpret_cast<const u32x4*>(Hp + (int64_t)t * I2T_ROWS * 16);
+    };
     bf16_t* Xo = Xout + ((int64_t)p * 4096 + row0) * DC;
 
     // folded operands of this prompt, straight into registers
@@ -536,6 +617,7 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     const int prow = 4 * wave + (lane >> 4), pchunk = (lane & 15) ^ (prow & 15);
     auto issue = [&](int t) {
         char* sx = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+        if (!BUILD)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t off = (int64_t)(t * I2T_ROWS + srow[i]) * DC + schunk[i] * 8;
@@ -590,8 +672,25 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
         __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(orow + 8 * DC));       // streamed: the 2 MB per prompt are read back by the next kernel long after they left the caches
     };
 
+    // BUILD: X0 tile t from the registers load_regs(t) filled: a[r] = X0[row fi][channel 64 qr + 16 ct + 4 fg + r], written where the wave
+    // reads its residual back (roff)
+    auto build_write = [&](int t) {
+        const uint32_t sx = smem_a + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+        const bf16x8 hf = __builtin_bit_cast(bf16x8, fg < 2 ? hb : (u32x4){0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ct], hf, eb[ct], 0, 0, 0);
+            lds_write_b64(sx + roff[ct], pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+        }
+    };
     issue(0); issue(1); issue(2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (BUILD) {
+        load_regs(0); build_write(0);
+        if (NT > 1) { load_regs(1); build_write(1); }
+        if (NT > 2) load_regs(2);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    } else
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < NT; ++t) {
@@ -626,7 +725,12 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
         // tile t+1 (issued two iterations ago) must have landed before the barrier makes it visible to everyone; the younger
         // loads and the bf16 stores stay in flight.  Queue behind L(t+1): [S(t-3)] L(t+2) [S(t-2)]; a load group is 3 ops, a store group 2.
         I2T_STAMP(0);
-        if (t + 3 >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (BUILD) {
+            // the wave's PEQ piece of tile t+1 is older than the registers of tile t+1, which were waited for when that tile was written
+            // (iteration t-1, or the prologue): nothing to wait for here but the LDS writes
+            if (t + 3 >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        else if (t + 3 >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (t < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else if (t == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -635,6 +739,10 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();      // the ONE barrier per tile: P(t) and stat(t-1) complete, tile t+1 visible, slot of tile t-1 free
         I2T_STAMP(2);
         if (t + 3 < NT) issue(t + 3);
+        if (BUILD) {
+            if (t + 2 < NT) build_write(t + 2);
+            if (t + 3 < NT) load_regs(t + 3);
+        }
         I2T_STAMP(3);
         if (t > 0) finish_tile(t - 1);
         I2T_STAMP(4);
@@ -687,8 +795,17 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
 }
 
 const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* VtT,
-                           const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s) {
+                           const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s, const XBuild* build) {
     if (P <= 0) return nullptr;
+    const float* nf = nullptr; const bf16_t* nb = nullptr;
+    if (build) {
+        if (!build->embb || !build->h2 || !build->w3 || build->map.div <= 0) return "dec_i2t: incomplete XBuild";
+        int ns = 1;
+        while (P * ns < 512 && ns < 8) ns *= 2;
+        hipLaunchKernelGGL((dec_i2t_kernel<1, false, true>), dim3(P * ns), dim3(256), I2TCfg<1>::LDS, s, (const bf16_t*)nullptr, build->map.stride, build->map.div, build->map.off, peq, Kt, tk,
+                           kscale, cb, VtT, bo, gamma, beta, eps, Xout, ns, 0, (unsigned long long*)nullptr, build->embb, build->h2, build->w3);
+        return nullptr;
+    }
     int nsplit = 1;
     while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's tiles over several blocks
     extern int g_saber_debug_flags;
@@ -696,12 +813,12 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
     extern unsigned long long* g_saber_stamp_buf;
     if (g_saber_debug_flags & 1)
-        hipLaunchKernelGGL((dec_i2t_kernel<2, false>), dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+        hipLaunchKernelGGL((dec_i2t_kernel<2, false, false>), dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
     else
         if (g_saber_stamp_buf)
-            hipLaunchKernelGGL((dec_i2t_kernel<1, true>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+            hipLaunchKernelGGL((dec_i2t_kernel<1, true, false>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
         else
-            hipLaunchKernelGGL((dec_i2t_kernel<1, false>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf);
+            hipLaunchKernelGGL((dec_i2t_kernel<1, false, false>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
     return nullptr;
 }
 
@@ -909,12 +1026,14 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
 }
 
 const char* decoder_fused_init_device() {
-    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<4>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
+    hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<4>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }

@@ -224,6 +224,74 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
     }
 }
 
+// phase 1 of mask_embed_src_kernel alone: the hidden vectors go to HBM as bf16 (the operand precision of the 1 x 1 conv's MFMA)
+__global__ __launch_bounds__(256) void mask_hidden_kernel(const float* __restrict__ mask_in, int P, MaskEmbedWeights w, bf16_t* __restrict__ h2out,
+                                                         float clamp_abs, int raw4_q0) {
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x >> 6, tok0 = (blockIdx.x & 63) * 64;
+    const int tl = tid >> 2, q = tid & 3;
+    const int py = q >> 1, px = q & 1;
+    int ty, tx;
+    perm_coords(tok0 + tl, 2, &ty, &tx);
+    const int64_t plane = raw4_q0 >= 0 ? (int64_t)(raw4_q0 + p) + (raw4_q0 + p) / 3 + 1 : (int64_t)p;
+    const float* mp = mask_in + plane * 65536 + (int64_t)(ty * 4 + py * 2) * 256 + tx * 4 + px * 2;
+    const float2 r0 = *reinterpret_cast<const float2*>(mp), r1 = *reinterpret_cast<const float2*>(mp + 256);
+    const float in[4] = {fminf(fmaxf(r0.x, -clamp_abs), clamp_abs), fminf(fmaxf(r0.y, -clamp_abs), clamp_abs),
+                         fminf(fmaxf(r1.x, -clamp_abs), clamp_abs), fminf(fmaxf(r1.y, -clamp_abs), clamp_abs)};
+    float v[4], mu = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float a = w.b1[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a += w.w1[c * 4 + k] * in[k];
+        v[c] = a;
+        mu += a;
+    }
+    mu *= 0.25f;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) var += (v[c] - mu) * (v[c] - mu);
+    float rstd = __builtin_amdgcn_rsqf(var * 0.25f + 1e-6f);
+    float h1[4][4], mine[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mine[c] = gelu_erf((v[c] - mu) * rstd * w.g1[c] + w.be1[c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h1[0][c] = quad_bcast<0>(mine[c]); h1[1][c] = quad_bcast<1>(mine[c]); h1[2][c] = quad_bcast<2>(mine[c]); h1[3][c] = quad_bcast<3>(mine[c]);
+    }
+    float h2[4];
+    mu = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * q + cc;
+        float a = w.b2[c];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a += w.w2[(c * 4 + ci) * 4 + k] * h1[k][ci];
+        h2[cc] = a;
+        mu += a;
+    }
+    mu = quad_sum(mu);
+    mu *= (1.0f / 16.0f);
+    var = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) var += (h2[cc] - mu) * (h2[cc] - mu);
+    var = quad_sum(var);
+    rstd = __builtin_amdgcn_rsqf(var * (1.0f / 16.0f) + 1e-6f);
+    const float o0 = gelu_erf((h2[0] - mu) * rstd * w.g2[4 * q + 0] + w.be2[4 * q + 0]);
+    const float o1 = gelu_erf((h2[1] - mu) * rstd * w.g2[4 * q + 1] + w.be2[4 * q + 1]);
+    const float o2 = gelu_erf((h2[2] - mu) * rstd * w.g2[4 * q + 2] + w.be2[4 * q + 2]);
+    const float o3 = gelu_erf((h2[3] - mu) * rstd * w.g2[4 * q + 3] + w.be2[4 * q + 3]);
+    *reinterpret_cast<uint2*>(h2out + ((int64_t)p * 4096 + tok0 + tl) * 16 + 4 * q) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+}
+const char* launch_mask_hidden(const float* mask_in, int P, MaskEmbedWeights w, bf16_t* h2, float clamp_abs, hipStream_t s, int raw4_q0) {
+    if (P <= 0) return nullptr;
+    if (!(clamp_abs > 0.f)) clamp_abs = 3.0e38f;
+    hipLaunchKernelGGL(mask_hidden_kernel, dim3(P * 64), dim3(256), 0, s, mask_in, P, w, h2, clamp_abs, raw4_q0);
+    return nullptr;
+}
+
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap em, const float* pos, MaskEmbedWeights w,
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s, int raw4_q0) {
     if (P <= 0) return nullptr;

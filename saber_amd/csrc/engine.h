@@ -83,6 +83,9 @@ struct saber_engine {
     float *emb = nullptr, *fs1 = nullptr, *fs0 = nullptr;
     // per-slot first-pass shared tensors (src0 = image_embed + no_mask_embed)
     bf16_t* src0_bf = nullptr;
+    float* embb = nullptr;            // per slot: image_embed + mask_downscaling.6.bias (the C operand of the in-kernel X0 tiles, XBuild)
+    bf16_t* h2_bf = nullptr;          // [max_prompts][4096][16]: hidden vectors of the mask-prompt embedding (launch_mask_hidden)
+    std::vector<char> slot_embb_valid;
     std::vector<char> slot_valid, slot_shared_valid;
 
     // decoder workspace (per chunk of max_prompts prompts)

@@ -623,8 +623,10 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->fs1, B * 16384 * 64));
     TRY(eng_alloc(e, &e->fs0, B * 65536 * 32));
     TRY(eng_alloc(e, &e->src0_bf, B * 4096 * 256));
+    TRY(eng_alloc(e, &e->embb, B * 4096 * 256));
     e->slot_valid.assign(B, 0);
     e->slot_shared_valid.assign(B, 0);
+    e->slot_embb_valid.assign(B, 0);
 
     TRY(eng_alloc(e, &e->tok_pe, P * 8 * 256));
     TRY(eng_alloc(e, &e->queries, P * 8 * 256));
@@ -636,6 +638,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->t_att, P * 8 * 256));
     TRY(eng_alloc(e, &e->t_hid, P * 8 * 2048));
     TRY(eng_alloc(e, &e->keys_bf, P * 4096 * 256));
+    TRY(eng_alloc(e, &e->h2_bf, P * 4096 * 16));
     TRY(eng_alloc(e, &e->fold_q, P * 64 * 256));
     TRY(eng_alloc(e, &e->fold_k, P * 64 * 256));
     TRY(eng_alloc(e, &e->fold_v, P * 64 * 256));
@@ -780,7 +783,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
     if (e->precision == SABER_PRECISION_EXACT) {
         TRY(exact_encode_blocks(e, n, slot0, s));
-        for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
+        for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; e->slot_embb_valid[slot0 + i] = 0; }
         return SABER_OK;
     }
     float* x = e->xa;
@@ -893,7 +896,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         g.Cf = e->fs0 + (size_t)slot0 * 65536 * 32; g.ldcf = 32;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
     }
-    for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
+    for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; e->slot_embb_valid[slot0 + i] = 0; }
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;
 }
@@ -952,6 +955,7 @@ extern "C" int saber_set_embed_tokens(saber_engine* e, int slot, const float* to
     hipStream_t s = (hipStream_t)stream;
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_gather_rows(tokens_dev, 4096, e->emb + (size_t)slot * 4096 * 256, 4096, e->eng_to_rm, 256, 1, s));
     e->slot_shared_valid[slot] = 0;        // image_embed + no_mask_embed of this slot must be rebuilt
+    e->slot_embb_valid[slot] = 0;
     return SABER_OK;
 }
 // Slot state across engine handles / ranks (propagation path: the per-frame encodes of a tomogram shard over ranks and are
@@ -982,7 +986,7 @@ extern "C" int saber_import_slots(saber_engine* e, int slot0, int n, const float
     ENG_HIP(e, hipMemcpyAsync(e->emb + (size_t)slot0 * 4096 * 256, emb_dev, (size_t)n * 4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     ENG_HIP(e, hipMemcpyAsync(e->fs1 + (size_t)slot0 * 16384 * 64, fs1_dev, (size_t)n * 16384 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     ENG_HIP(e, hipMemcpyAsync(e->fs0 + (size_t)slot0 * 65536 * 32, fs0_dev, (size_t)n * 65536 * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; }
+    for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; e->slot_embb_valid[slot0 + i] = 0; }
     return SABER_OK;
 }
 // the 8 tokens of the first n prompts of the LAST decode call after the two-way transformer ([obj, iou, mask0..3, point, pad] x 256 fp32):
@@ -1003,6 +1007,15 @@ static int ensure_shared(saber_engine* e, int slot, hipStream_t s) {
     // src0 = image_embed + no_mask_embed (identical for every first-pass prompt of this crop)
     ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->emb + o256, e->no_mask_embed, 1, e->src0_bf + o256, nullptr, 4096, 256, s));
     e->slot_shared_valid[slot] = 1;
+    return SABER_OK;
+}
+
+static int ensure_embb(saber_engine* e, int slot, hipStream_t s) {
+    if (e->slot_embb_valid[slot]) return SABER_OK;
+    const size_t o256 = (size_t)slot * 4096 * 256;
+    // image_embed + b3 (fp32): what mask_embed_src_kernel adds before its MFMA; the layer-0 kernels load it as their tiles' C operand
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->emb + o256, e->mw.b3, 1, nullptr, e->embb + o256, 4096, 256, s));
+    e->slot_embb_valid[slot] = 1;
     return SABER_OK;
 }
 
@@ -1036,12 +1049,23 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
     const bf16_t* X;      // image tokens of each prompt, bf16 [4096][256], engine order
     XMap xm;
+    XBuild xb;
+    const XBuild* build = nullptr;          // layer 0 of a mask-prompted decode: X0 tiles assembled in the kernels
+    const bool no_build = getenv("SABER_AMD_NO_XBUILD") != nullptr;      // development A/B switch (read per call): materialise src with mask_embed_src_kernel
     if (shared) {
         for (int sl = slot0 + p_base / per_slot; sl <= slot_last; ++sl) TRY(ensure_shared(e, sl, s));
         X = e->src0_bf + o256; xm = slots;
-    } else {
+    } else if (no_build) {
         ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 256 * 2), launch_mask_embed_src(mask_in, P, e->emb + o256, slots, e->dense_pe, e->mw, nullptr, e->keys_bf, nullptr, mask_clamp, s, mask_in_q0));
         X = e->keys_bf; xm = per_prompt;
+    } else {
+        // src = image_embed + mask-prompt embedding is never materialised: only the 16-channel hidden vectors go to HBM (32 B per token
+        // against 512 B), the layer-0 kernels assemble the tiles (XBuild)
+        for (int sl = slot0 + p_base / per_slot; sl <= slot_last; ++sl) TRY(ensure_embb(e, sl, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)P * (65536.0 * 4 + 4096.0 * 16 * 2), launch_mask_hidden(mask_in, P, e->mw, e->h2_bf, mask_clamp, s, mask_in_q0));
+        xb.embb = e->embb + o256; xb.map = slots; xb.h2 = e->h2_bf; xb.w3 = e->mw.w3;
+        build = &xb;
+        X = nullptr; xm = per_prompt;
     }
 
     // tokens -> image: fold q into 64 rows of dimension 256, stream X once (dec_t2i), un-fold with v_proj
@@ -1051,7 +1075,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         g.Cf = e->tq; g.ldcf = 128;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tq, a.k.w, nullptr, 0, kScale, e->fold_q, nullptr, P, s));
-        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, a.pe_proj, e->fold_q, e->tq, kScale, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s));
+        ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, a.pe_proj, e->fold_q, e->tq, kScale, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s, build));
         g = mk_gemm(e->t_att, 128, PT, a.o);
         g.Cf = e->queries; g.ldcf = 256; g.res = e->queries; g.ldres = 256;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
@@ -1088,8 +1112,8 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         g = mk_gemm(e->t_bf1, 256, PT, w.i2t.v); g.Cf = e->tv; g.ldcf = 128; ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K, gemm_bytes(g), launch_gemm(g, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tk, w.i2t.q.w, w.i2t.q.b, 0, kScale, e->fold_k, e->fold_cb, P, s));
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_dec_fold(e->tv, w.i2t.o.w, nullptr, 1, 1.0f, e->fold_v, nullptr, P, s));
-        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, w.i2t.pe_proj, e->fold_k, e->tk, kScale, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s));
-        X = e->keys_bf; xm = per_prompt;
+        ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, w.i2t.pe_proj, e->fold_k, e->tk, kScale, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s, build));
+        X = e->keys_bf; xm = per_prompt; build = nullptr;
     }
     TRY(t2i(e->final_attn, e->final_ln));
 

@@ -102,6 +102,16 @@ struct XMap { int64_t stride; int div; int off; };
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap emb_map, const float* pos, MaskEmbedWeights w,
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s, int raw4_q0 = -1);   // clamp_abs > 0: mask_in is clamped to +-clamp_abs on load
 
+// h2[p][tok][16] (bf16, engine token order) = the 16-channel hidden vector of the mask-prompt embedding: the first two stages of
+// mask_downscaling (conv k2s2 1->4, LN2d, GELU, conv k2s2 4->16, LN2d, GELU) on the 4 x 4 logit patch of each token.  The 1 x 1 conv to 256
+// channels + image_embed ("src") is assembled tile by tile inside the layer-0 kernels of the two-way transformer (XBuild below) and never
+// reaches HBM: 32 B per token instead of 512 B written once and read twice.
+const char* launch_mask_hidden(const float* mask_in, int P, MaskEmbedWeights w, bf16_t* h2, float clamp_abs, hipStream_t s, int raw4_q0 = -1);
+// How a layer-0 kernel assembles X0 = bf16(image_embed + b3 + h2 . W3^T) for prompt p: embb = image_embed + b3 (fp32 [slots][4096][256],
+// engine token order) of slot (p + map.off) / map.div; h2 as above; w3 = mask_downscaling.6.weight fp32 [256][16].  Same arithmetic as
+// mask_embed_src_kernel<true> (one K = 16 MFMA per 16 x 16 block with the fp32 image_embed + b3 as its C operand): bit-identical tiles.
+struct XBuild { const float* embb = nullptr; XMap map{0, 1, 0}; const bf16_t* h2 = nullptr; const float* w3 = nullptr; };
+
 // fp32 multi-head attention for the two-way transformer.  q [B][nq][heads*hd], k/v [B or 1][nk][heads*hd].
 // Output is bf16 (it always feeds the out_proj GEMM).
 const char* launch_dec_attention(const float* q, const float* k, const float* v, bf16_t* out, int B, int nq, int nk, int heads,
@@ -119,9 +129,9 @@ const char* launch_dec_fold(const float* a, const bf16_t* W, const float* bias, 
 // pek / peq: the dense positional encoding projected by the attention's image-side weight, bf16 [4096][128] in engine token order
 // (pe W_k^T for tokens->image, pe W_q^T for image->tokens); tq / tk: the token-side projections fp32 [P*8][128]; scale: head_dim^-0.5 log2(e)
 const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, float* Opart, float* ML,
-                           int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
+                           int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s, const XBuild* build = nullptr);
 const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* Vt,
-                           const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s);
+                           const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s, const XBuild* build = nullptr);
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap slot_map, const float* hyper, float* masks4, int P,
                                hipStream_t s);

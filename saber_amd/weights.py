@@ -210,6 +210,32 @@ def seeded_weights(cfg: HieraConfig, seed: int = 0, video: bool = False) -> Dict
     return OrderedDict((n, _gen(n, s, k, g, seed)) for n, (s, k, g) in specs.items())
 
 
+def stress_weights(cfg: HieraConfig, seed: int = 0, gamma_outlier: float = 30.0, massive: float = 60.0) -> Dict[str, np.ndarray]:
+    """seeded_weights with the activation statistics trained ViT checkpoints are known for and random initialisation lacks (no real
+    SAM2.1 checkpoint can be fetched offline): (a) outlier LayerNorm gains - two channels of every norm1 / norm2
+    scaled by `gamma_outlier`, so two input columns of each qkv / fc1 GEMM carry values ~30x the rest; (b) two "massive" residual
+    channels - in the second block of stages 1 and 2 two output rows of mlp.layers.1 are scaled by `massive` and biased, which leaves
+    |x| ~ 100-1000 in those channels of the residual stream for the rest of the trunk (every later LayerNorm's variance is then set
+    by two channels); (c) a 5x larger background pos_embed.  Used by tests only: the precision modes are compared on it."""
+    W = seeded_weights(cfg, seed)
+    rng = np.random.default_rng(1000 + seed)
+    t = "image_encoder.trunk."
+    specs = cfg.block_specs()
+    for i, (din, dout, heads, win, qs) in enumerate(specs):
+        for nm, c in (("norm1", din), ("norm2", dout)):
+            ch = rng.choice(c, 2, replace=False)
+            W[f"{t}blocks.{i}.{nm}.weight"][ch] *= np.float32(gamma_outlier)
+    ends = cfg.stage_ends
+    for st in (1, 2):
+        i = ends[st - 1] + 2                       # second block of the stage
+        dout = specs[i][1]
+        ch = rng.choice(dout, 2, replace=False)
+        W[f"{t}blocks.{i}.mlp.layers.1.weight"][ch] *= np.float32(massive)
+        W[f"{t}blocks.{i}.mlp.layers.1.bias"][ch] += np.float32(massive) * np.float32([1.0, -1.0])
+    W[t + "pos_embed"] *= np.float32(5.0)
+    return W
+
+
 def load_checkpoint(path: str, cfg: HieraConfig, video: bool = False) -> Dict[str, np.ndarray]:
     """Read an upstream ``sam2.1_hiera_*.pt`` and keep the image-model tensors.
 

@@ -1,0 +1,128 @@
+"""GPU: BASELINE configs[3] and configs[4] at FULL size on one GPU.
+
+configs[3]: the 512-slice tomogram (1024 x 1024 x 512 uint16, oracle.saber_ref.synthetic_volume(seed=2), SURVEY.md 8d "Config 4") through the
+product's z-loop (propagationSegmenter.slice_by_slice_device: Hiera-L, cfgAMG's default grid and crop pyramid, two slices in flight, label
+planes painted and stitched on the device).  The 8-GPU form differs only in which rank owns which z-chunk and in one all-gather
+(tests/test_distributed_cpu.py: sharding + gather on gloo; tests/test_gpu_round2.py: the RCCL call path).
+configs[4]: one of the batch's 256-slice tomograms with e4m3 weights and hipGraph replay of the per-slice encode + decode sequences.
+
+The score thresholds are those of tests/test_gpu_config2_volume.py (the seeded, untrained decoder leaves nothing at cfgAMG's own), so the
+paint / gather / stitch steps run on real labels.  Full-size checks are size-independent properties of slice_by_slice's contract
+(propagation.py:163-189) plus exact equalities on z-windows that a host recomputation can afford."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def segmenter():
+    import os
+    os.environ["SABER_AMD_SEEDED_WEIGHTS"] = "1"
+    from saber_amd.adapters.base import SAM2AdapterConfig
+    from saber_amd.adapters.sam2.amg import cfgAMG
+    from saber_amd.segmenters.propagation import propagationSegmenter
+    amg = cfgAMG(sam2_cfg="large", pred_iou_thresh=0.5, stability_score_thresh=0.8)
+    assert (amg.npoints, amg.crop_n_layers, amg.box_nms_thresh) == (32, 2, 0.7)
+    cfg = SAM2AdapterConfig(cfg="large", amg_cfg=amg, min_mask_area=50)
+    return propagationSegmenter(deviceID=0, cfg=cfg, min_mask_area=50)
+
+
+def test_config3_512_slices_full_size(segmenter):
+    from oracle import saber_ref
+    from saber_amd.segmenters import utils
+    from saber_amd.segmenters.slice_driver import shard_bounds
+    t0 = time.perf_counter()
+    vol = saber_ref.synthetic_volume(seed=2, depth=512)
+    print(f"configs[3]: synthetic 512-slice tomogram built on the host in {time.perf_counter() - t0:.0f} s", flush=True)
+    assert vol.shape == (512, 1024, 1024) and vol.dtype == np.uint16
+    dev = torch.from_numpy(vol).cuda()                                # the tomogram resident in HBM (1 GiB), as bench.py times it
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    planes = segmenter.slice_by_slice_device(dev, stitch=False)
+    dt = time.perf_counter() - t0
+    print(f"configs[3] on one GPU: 512 slices -> label planes in {dt:.1f} s = {512 / dt:.2f} slices/s", flush=True)
+    assert planes.shape == vol.shape and planes.dtype == np.uint16
+    n_fg = int((planes.reshape(512, -1).max(1) > 0).sum())
+    print(f"configs[3]: {n_fg} of 512 planes carry masks, max per-slice id {int(planes.max())}")
+    assert n_fg > 256
+    # (1) per-slice ids are list positions: contiguous 1..n on every plane (propagation.py:185-186)
+    for z in range(0, 512, 37):
+        ids = np.unique(planes[z])
+        assert np.array_equal(ids[ids > 0], np.arange(1, (ids > 0).sum() + 1)), z
+    # (2) slices are independent units: the 8-rank z-chunks recomputed standalone give the planes of the full run (what makes the sharded
+    #     run equal to this one by construction); first slice of four of the eight chunks + a mid-chunk slice
+    for r in (0, 3, 5, 7):
+        z0, z1 = shard_bounds(512, 8, r)
+        assert z1 - z0 == 64
+        for z in (z0, z0 + 31):
+            again = segmenter.slice_by_slice_device(dev[z:z + 1], stitch=False)
+            assert np.array_equal(again[0], planes[z]), z
+    # (3) stitched volume on the device
+    t0 = time.perf_counter()
+    eng = segmenter.adapter._generator().base_generator.engine
+    pd = torch.from_numpy(planes.view(np.int16)).cuda()
+    labels_dev, K = eng.separate_masks(pd, min_mask_area=100)
+    labels = labels_dev.cpu().numpy().view(np.uint32)
+    print(f"configs[3]: device stitch of 512 planes: {K} labels in {time.perf_counter() - t0:.2f} s (incl. H2D / D2H of the volume)")
+    assert labels.shape == vol.shape and K == int(labels.max()) and K >= 1
+    counts = np.bincount(labels.ravel(), minlength=K + 1)
+    assert (counts[1:] >= 1000).all()                                  # min_mask_area * 10 voxels (utils.py:113-119)
+    assert not (labels.astype(bool) & ~planes.astype(bool)).any()
+    # (4) device stitch = host stitch on a z-window (scipy on 24 planes), min_mask_area = 0 so that the window's components are all kept
+    win = np.ascontiguousarray(planes[200:224])
+    host = utils.separate_masks(win, min_mask_area=0)
+    devw, _ = eng.separate_masks(torch.from_numpy(win.view(np.int16)).cuda(), min_mask_area=0)
+    assert np.array_equal(devw.cpu().numpy().view(np.uint32), host)
+    # (5) the labels of the full stitch restricted to the window are a coarsening of the window's own components (components only merge
+    #     through planes outside the window) and every kept voxel of the window is foreground
+    lw = labels[200:224]
+    sel = lw > 0
+    pairs = np.unique(np.stack([host[sel].astype(np.int64), lw[sel].astype(np.int64)], 1), axis=0)
+    assert len(np.unique(pairs[:, 0])) == len(pairs)                   # each window component maps to ONE global label
+
+
+def test_config4_256_slices_fp8_weights_hipgraph(large_weights):
+    from oracle import saber_ref
+    from saber_amd.engine import Engine, make_amg_params
+    from saber_amd.segmenters.slice_driver import segment_slice_to_plane
+    cfg, W = large_weights
+    vol = saber_ref.synthetic_volume(seed=3, depth=256)
+    dev = torch.from_numpy(vol).cuda()
+    params = make_amg_params(dict(pred_iou_thresh=0.5, stability_score_thresh=0.8))
+    eng = Engine("large", device=0, weights=W, max_images=21, max_prompts=1024, weight_format="fp8")
+    try:
+        st = torch.cuda.Stream()
+        planes = torch.zeros((256, 1024, 1024), dtype=torch.int16, device="cuda")
+        eng.set_graphs(True)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st):
+            for z in range(256):
+                p, _ = segment_slice_to_plane(eng, dev[z], params, min_mask_area=50)
+                planes[z] = p.view(torch.int16)
+            st.synchronize()
+        dt = time.perf_counter() - t0
+        cap, rep = eng.graph_stats()
+        print(f"configs[4] on one GPU: 256 slices, e4m3 weights, hipGraph replay ({cap} sequences captured, {rep} replays) in {dt:.1f} s = {256 / dt:.2f} slices/s")
+        assert cap >= 7 and rep >= 7 * 250                             # encoder pass + 6 decoder batches per slice, replayed from the third slice on
+        n_fg = int((planes.view(256, -1).max(1).values > 0).sum())
+        assert n_fg > 128
+        # eager fp8 run of a z-subsample: planes identical to the replayed run's
+        eng.set_graphs(False)
+        with torch.cuda.stream(st):
+            for z in (0, 1, 2, 77, 128, 255):
+                p, _ = segment_slice_to_plane(eng, dev[z], params, min_mask_area=50)
+                assert torch.equal(p.view(torch.int16), planes[z]), z
+            st.synchronize()
+        # stitch of the tomogram on the device, and the properties of its result
+        labels, K = eng.separate_masks(planes, min_mask_area=100)
+        lab = labels.cpu().numpy().view(np.uint32)
+        assert K >= 1 and K == int(lab.max())
+        counts = np.bincount(lab.ravel(), minlength=K + 1)
+        assert (counts[1:] >= 1000).all()
+        assert not (lab.astype(bool) & ~(planes.cpu().numpy() != 0)).any()
+    finally:
+        eng.close()

@@ -183,3 +183,27 @@ def test_flat_slices_through_prepare_and_the_slice_step(engine):
             assert not ref.any() and not got.any()
         plane, n = segment_slice_to_plane(engine, torch.from_numpy(sl).cuda(), make_amg_params(dict(npoints=4, crop_n_layers=0)), min_mask_area=50)
         assert plane.shape == (1024, 1024) and plane.dtype == torch.uint16 and int(plane.cpu().numpy().max()) <= n
+
+
+def test_m2m_src_assembled_in_kernel_equals_materialised(engine):
+    """Round 3: the m2m prompts' src = image_embed + mask-prompt embedding is assembled tile by tile inside layer 0's dec_t2i / dec_i2t
+    (XBuild) from the 16-channel hidden vectors instead of being written by mask_embed_src_kernel and read back twice: bit-identical
+    outputs (same MFMA, same C operand, same bf16 rounding of the tile), single-slot and multi-slot batches, ragged prompt counts."""
+    import os
+    rng = np.random.default_rng(21)
+    img = torch.from_numpy(rng.uniform(0, 1, (1024, 1024)).astype(np.float32)).cuda()
+    engine.encode(img, [[0, 0, 1024, 1024], [100, 50, 700, 650]], slot0=0)
+    for n in (1, 7, 32, 45):
+        pts = torch.tensor(rng.uniform(0, 1024, (n, 2)).astype(np.float32)).cuda()
+        mi = (torch.from_numpy(rng.normal(0, 6, (n, 256, 256)).astype(np.float32))).cuda()
+        for slot in (0, 1):
+            os.environ["SABER_AMD_NO_XBUILD"] = "1"
+            try:
+                ref = engine.decode_points(pts, slot=slot, multimask=False, mask_input=mi)
+                torch.cuda.synchronize()
+            finally:
+                del os.environ["SABER_AMD_NO_XBUILD"]
+            got = engine.decode_points(pts, slot=slot, multimask=False, mask_input=mi)
+            torch.cuda.synchronize()
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), (n, slot)
