@@ -194,7 +194,9 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     const bf16_t* Xp = X + (BUILD ? 0 : (int64_t)((p + x_off) / x_div) * x_bs + (int64_t)key0 * DC);   // image tokens of prompt p (see kernels.h XMap)
     const bf16_t* Pp = pek + (int64_t)key0 * 128;
     // BUILD: embb rows of the prompt's slot (x_bs / x_div / x_off describe the slot map then), this wave's channels; h2 rows of the prompt
-    const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + ((int64_t)key0 + fi) * DC + 32 * wave + 4 * fg : nullptr;
+    // embb is stored in the builder's own order (launch_embb_tiles): [16-row tile][16-channel tile][lane][4 floats], so that one load
+    // instruction of a wave reads one contiguous KB.  This wave: channel tiles 2 wave, 2 wave + 1 of the block's four row tiles.
+    const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + ((int64_t)(key0 / 16) * 16 + 2 * wave) * 256 + lane * 4 : nullptr;
     const bf16_t* Hp = BUILD ? h2 + ((int64_t)p * 4096 + key0 + fi) * 16 + 8 * (fg & 1) : nullptr;
     bf16x8 w3f[2];
     if (BUILD) {
@@ -211,17 +213,22 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     }
     f32x4 eb[2][4];
     u32x4 hb[4];
+    // The loads go through inline asm and are waited for by hand (build_write): left to the compiler, its wait lands wherever it
+    // schedules the first register copy, and across the loop's back edge it is always vmcnt(0).
     auto load_regs = [&](int kb) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const int64_t r = (int64_t)(kb * T2I_KB + 16 * tt);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) eb[ct][tt] = *reinterpret_cast<const f32x4*>(Ep + r * DC + 16 * ct);
-            hb[tt] = *reinterpret_cast<const u32x4*>(Hp + r * 16);
+            const float* ea = Ep + (int64_t)(kb * 4 + tt) * 16 * 256;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024" : "=&v"(eb[0][tt]), "=&v"(eb[1][tt]) : "v"(ea) : "memory");
+            const bf16_t* ha = Hp + (int64_t)(kb * T2I_KB + 16 * tt) * 16;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(hb[tt]) : "v"(ha) : "memory");
         }
     };
     auto build_write = [&](int stage) {
         const uint32_t sx = (uint32_t)(uintptr_t)(lptr_d)(smem + stage * T2I_STAGE);
+        // every load of this wave has landed (the registers are operands of the wait so that no use can be scheduled above it)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(eb[0][0]), "+v"(eb[0][1]), "+v"(eb[0][2]), "+v"(eb[0][3]), "+v"(eb[1][0]), "+v"(eb[1][1]), "+v"(eb[1][2]), "+v"(eb[1][3]),
+                     "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]) :: "memory");
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const bf16x8 hf = __builtin_bit_cast(bf16x8, fg < 2 ? hb[tt] : (u32x4){0u, 0u, 0u, 0u});
@@ -525,6 +532,7 @@ template <int RT> struct I2TCfg {
     static constexpr int STAT_B = RT * 16 * 4 * 2 * 4;                  // one statistics buffer: [RT][16 rows][4 quarters][sum, sumsq]
     static constexpr int OSCR_B = 4 * RT * 2048;                        // per wave: 16 rows x 128 B of the output tile, transposed into full-line stores
     static constexpr int LDS = I2T_NSTAGE * STAGE + 2 * PBUF_B + 2 * STAT_B + OSCR_B;
+    static constexpr int W3_B = 256 * 32;                               // BUILD: mask_downscaling.6.weight as bf16 [256][16]
 };
 
 // BUILD (RT = 1): the X tile is assembled by the waves as bf16(embb + h2 . W3^T) instead of being copied from HBM (see dec_t2i_kernel):
@@ -532,7 +540,7 @@ template <int RT> struct I2TCfg {
 // registers of tile t + 3 are loaded right after the barrier of iteration t, tile t + 2 is written from the registers loaded one
 // iteration earlier; it becomes visible with the barrier of iteration t + 1 and is consumed in iteration t + 2.
 template <int RT, bool STAMPS, bool BUILD>
-__global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
+__global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
                                                       const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
                                                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -556,27 +564,30 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     const int64_t row0 = (int64_t)(blockIdx.x % nsplit) * NT * I2T_ROWS;
     const bf16_t* Xp = X + (BUILD ? 0 : (int64_t)((p + x_off) / x_div) * x_bs + row0 * DC);
     const bf16_t* pep = peq + row0 * 128;
-    const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + (row0 + fi) * DC + 64 * qr + 4 * fg : nullptr;
+    // (embb in the builder's order, see dec_t2i_kernel: this wave reads channel tiles 4 qr .. 4 qr + 3 of a row tile = 4 contiguous KB)
+    const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + ((row0 / 16) * 16 + 4 * qr) * 256 + lane * 4 : nullptr;
     const bf16_t* Hp = BUILD ? h2 + ((int64_t)p * 4096 + row0 + fi) * 16 + 8 * (fg & 1) : nullptr;
-    bf16x8 w3f[4];
+    // W3 (bf16) lives in LDS behind the kernel's own regions: 16 registers per lane would push the kernel past 256 and cost the second
+    // workgroup of the CU.  A-operand fragment of channel tile ct: row 64 qr + 16 ct + fi, k = 8 (fg & 1) .. + 7; the lanes of k >= 16
+    // (fg >= 2) read the same bytes as their k - 16 twins: their products vanish against the zeros of the h2 operand.
+    const uint32_t w3_a = (uint32_t)(uintptr_t)(lptr_d)(smem + CF::LDS) + (64 * qr + fi) * 32 + (fg & 1) * 16;
     if (BUILD) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (fg < 2) {
-                const float* wr = w3 + (64 * qr + 16 * ct + fi) * 16 + 8 * fg;
-                const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            }
-            w3f[ct] = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        }
+        const int ch = tid;        // 256 threads: one W3 row each
+        const float* wr = w3 + ch * 16;
+        const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4), c = *reinterpret_cast<const float4*>(wr + 8), d = *reinterpret_cast<const float4*>(wr + 12);
+        *reinterpret_cast<uint4*>(smem + CF::LDS + ch * 32) = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+        *reinterpret_cast<uint4*>(smem + CF::LDS + ch * 32 + 16) = make_uint4(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w), pack_bf16(d.x, d.y), pack_bf16(d.z, d.w));
+        __syncthreads();
     }
     f32x4 eb[4];
     u32x4 hb;
+    // 5 loads per tile through inline asm, waited for by hand in build_write (counted: the younger PEQ piece and output stores stay in flight)
     auto load_regs = [&](int t) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) eb[ct] = *reinterpret_cast<const f32x4*>(Ep + (int64_t)t * I2T_ROWS * DC + 16 * ct);
-        hb = *reinterpret_cast<const u32x4*>(Hp + (int64_t)t * I2T_ROWS * 16);
+        const float* ea = Ep + (int64_t)t * 16 * 256;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\tglobal_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
+                     : "=&v"(eb[0]), "=&v"(eb[1]), "=&v"(eb[2]), "=&v"(eb[3]) : "v"(ea) : "memory");
+        const bf16_t* ha = Hp + (int64_t)t * I2T_ROWS * 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(hb) : "v"(ha) : "memory");
     };
     bf16_t* Xo = Xout + ((int64_t)p * 4096 + row0) * DC;
 
@@ -674,9 +685,15 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
 
     // BUILD: X0 tile t from the registers load_regs(t) filled: a[r] = X0[row fi][channel 64 qr + 16 ct + 4 fg + r], written where the wave
     // reads its residual back (roff)
-    auto build_write = [&](int t) {
+    auto build_write = [&](int t, int younger) {
         const uint32_t sx = smem_a + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+        // `younger` = this wave's vector-memory operations issued after the tile's loads that may stay in flight
+#define I2T_WAITR(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(eb[0]), "+v"(eb[1]), "+v"(eb[2]), "+v"(eb[3]), "+v"(hb) :: "memory")
+        if (younger >= 3) I2T_WAITR(3); else if (younger == 2) I2T_WAITR(2); else if (younger == 1) I2T_WAITR(1); else I2T_WAITR(0);
         const bf16x8 hf = __builtin_bit_cast(bf16x8, fg < 2 ? hb : (u32x4){0u, 0u, 0u, 0u});
+        bf16x8 w3f[4];
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w3f[0]), "=&v"(w3f[1]), "=&v"(w3f[2]), "=&v"(w3f[3]) : "v"(w3_a) : "memory");
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ct], hf, eb[ct], 0, 0, 0);
@@ -685,8 +702,8 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
     };
     issue(0); issue(1); issue(2);
     if (BUILD) {
-        load_regs(0); build_write(0);
-        if (NT > 1) { load_regs(1); build_write(1); }
+        load_regs(0); build_write(0, 0);
+        if (NT > 1) { load_regs(1); build_write(1, 0); }
         if (NT > 2) load_regs(2);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     } else
@@ -740,7 +757,9 @@ __global__ __launch_bounds__(256 * RT) void dec_i2t_kernel(const bf16_t* __restr
         I2T_STAMP(2);
         if (t + 3 < NT) issue(t + 3);
         if (BUILD) {
-            if (t + 2 < NT) build_write(t + 2);
+            // behind the loads of tile t+2 (issued in iteration t-1, in the prologue for t = 0) this wave has issued: the 2 output stores of
+            // iteration t-1 (t >= 2) and this iteration's PEQ piece (t + 3 < NT)
+            if (t + 2 < NT) build_write(t + 2, (t >= 2 ? 2 : 0) + (t + 3 < NT ? 1 : 0));
             if (t + 3 < NT) load_regs(t + 3);
         }
         I2T_STAMP(3);
@@ -802,7 +821,7 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
         if (!build->embb || !build->h2 || !build->w3 || build->map.div <= 0) return "dec_i2t: incomplete XBuild";
         int ns = 1;
         while (P * ns < 512 && ns < 8) ns *= 2;
-        hipLaunchKernelGGL((dec_i2t_kernel<1, false, true>), dim3(P * ns), dim3(256), I2TCfg<1>::LDS, s, (const bf16_t*)nullptr, build->map.stride, build->map.div, build->map.off, peq, Kt, tk,
+        hipLaunchKernelGGL((dec_i2t_kernel<1, false, true>), dim3(P * ns), dim3(256), I2TCfg<1>::LDS + I2TCfg<1>::W3_B, s, (const bf16_t*)nullptr, build->map.stride, build->map.div, build->map.off, peq, Kt, tk,
                            kscale, cb, VtT, bo, gamma, beta, eps, Xout, ns, 0, (unsigned long long*)nullptr, build->embb, build->h2, build->w3);
         return nullptr;
     }
@@ -1032,7 +1051,7 @@ const char* decoder_fused_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2ICfg<8>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
-    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS + I2TCfg<1>::W3_B);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);

@@ -292,6 +292,18 @@ const char* launch_mask_hidden(const float* mask_in, int P, MaskEmbedWeights w, 
     return nullptr;
 }
 
+__global__ __launch_bounds__(256) void embb_tiles_kernel(const float* __restrict__ emb, const float* __restrict__ b3, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // one float4 of the output: (row tile, channel tile, lane)
+    const int lane = idx & 63, ct = (idx >> 6) & 15, rt = idx >> 10;
+    const int row = 16 * rt + (lane & 15), ch = 16 * ct + 4 * (lane >> 4);
+    const float4 e = *reinterpret_cast<const float4*>(emb + (int64_t)row * 256 + ch), b = *reinterpret_cast<const float4*>(b3 + ch);
+    *reinterpret_cast<float4*>(out + (int64_t)idx * 4) = make_float4(e.x + b.x, e.y + b.y, e.z + b.z, e.w + b.w);
+}
+const char* launch_embb_tiles(const float* emb, const float* b3, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(embb_tiles_kernel, dim3(4096 * 256 / 4 / 256), dim3(256), 0, s, emb, b3, out);
+    return nullptr;
+}
+
 const char* launch_mask_embed_src(const float* mask_in, int P, const float* image_embed, XMap em, const float* pos, MaskEmbedWeights w,
                                   float* src_f, bf16_t* src_bf, bf16_t* srcpos_bf, float clamp_abs, hipStream_t s, int raw4_q0) {
     if (P <= 0) return nullptr;

@@ -1014,7 +1014,7 @@ static int ensure_embb(saber_engine* e, int slot, hipStream_t s) {
     if (e->slot_embb_valid[slot]) return SABER_OK;
     const size_t o256 = (size_t)slot * 4096 * 256;
     // image_embed + b3 (fp32): what mask_embed_src_kernel adds before its MFMA; the layer-0 kernels load it as their tiles' C operand
-    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->emb + o256, e->mw.b3, 1, nullptr, e->embb + o256, 4096, 256, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_embb_tiles(e->emb + o256, e->mw.b3, e->embb + o256, s));
     e->slot_embb_valid[slot] = 1;
     return SABER_OK;
 }
@@ -1051,7 +1051,11 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     XMap xm;
     XBuild xb;
     const XBuild* build = nullptr;          // layer 0 of a mask-prompted decode: X0 tiles assembled in the kernels
-    const bool no_build = getenv("SABER_AMD_NO_XBUILD") != nullptr;      // development A/B switch (read per call): materialise src with mask_embed_src_kernel
+    // Opt-in experiment (round 3, SABER_AMD_XBUILD=1, read per call): assemble the m2m prompts' src inside layer 0's dec_t2i / dec_i2t instead
+    // of materialising it.  Bit-identical and 55 GB per slice less HBM traffic, but SLOWER on this memory system: the fp32 image_embed
+    // tiles (4 MB per prompt and pass, from the Infinity Cache) cost more than the 2 MB of bf16 src from HBM they replace, and with two
+    // slices in flight they evict the encoder's working set from that cache (same-box A/B: 156.7 vs 144.3 ms per slice).  DESIGN.md section 4.
+    const bool no_build = getenv("SABER_AMD_XBUILD") == nullptr;
     if (shared) {
         for (int sl = slot0 + p_base / per_slot; sl <= slot_last; ++sl) TRY(ensure_shared(e, sl, s));
         X = e->src0_bf + o256; xm = slots;

@@ -107,9 +107,12 @@ const char* launch_mask_embed_src(const float* mask_in, int P, const float* imag
 // channels + image_embed ("src") is assembled tile by tile inside the layer-0 kernels of the two-way transformer (XBuild below) and never
 // reaches HBM: 32 B per token instead of 512 B written once and read twice.
 const char* launch_mask_hidden(const float* mask_in, int P, MaskEmbedWeights w, bf16_t* h2, float clamp_abs, hipStream_t s, int raw4_q0 = -1);
-// How a layer-0 kernel assembles X0 = bf16(image_embed + b3 + h2 . W3^T) for prompt p: embb = image_embed + b3 (fp32 [slots][4096][256],
-// engine token order) of slot (p + map.off) / map.div; h2 as above; w3 = mask_downscaling.6.weight fp32 [256][16].  Same arithmetic as
+// How a layer-0 kernel assembles X0 = bf16(image_embed + b3 + h2 . W3^T) for prompt p: embb = image_embed + b3 (fp32 [slots][4096 x 256] in the
+// order of launch_embb_tiles) of slot (p + map.off) / map.div; h2 as above; w3 = mask_downscaling.6.weight fp32 [256][16].  Same arithmetic as
 // mask_embed_src_kernel<true> (one K = 16 MFMA per 16 x 16 block with the fp32 image_embed + b3 as its C operand): bit-identical tiles.
+// embb in the tile builders' order: out[(row / 16) * 16 + ch / 16][lane = (ch % 16 / 4) * 16 + row % 16][ch % 4] = emb[row][ch] + b3[ch]
+// (one KB per (16-row tile, 16-channel tile): the C operand of one MFMA of the builders, read by one load instruction)
+const char* launch_embb_tiles(const float* emb, const float* b3, float* out, hipStream_t s);
 struct XBuild { const float* embb = nullptr; XMap map{0, 1, 0}; const bf16_t* h2 = nullptr; const float* w3 = nullptr; };
 
 // fp32 multi-head attention for the two-way transformer.  q [B][nq][heads*hd], k/v [B or 1][nk][heads*hd].

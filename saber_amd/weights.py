@@ -210,7 +210,7 @@ def seeded_weights(cfg: HieraConfig, seed: int = 0, video: bool = False) -> Dict
     return OrderedDict((n, _gen(n, s, k, g, seed)) for n, (s, k, g) in specs.items())
 
 
-def stress_weights(cfg: HieraConfig, seed: int = 0, gamma_outlier: float = 30.0, massive: float = 60.0) -> Dict[str, np.ndarray]:
+def stress_weights(cfg: HieraConfig, seed: int = 0, gamma_outlier: float = 30.0, massive: float = 200.0) -> Dict[str, np.ndarray]:
     """seeded_weights with the activation statistics trained ViT checkpoints are known for and random initialisation lacks (no real
     SAM2.1 checkpoint can be fetched offline): (a) outlier LayerNorm gains - two channels of every norm1 / norm2
     scaled by `gamma_outlier`, so two input columns of each qkv / fc1 GEMM carry values ~30x the rest; (b) two "massive" residual

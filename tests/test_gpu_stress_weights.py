@@ -33,7 +33,7 @@ def test_precision_modes_on_stress_weights():
     top = absx.max(0).values.topk(4).values
     print("stress weights: |x| of the four largest residual channels at the end of stage 2:", [round(float(v), 1) for v in top],
           "median channel max:", round(float(absx.max(0).values.median()), 2))
-    assert float(top[1]) > 20 * float(absx.max(0).values.median())          # the massive channels did form
+    assert float(top[1]) > 8 * float(absx.max(0).values.median())          # the massive channels did form
     t = torch.from_numpy(img).cuda()
     eng = Engine("large", device=0, weights=Wnp, max_images=1, max_prompts=16, precision="exact")
     eng8 = Engine("large", device=0, weights=Wnp, max_images=1, max_prompts=16, weight_format="fp8")
