@@ -185,6 +185,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();
         if (!m) m = decoder_fused_init_device();
+        if (!m) m = decoder_tokens_init_device();
         (void)hipGetLastError();
         if (m) { delete e; return eng_fail(nullptr, SABER_ERR_HIP, std::string("kernel attribute setup: ") + m); }
     }
@@ -316,12 +317,22 @@ struct Finalizer {
         l.g = up_f32(g->data); l.b = up_f32(b->data);
         return l;
     }
-    AttnW attn(const std::string& prefix, int internal) {
+    // image_side: "k" (tokens -> image attentions) or "q" (image -> tokens): that projection's weight is also kept transposed
+    AttnW attn(const std::string& prefix, int internal, const char* image_side = nullptr) {
         AttnW a;
         a.q = lin(prefix + ".q_proj", internal, 256);
         a.k = lin(prefix + ".k_proj", internal, 256);
         a.v = lin(prefix + ".v_proj", internal, 256);
         a.o = lin(prefix + ".out_proj", 256, internal);
+        if (image_side && internal == 128) {
+            const HostTensor* w = get(prefix + "." + image_side + "_proj.weight", {internal, 256});
+            if (w) {
+                std::vector<float> t((size_t)256 * 128);
+                for (int r = 0; r < 128; ++r)
+                    for (int c = 0; c < 256; ++c) t[(size_t)c * 128 + r] = w->data[(size_t)r * 256 + c];
+                a.img_wT = up_bf16(t);
+            }
+        }
         return a;
     }
 };
@@ -512,15 +523,15 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
             DecLayerW& w = e->dl[l];
             w.self_attn = F.attn(L + "self_attn", 256);
             w.n1 = F.ln(L + "norm1", 256);
-            w.t2i = F.attn(L + "cross_attn_token_to_image", 128);
+            w.t2i = F.attn(L + "cross_attn_token_to_image", 128, "k");
             w.n2 = F.ln(L + "norm2", 256);
             w.mlp1 = F.lin(L + "mlp.layers.0", 2048, 256);
             w.mlp2 = F.lin(L + "mlp.layers.1", 256, 2048);
             w.n3 = F.ln(L + "norm3", 256);
             w.n4 = F.ln(L + "norm4", 256);
-            w.i2t = F.attn(L + "cross_attn_image_to_token", 128);
+            w.i2t = F.attn(L + "cross_attn_image_to_token", 128, "q");
         }
-        e->final_attn = F.attn(d + "transformer.final_attn_token_to_image", 128);
+        e->final_attn = F.attn(d + "transformer.final_attn_token_to_image", 128, "k");
         e->final_ln = F.ln(d + "transformer.norm_final_attn", 256);
         // ConvTranspose2d(k2,s2) as a GEMM: N index = (ky*2+kx)*Cout + co
         auto convT = [&](const std::string& prefix, int cin, int cout, LinW* out) {
@@ -1072,6 +1083,57 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         X = nullptr; xm = per_prompt;
     }
 
+    static const bool no_tokfuse = getenv("SABER_AMD_NO_TOKFUSE") != nullptr;      // development A/B switch: the ~58 separate token-side launches
+    if (!no_tokfuse) {
+        // token side as four fused segments (decoder_tokens.hip) around the five image-side kernels
+        auto lin = [](const LinW& l) { TokLin t; t.w = l.w; t.b = l.b; t.ldw = l.ldw; t.n = l.out; return t; };
+        auto lnw = [](const LnW& l) { TokLn t; t.g = l.g; t.b = l.b; return t; };
+        auto base = [&]() { TokSeg g; g.P = P; g.queries = e->queries; g.tok_pe = e->tok_pe; g.kscale = kScale; return g; };
+        auto with_t2i = [&](TokSeg& g, const AttnW& a) { g.do_t2i = 1; g.t2i_q = lin(a.q); g.t2i_kT = a.img_wT; g.tq_out = e->tq; g.fold_q = e->fold_q; };
+        auto with_self = [&](TokSeg& g, const DecLayerW& w, int first) {
+            g.do_self = 1; g.self_first = first; g.sa_q = lin(w.self_attn.q); g.sa_k = lin(w.self_attn.k); g.sa_v = lin(w.self_attn.v); g.sa_o = lin(w.self_attn.o); g.ln1 = lnw(w.n1);
+        };
+        auto with_att_out = [&](TokSeg& g, const AttnW& a, const LnW& ln) { g.t_att = e->t_att; g.att_o = lin(a.o); g.att_ln = lnw(ln); g.att_eps = 1e-5f; };
+        auto with_mlp_i2t = [&](TokSeg& g, const DecLayerW& w) {
+            g.do_mlp = 1; g.mlp1 = lin(w.mlp1); g.mlp2 = lin(w.mlp2); g.ln3 = lnw(w.n3);
+            g.i2t_k = lin(w.i2t.k); g.i2t_v = lin(w.i2t.v); g.i2t_qT = w.i2t.img_wT; g.i2t_qb = w.i2t.q.b; g.i2t_o = w.i2t.o.w;
+            g.tk_out = e->tk; g.fold_k = e->fold_k; g.fold_cb = e->fold_cb; g.fold_v = e->fold_v;
+        };
+        const double tflops = 2.0 * PT * 256.0;     // per 256 x 1 column of weights
+        auto run_t2i = [&](const AttnW& a) -> int {
+            ENG_KP(e, PC_DEC_T2I, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 2, launch_dec_t2i(X, xm, a.pe_proj, e->fold_q, e->tq, kScale, e->t2i_part, e->t2i_ml, P, split, a.v.w, a.v.b, e->t_att, s, build));
+            return SABER_OK;
+        };
+        auto run_i2t = [&](const DecLayerW& w) -> int {
+            ENG_KP(e, PC_DEC_I2T, 4.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4, launch_dec_i2t(X, xm, w.i2t.pe_proj, e->fold_k, e->tk, kScale, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P, s, build));
+            X = e->keys_bf; xm = per_prompt; build = nullptr;
+            return SABER_OK;
+        };
+        {   // S0: self attention of layer 0, operands of its tokens -> image attention
+            TokSeg g = base(); with_self(g, e->dl[0], 1); with_t2i(g, e->dl[0].t2i);
+            ENG_KP(e, PC_DEC_ATTN, tflops * (4 * 256 + 128 + 128), 0.0, launch_dec_tokens(g, s));
+        }
+        TRY(run_t2i(e->dl[0].t2i));
+        {   // S1: rest of layer 0 on the token side, self attention of layer 1, operands of its tokens -> image attention
+            TokSeg g = base(); with_att_out(g, e->dl[0].t2i, e->dl[0].n2); with_mlp_i2t(g, e->dl[0]); with_self(g, e->dl[1], 0); with_t2i(g, e->dl[1].t2i);
+            ENG_KP(e, PC_DEC_ATTN, tflops * (128 + 4096 + 4 * 128 + 4 * 256 + 256), 0.0, launch_dec_tokens(g, s));
+        }
+        TRY(run_i2t(e->dl[0]));
+        TRY(run_t2i(e->dl[1].t2i));
+        {   // S2: rest of layer 1, operands of the final tokens -> image attention
+            TokSeg g = base(); with_att_out(g, e->dl[1].t2i, e->dl[1].n2); with_mlp_i2t(g, e->dl[1]); with_t2i(g, e->final_attn);
+            ENG_KP(e, PC_DEC_ATTN, tflops * (128 + 4096 + 4 * 128 + 256), 0.0, launch_dec_tokens(g, s));
+        }
+        TRY(run_i2t(e->dl[1]));
+        TRY(run_t2i(e->final_attn));
+        {   // S3: final output projection + LayerNorm, IoU / object-score / hypernetwork heads
+            TokSeg g = base(); with_att_out(g, e->final_attn, e->final_ln);
+            g.do_heads = 1;
+            for (int l = 0; l < 3; ++l) { g.iou[l] = lin(e->iou_head[l]); g.obj[l] = lin(e->obj_head[l]); g.hyper[l] = lin(e->hyper[l]); }
+            g.iou4 = e->iou4; g.obj_out = out_obj; g.hyper_out = e->hyper_out;
+            ENG_KP(e, PC_DEC_ATTN, tflops * (128 + 6 * 512.0 / 8), 0.0, launch_dec_tokens(g, s));
+        }
+    } else {
     // tokens -> image: fold q into 64 rows of dimension 256, stream X once (dec_t2i), un-fold with v_proj
     auto t2i = [&](const AttnW& a, const LnW& ln) -> int {
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_add_to_bf16(e->queries, e->tok_pe, PT, e->t_bf0, nullptr, PT, 256, s));
@@ -1145,6 +1207,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         g.Cf = e->hyper_out; g.ldcf = 128; g.strideCf = 32;
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, gemm_bytes(g), launch_gemm(g, s));
     }
+    }   // (separate token-side launches)
     // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
            launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot0 * 16384 * 64,

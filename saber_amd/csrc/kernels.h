@@ -140,6 +140,36 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
                                hipStream_t s);
 const char* decoder_fused_init_device();
 
+// ------------------------------------------------------------------ decoder_tokens.hip
+// One segment of the token side of the two-way transformer (everything between two image-side kernels) as one launch; see the file header.
+struct TokLin { const bf16_t* w = nullptr; const float* b = nullptr; int ldw = 0; int n = 0; };
+struct TokLn { const float* g = nullptr; const float* b = nullptr; };
+struct TokSeg {
+    int P = 0;
+    float* queries = nullptr; const float* tok_pe = nullptr;
+    float kscale = 0.f;
+    // (1) queries = LN(queries + o_proj(t_att))                         [after a tokens -> image attention]
+    const bf16_t* t_att = nullptr; TokLin att_o; TokLn att_ln; float att_eps = 1e-5f;
+    // (2) queries = LN3(queries + mlp(queries)); image -> tokens operands of this layer
+    int do_mlp = 0;
+    TokLin mlp1, mlp2; TokLn ln3;
+    TokLin i2t_k, i2t_v; const bf16_t* i2t_qT = nullptr; const float* i2t_qb = nullptr; const bf16_t* i2t_o = nullptr;
+    float* tk_out = nullptr; bf16_t* fold_k = nullptr; float* fold_cb = nullptr; bf16_t* fold_v = nullptr;
+    // (3) self attention of the tokens + LN1
+    int do_self = 0, self_first = 0;
+    TokLin sa_q, sa_k, sa_v, sa_o; TokLn ln1;
+    // (4) operands of the next tokens -> image attention
+    int do_t2i = 0;
+    TokLin t2i_q; const bf16_t* t2i_kT = nullptr; float* tq_out = nullptr; bf16_t* fold_q = nullptr;
+    // (5) heads: IoU, object score, hypernetwork MLPs
+    int do_heads = 0;
+    TokLin iou[3], obj[3], hyper[3];
+    float* iou4 = nullptr; float* obj_out = nullptr; float* hyper_out = nullptr;
+};
+
+const char* launch_dec_tokens(const TokSeg& s, hipStream_t st);
+const char* decoder_tokens_init_device();
+
 // K8: bilinear upsample of 256x256 logits to the crop, threshold / stability counts / bbox / bit-packing.
 struct MaskStats { int area; int inter; int uni; int x0; int y0; int x1; int y1; int pad; };
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
