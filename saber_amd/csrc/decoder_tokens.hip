@@ -4,7 +4,7 @@
 // projection + residual + LayerNorm, the 256 -> 2048 -> 256 MLP, the k / v projections and folds that prepare the next image-side kernel,
 // the 8 x 8 self attention of the next layer, the q projection and fold of the next tokens -> image attention.  As separate launches that
 // was ~58 kernels of 5-25 us per decoder batch (M = 8 192 rows at most: launch-to-drain latency, not work): 7-8 ms per slice.  Here a
-// workgroup owns FOUR prompts (32 token rows) and walks the whole chain with the rows resident in LDS; weights stream from L2 straight
+// workgroup (8 waves) owns FOUR prompts (32 token rows) and walks the whole chain with the rows resident in LDS; weights stream from L2 straight
 // into MFMA operand registers (every workgroup reads every weight once: ~3 MB per workgroup and segment).
 //
 // Arithmetic as in the separate kernels: bf16 MFMA operands (activations rounded where they were rounded before), fp32 accumulation, fp32
@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #define TK_G 4                 // prompts per workgroup
+#define TK_T 512               // threads per workgroup: 8 waves, two output tiles of 16 columns each per 256-wide projection
 #define TK_R (8 * TK_G)        // token rows per workgroup
 #define TK_AS 528              // bytes per row of a bf16 operand buffer (256 + 8 elements: 16 rows x 16 B hit disjoint banks)
 #define TK_FS 132              // floats per row of an fp32 scratch buffer (128 + 4)
@@ -30,7 +31,7 @@ __device__ __forceinline__ void wgemm(const TokCtx& c, const char* A, int K, con
     const bf16_t* wr[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) wr[i] = W + (int64_t)min(n0 + 16 * (c.wave * NTW + i) + c.fi, nrows - 1) * ldw + 8 * c.fg;
-#pragma unroll 2
+#pragma unroll 8
     for (int ks = 0; ks < K / 32; ++ks) {
         bf16x8 b[MT];
 #pragma unroll
@@ -46,7 +47,7 @@ __device__ __forceinline__ void wgemm(const TokCtx& c, const char* A, int K, con
 
 // B = bf16(Q + (pe ? tok_pe : 0)) for the workgroup's 32 rows
 __device__ __forceinline__ void to_operand(const TokCtx& c, char* B, const float* pe_rows /* global, this workgroup's first row, or null */, int rows_valid) {
-    for (int idx = c.tid; idx < TK_R * 64; idx += 256) {
+    for (int idx = c.tid; idx < TK_R * 64; idx += TK_T) {
         const int r = idx >> 6, c4 = (idx & 63) * 4;
         float4 v = *reinterpret_cast<const float4*>(c.Q + (r * 256 + c4) * 4);
         if (pe_rows && r < rows_valid) {
@@ -56,10 +57,10 @@ __device__ __forceinline__ void to_operand(const TokCtx& c, char* B, const float
         *reinterpret_cast<uint2*>(B + r * TK_AS + c4 * 2) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
     }
 }
-// Q[row] = LN(Q[row]) for the workgroup's 32 rows (wave w: rows 8 w .. 8 w + 7; a lane holds 4 channels)
+// Q[row] = LN(Q[row]) for the workgroup's 32 rows (wave w: rows 4 w .. 4 w + 3; a lane holds 4 channels)
 __device__ __forceinline__ void ln_rows(const TokCtx& c, TokLn ln, float eps) {
     const float4 g = *reinterpret_cast<const float4*>(ln.g + 4 * c.lane), b = *reinterpret_cast<const float4*>(ln.b + 4 * c.lane);
-    for (int r = 8 * c.wave; r < 8 * c.wave + 8; ++r) {
+    for (int r = 4 * c.wave; r < 4 * c.wave + 4; ++r) {
         float4* q = reinterpret_cast<float4*>(c.Q + (r * 256 + 4 * c.lane) * 4);
         const float4 v = *q;
         const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
@@ -70,11 +71,11 @@ __device__ __forceinline__ void ln_rows(const TokCtx& c, TokLn ln, float eps) {
 }
 // Q (+)= A . W^T + bias for N = 256 (residual: add to Q, else overwrite)
 __device__ __forceinline__ void proj_to_q(const TokCtx& c, const char* A, int K, TokLin L, bool residual) {
-    f32x4 acc[4][2];
-    wgemm<4, 2>(c, A, K, L.w, L.ldw, 0, 256, acc);
+    f32x4 acc[2][2];
+    wgemm<2, 2>(c, A, K, L.w, L.ldw, 0, 256, acc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = 16 * (c.wave * 4 + i) + 4 * c.fg;
+    for (int i = 0; i < 2; ++i) {
+        const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
         const float4 b = *reinterpret_cast<const float4*>(L.b + n);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -87,11 +88,11 @@ __device__ __forceinline__ void proj_to_q(const TokCtx& c, const char* A, int K,
 }
 // F[row][0..127] = A . W[n0 .. n0+127]^T + bias (fp32 scratch, 128 columns)
 __device__ __forceinline__ void proj_to_f(const TokCtx& c, const char* A, int K, TokLin L, int n0, char* F) {
-    f32x4 acc[2][2];
-    wgemm<2, 2>(c, A, K, L.w, L.ldw, n0, L.n, acc);
+    f32x4 acc[1][2];
+    wgemm<1, 2>(c, A, K, L.w, L.ldw, n0, L.n, acc);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
+    for (int i = 0; i < 1; ++i) {
+        const int n = 16 * (c.wave + i) + 4 * c.fg;
         const float4 b = *reinterpret_cast<const float4*>(L.b + n0 + n);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -124,8 +125,8 @@ __device__ __forceinline__ void fold_rows(const TokCtx& c, const char* F, const 
             bf16x8 hi, lo;
             fold_operand(c, F, pi, hp, scale, &hi, &lo);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int dt = c.wave * 4 + i;
+            for (int i = 0; i < 2; ++i) {
+                const int dt = c.wave * 2 + i;
                 const bf16x8 w = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(WT + (16 * dt + c.fi) * 128 + 32 * hp + 8 * c.fg));
                 f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hi, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, lo, acc, 0, 0, 0);
@@ -144,8 +145,8 @@ __device__ __forceinline__ void fold_cols(const TokCtx& c, const char* F, const 
             bf16x8 hi, lo;
             fold_operand(c, F, pi, hp, 1.0f, &hi, &lo);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int dt = c.wave * 4 + i;
+            for (int i = 0; i < 2; ++i) {
+                const int dt = c.wave * 2 + i;
                 const bf16x8 w = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W + (int64_t)(16 * dt + c.fi) * ldw + 32 * hp + 8 * c.fg));
                 f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, w, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, w, acc, 0, 0, 0);
@@ -157,7 +158,7 @@ __device__ __forceinline__ void fold_cols(const TokCtx& c, const char* F, const 
     }
 }
 
-__global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
+__global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TokCtx c;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.fi = c.lane & 15; c.fg = c.lane >> 4;
@@ -168,13 +169,13 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
     const int64_t row0 = (int64_t)p0 * 8;
     const float* pe = s.tok_pe + row0 * 256;
     // residual stream of the workgroup's tokens
-    for (int idx = c.tid; idx < TK_R * 64; idx += 256) {
+    for (int idx = c.tid; idx < TK_R * 64; idx += TK_T) {
         const int r = idx >> 6, c4 = (idx & 63) * 4;
         *reinterpret_cast<float4*>(c.Q + (r * 256 + c4) * 4) = r < rows ? *reinterpret_cast<const float4*>(s.queries + (row0 + r) * 256 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // ---------------- (1) output projection of the tokens -> image attention that has just run
     if (s.t_att) {
-        for (int idx = c.tid; idx < TK_R * 16; idx += 256) {
+        for (int idx = c.tid; idx < TK_R * 16; idx += TK_T) {
             const int r = idx >> 4, c8 = (idx & 15) * 8;
             *reinterpret_cast<uint4*>(c.B1 + r * TK_AS + c8 * 2) = r < rows ? *reinterpret_cast<const uint4*>(s.t_att + (row0 + r) * 128 + c8) : make_uint4(0u, 0u, 0u, 0u);
         }
@@ -188,17 +189,17 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
     if (s.do_mlp) {
         to_operand(c, c.B0, nullptr, rows);
         __syncthreads();
-        f32x4 acc2[4][2];
+        f32x4 acc2[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc2[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int ch = 0; ch < 8; ++ch) {            // hidden columns 256 ch .. 256 ch + 255
-            f32x4 acc[4][2];
-            wgemm<4, 2>(c, c.B0, 256, s.mlp1.w, s.mlp1.ldw, 256 * ch, 2048, acc);
+            f32x4 acc[2][2];
+            wgemm<2, 2>(c, c.B0, 256, s.mlp1.w, s.mlp1.ldw, 256 * ch, 2048, acc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = 16 * (c.wave * 4 + i) + 4 * c.fg;
+            for (int i = 0; i < 2; ++i) {
+                const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
                 const float4 b = *reinterpret_cast<const float4*>(s.mlp1.b + 256 * ch + n);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -206,17 +207,17 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
                         make_uint2(pack_bf16(fmaxf(acc[i][m][0] + b.x, 0.f), fmaxf(acc[i][m][1] + b.y, 0.f)), pack_bf16(fmaxf(acc[i][m][2] + b.z, 0.f), fmaxf(acc[i][m][3] + b.w, 0.f)));
             }
             __syncthreads();
-            f32x4 part[4][2];
-            wgemm<4, 2>(c, c.H, 256, s.mlp2.w + 256 * ch, s.mlp2.ldw, 0, 256, part);
+            f32x4 part[2][2];
+            wgemm<2, 2>(c, c.H, 256, s.mlp2.w + 256 * ch, s.mlp2.ldw, 0, 256, part);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc2[i][m] += part[i][m];
             __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = 16 * (c.wave * 4 + i) + 4 * c.fg;
+        for (int i = 0; i < 2; ++i) {
+            const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
             const float4 b = *reinterpret_cast<const float4*>(s.mlp2.b + n);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
         proj_to_f(c, c.B0, 256, s.i2t_k, 0, c.F0);
         proj_to_f(c, c.B1, 256, s.i2t_v, 0, c.F1);
         __syncthreads();
-        for (int idx = c.tid; idx < rows * 32; idx += 256) {
+        for (int idx = c.tid; idx < rows * 32; idx += TK_T) {
             const int r = idx >> 5, c4 = (idx & 31) * 4;
             *reinterpret_cast<float4*>(s.tk_out + (row0 + r) * 128 + c4) = *reinterpret_cast<const float4*>(c.F0 + (r * TK_FS + c4) * 4);
         }
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
         __syncthreads();
         proj_to_f(c, c.B0, 256, s.t2i_q, 0, c.F0);
         __syncthreads();
-        for (int idx = c.tid; idx < rows * 32; idx += 256) {
+        for (int idx = c.tid; idx < rows * 32; idx += TK_T) {
             const int r = idx >> 5, c4 = (idx & 31) * 4;
             *reinterpret_cast<float4*>(s.tq_out + (row0 + r) * 128 + c4) = *reinterpret_cast<const float4*>(c.F0 + (r * TK_FS + c4) * 4);
         }
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
     }
     // the residual stream goes back (the next segment, or saber_get_decoder_tokens, reads it)
     __syncthreads();
-    for (int idx = c.tid; idx < rows * 64; idx += 256) {
+    for (int idx = c.tid; idx < rows * 64; idx += TK_T) {
         const int r = idx >> 6, c4 = (idx & 63) * 4;
         *reinterpret_cast<float4*>(s.queries + (row0 + r) * 256 + c4) = *reinterpret_cast<const float4*>(c.Q + (r * 256 + c4) * 4);
     }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
     if (s.do_heads) {
         // three-layer MLP on ONE token per prompt: rows 0..3 of a 16-row operand tile (the other rows are zero)
         auto mlp3 = [&](const TokLin* L, int64_t w_off0, int64_t w_off2, int b_off0, int b_off2, int token, int n_out, int sigmoid, float* out, int ldo, int o_off) {
-            for (int idx = c.tid; idx < 16 * 64; idx += 256) {
+            for (int idx = c.tid; idx < 16 * 64; idx += TK_T) {
                 const int r = idx >> 6, c4 = (idx & 63) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < np) v = *reinterpret_cast<const float4*>(c.Q + ((8 * r + token) * 256 + c4) * 4);
@@ -337,11 +338,11 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
             for (int l = 0; l < 2; ++l) {
                 const char* in = l == 0 ? c.B0 : c.B1;
                 char* outb = l == 0 ? c.B1 : c.H;
-                f32x4 acc[4][1];
-                wgemm<4, 1>(c, in, 256, L[l].w + w_off0, L[l].ldw, 0, 256, acc);
+                f32x4 acc[2][1];
+                wgemm<2, 1>(c, in, 256, L[l].w + w_off0, L[l].ldw, 0, 256, acc);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = 16 * (c.wave * 4 + i) + 4 * c.fg;
+                for (int i = 0; i < 2; ++i) {
+                    const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
                     const float4 b = *reinterpret_cast<const float4*>(L[l].b + b_off0 + n);
                     *reinterpret_cast<uint2*>(outb + c.fi * TK_AS + n * 2) =
                         make_uint2(pack_bf16(fmaxf(acc[i][0][0] + b.x, 0.f), fmaxf(acc[i][0][1] + b.y, 0.f)), pack_bf16(fmaxf(acc[i][0][2] + b.z, 0.f), fmaxf(acc[i][0][3] + b.w, 0.f)));
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void dec_tokens_kernel(TokSeg s) {
 #define TK_LDS (TK_R * 256 * 4 + 3 * TK_R * TK_AS + 3 * TK_R * TK_FS * 4)
 const char* launch_dec_tokens(const TokSeg& s, hipStream_t st) {
     if (s.P <= 0) return nullptr;
-    hipLaunchKernelGGL(dec_tokens_kernel, dim3((s.P + TK_G - 1) / TK_G), dim3(256), TK_LDS, st, s);
+    hipLaunchKernelGGL(dec_tokens_kernel, dim3((s.P + TK_G - 1) / TK_G), dim3(TK_T), TK_LDS, st, s);
     return nullptr;
 }
 const char* decoder_tokens_init_device() {

@@ -25,6 +25,9 @@ _MIN_BUFFER = 128                # c-blosc stores buffers below this size uncomp
 _BLOCK = 256 << 10
 
 
+_WARNED = False
+
+
 def _zstd():
     try:
         import pyarrow as pa
@@ -33,6 +36,29 @@ def _zstd():
     except ImportError:
         pass
     return None
+
+
+def zstd_backend() -> str:
+    """Which compressor the chunks written by this process use: 'numcodecs' (the reference's own codec), 'pyarrow' (c-blosc-1 frames
+    built here around pyarrow's libzstd) or 'none' (valid but UNCOMPRESSED `memcpyed` Blosc frames: any Blosc reader opens them, the
+    store is just larger).  SABER_AMD_REQUIRE_ZSTD=1 turns the last case into an ImportError instead of a warning."""
+    try:
+        import numcodecs  # noqa: F401
+        return "numcodecs"
+    except ImportError:
+        return "pyarrow" if _zstd() is not None else "none"
+
+
+def _no_zstd():
+    global _WARNED
+    if os.environ.get("SABER_AMD_REQUIRE_ZSTD", "0") not in ("", "0"):
+        raise ImportError("saber_amd.utils.zarr_v2: no zstd compressor is importable (numcodecs, or pyarrow with zstd); "
+                          "install one, or unset SABER_AMD_REQUIRE_ZSTD to write uncompressed Blosc frames")
+    if not _WARNED:
+        import warnings
+        warnings.warn("saber_amd.utils.zarr_v2: neither numcodecs nor pyarrow(zstd) is importable - chunks are written as valid but "
+                      "UNCOMPRESSED Blosc frames", RuntimeWarning, stacklevel=3)
+        _WARNED = True
 
 
 class BloscZstd:
@@ -82,6 +108,8 @@ class BloscZstd:
         def memcpyed():
             return struct.pack("<BBBBIII", _BLOSC_VERSION, _ZSTD_FORMAT_VERSION, _F_MEMCPY | _F_NOSPLIT | (_ZSTD_CODE << 5), typesize, n,
                                max(n, 1), n + 16) + src.tobytes()
+        if pa is None and n >= _MIN_BUFFER:
+            _no_zstd()
         if pa is None or n < _MIN_BUFFER:
             return memcpyed()
         codec = pa.Codec("zstd", compression_level=max(1, self.clevel))

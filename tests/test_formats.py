@@ -115,6 +115,30 @@ def test_blosc_frame_layout_and_round_trip():
         codec.decode(frame[:-1])
 
 
+def test_blosc_without_any_zstd_backend(monkeypatch):
+    """No numcodecs and no pyarrow: chunks become valid uncompressed (memcpyed) Blosc frames, with ONE warning; with
+    SABER_AMD_REQUIRE_ZSTD=1 the writer refuses instead (the pyarrow-libzstd dependency is guarded)."""
+    import warnings
+    from saber_amd.utils import zarr_v2
+    codec = zarr_v2.BloscZstd()
+    if codec._nc is not None:
+        pytest.skip("numcodecs present")
+    monkeypatch.setattr(zarr_v2, "_zstd", lambda: None)
+    monkeypatch.setattr(zarr_v2, "_WARNED", False)
+    assert zarr_v2.zstd_backend() == "none"
+    a = np.arange(4096, dtype=np.uint16)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        f1, f2 = codec.encode(a), codec.encode(a)
+    assert len([x for x in w if "UNCOMPRESSED" in str(x.message)]) == 1
+    # the frame, byte for byte, from the c-blosc-1 header definition: version 2, zstd format 1, flags memcpy | nosplit | zstd << 5
+    want = struct.pack("<BBBBIII", 2, 1, 0x02 | 0x10 | (4 << 5), 2, a.nbytes, a.nbytes, a.nbytes + 16) + a.tobytes()
+    assert f1 == want and f2 == want and codec.decode(f1) == a.tobytes()
+    monkeypatch.setenv("SABER_AMD_REQUIRE_ZSTD", "1")
+    with pytest.raises(ImportError, match="no zstd compressor"):
+        codec.encode(a)
+
+
 def test_zarr_store_documents_and_round_trip(tmp_path):
     from saber_amd.utils import zarr_v2
     root = zarr_v2.open_group(str(tmp_path / "s.zarr"), mode="w")
