@@ -855,6 +855,12 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 // Phase B: [(pos w, 32 tok)] x [128 = pos2*32+ch2] over K=64, epilogue = +feat_s0, GELU, 4 dot products with hyper.
 // The 32-channel 256x256 upscaled embedding (8 MB fp32 per prompt) never exists in memory.
 #define UP_TOK 32
+// Experiment (round 3, off): the hypernetwork product on the matrix cores.  -55 static VALU instructions per prompt (7 %), 26 registers
+// fewer, the same 26 ms per slice on the same box, +4 % decoder error (u2 rounded to bf16): the kernel is not bound by the VALU work
+// of that product.  make EXTRA=-DUP_MFMA_HYPER=1 builds it.
+#ifndef UP_MFMA_HYPER
+#define UP_MFMA_HYPER 0
+#endif
 #define UP_W1S (256 * ROW_B)          // W1 [256 n][256 k] bf16, kswz
 #define UP_W2S (128 * 128)            // W2p [128 n2][64] bf16 (k-slots pre-permuted), swz128
 #define UP_LDS (UP_W1S + UP_W2S)
@@ -943,11 +949,31 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             const int slot = (p + s_off) / s_div;     // block-uniform
             if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
         }
+#if UP_MFMA_HYPER
+        // The hypernetwork product masks[k] = hyper[k] . u2 on the matrix cores (instead of 128 FMAs + a 3-step lane transpose per lane and
+        // prompt).  A operand:
+        // row fi = mask fi >> 2 (each mask's row four times), k-slot 8 fg + j = channel 4 fg + j (j < 4) | 16 + 4 fg + (j - 4): the order
+        // phase B leaves its GELU outputs in, so they are packed into the B operand as they stand.  Every row 4 fg + r of the result is
+        // mask fg of token fi: the lane reads its own mask from register 0, no lane movement.  hyper enters as a bf16 hi + lo pair (two
+        // MFMAs, exact to 2^-17); u2 is rounded to bf16 (2^-9 per element, averaged over the 32-term sum).
+        bf16x8 hy_hi, hy_lo;
+        {
+            const float* hp = hyper + (int64_t)p * 128 + (fi >> 2) * 32 + 4 * fg;
+            const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 16);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            float l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l[j] = v[j] - bf2f(f2bf(v[j]));
+            hy_hi = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            hy_lo = pack8_d(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]);
+        }
+#else
         float4 hy[2][4];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hyper + (int64_t)p * 128 + k * 32 + hh * 16 + 4 * fg);
+#endif
         // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256
         f32x4 acc[4];
 #pragma unroll
@@ -1009,6 +1035,15 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
+#if UP_MFMA_HYPER
+                const f32x2 ua0 = gelu_erf2((f32x2){c2[2 * pp][0], c2[2 * pp][1]}), ub0 = gelu_erf2((f32x2){c2[2 * pp][2], c2[2 * pp][3]});
+                const f32x2 ua1 = gelu_erf2((f32x2){c2[2 * pp + 1][0], c2[2 * pp + 1][1]}), ub1 = gelu_erf2((f32x2){c2[2 * pp + 1][2], c2[2 * pp + 1][3]});
+                const bf16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
+                f32x4 dm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hy_hi, uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hy_lo, uop, dm, 0, 0, 0);
+                if (pp == 0) px2.x = dm[0]; else px2.y = dm[0];
+                continue;
+#else
                 const int pos2 = 2 * hb + pp;
                 float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1028,6 +1063,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 float mine = fb1 ? k1 : k0;
                 mine += shfl_xor32(fb1 ? k0 : k1, lane >= 32);
                 if (pp == 0) px2.x = mine; else px2.y = mine;
+#endif
             }
             *reinterpret_cast<float2*>(orow + hb * 256) = px2;
         }
