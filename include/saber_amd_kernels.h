@@ -85,6 +85,9 @@ int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const 
 int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False, antialias) of n planes, fused post transform: 0 none, 1 a*sigmoid(v)+c, 2 a*(v>0)+c, 3 a*v+c, 4 (v>=a) */
 int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream);
+/* one axis (0: rows, 1: columns) of scipy.ndimage.gaussian_filter(sigma, mode="mirror", truncate=4) on n planes of H x W: the anti-aliasing filter
+ * skimage.transform.resize applies before it down-samples a tomogram slice to the model's 1024 px (saber/adapters/preprocessing.py:21) */
+int saber_k_gauss_mirror(const float* in, float* out, int n_planes, int H, int W, int axis, double sigma, void* stream);
 /* out = x + alpha * g[c] * y  (x, g may be NULL) */
 int saber_k_axpy(const float* x, const float* y, const float* g, float alpha, int64_t rows, int C, float* out, void* stream);
 /* out = x + y[row % y_rows] as bf16 and/or fp32 (y may be NULL) */

@@ -449,7 +449,8 @@ class VideoPredictorRef:
 
 def load_tomogram_frames(tomogram: "np.ndarray", image_size: int = 1024, light_modality: bool = False) -> T:
     """adapters/preprocessing.py:27-76 as SAM2Adapter.create_inference_state_from_tomogram applies it: min-max to [-1,1], per-slice resize
-    to image_size (skimage.transform.resize, anti_aliasing=True: the identity at image_size, order-1 interpolation when up-sampling),
+    to image_size (skimage.transform.resize, anti_aliasing=True: the identity at image_size, order-1 interpolation at pixel centres,
+    preceded by a Gaussian of sigma (factor - 1) / 2 on down-sampled axes),
     3 x channel repeat, then 2x - 1 again (img_mean / img_std are None on this path)."""
     t = np.asarray(tomogram, dtype=np.float64)
     t = (t - t.min()) / (t.max() - t.min())
@@ -457,7 +458,13 @@ def load_tomogram_frames(tomogram: "np.ndarray", image_size: int = 1024, light_m
     x = torch.from_numpy(t).float()[:, None]
     if x.shape[-2:] != (image_size, image_size):
         if x.shape[-2] > image_size or x.shape[-1] > image_size:
-            raise NotImplementedError("down-sampling resize (Gaussian anti-aliasing of skimage) is not restated")
+            # skimage.transform.resize(anti_aliasing=True), restated from its published source (skimage is absent here): on every axis
+            # that is down-sampled, scipy.ndimage.gaussian_filter with sigma = (input / output - 1) / 2, cval 0, boundary mode 'mirror'
+            # (skimage's default mode 'reflect' maps to ndimage 'mirror'), truncate 4; then order-1 interpolation at pixel centres
+            from scipy import ndimage as ndi
+            H, Wd = x.shape[-2:]
+            sig = (max(0.0, (H / image_size - 1) / 2), max(0.0, (Wd / image_size - 1) / 2))
+            x = torch.from_numpy(np.stack([ndi.gaussian_filter(pl[0].numpy(), sig, mode="mirror") for pl in x]))[:, None]
         x = F.interpolate(x, size=(image_size, image_size), mode="bilinear", align_corners=False)
     x = x.repeat(1, 3, 1, 1)
     x = 2 * x - 1

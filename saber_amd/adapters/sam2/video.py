@@ -70,7 +70,7 @@ def window_shares(k: int, world: int) -> List[Tuple[int, int]]:
 def load_tomogram_frames(tomogram: np.ndarray, image_size: int = 1024, light_modality: bool = False) -> np.ndarray:
     """TomogramPreprocessor as the adapter applies it (saber/adapters/preprocessing.py:27-76 via predictor.py:98-105): min-max to [-1,1],
     per-slice resize to image_size (skimage.transform.resize(anti_aliasing=True): the identity at image_size, order-1 interpolation at
-    pixel centres when up-sampling; the Gaussian anti-aliasing of a DOWN-sampling resize is not restated), then `2x - 1` once more
+    pixel centres; on a DOWN-sampled axis preceded by the Gaussian anti-aliasing filter of sigma (factor - 1) / 2), then `2x - 1` once more
     (img_mean / img_std are None on this path, so frames span [-3, 1]).  Host glue on the whole volume, like the reference.
     Returns (Z, image_size, image_size) float32: one gray plane per frame (the reference's 3 identical channels)."""
     t = np.asarray(tomogram, dtype=np.float64)
@@ -79,8 +79,11 @@ def load_tomogram_frames(tomogram: np.ndarray, image_size: int = 1024, light_mod
     Z, H, W = t.shape
     if (H, W) != (image_size, image_size):
         if H > image_size or W > image_size:
-            raise NotImplementedError("tomograms larger than the model's 1024 px are down-sampled by skimage with Gaussian anti-aliasing in "
-                                      "the reference; resample them first (saber's Fourier cropping) - not restated here")
+            # skimage.transform.resize(anti_aliasing=True) on a down-sampled axis: Gaussian of sigma = (factor - 1) / 2 (scipy's
+            # gaussian_filter, boundary mode 'mirror' = skimage's default 'reflect', truncate 4), then order-1 interpolation at pixel centres
+            from scipy import ndimage as ndi
+            sig = (max(0.0, (H / image_size - 1) / 2), max(0.0, (W / image_size - 1) / 2))
+            t = np.stack([ndi.gaussian_filter(t[z], sig, mode="mirror") for z in range(Z)])
         ys = np.clip((np.arange(image_size) + 0.5) * H / image_size - 0.5, 0, H - 1)
         xs = np.clip((np.arange(image_size) + 0.5) * W / image_size - 0.5, 0, W - 1)
         y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
@@ -98,16 +101,23 @@ def load_tomogram_frames(tomogram: np.ndarray, image_size: int = 1024, light_mod
 def load_tomogram_frames_device(tomogram: np.ndarray, lib, device, image_size: int = 1024, light_modality: bool = False) -> torch.Tensor:
     """load_tomogram_frames on the device: the two affine steps (min-max to [-1,1], then 2x - 1) commute with the bilinear resize, so the
     volume is uploaded once and one resize launch with the fused affine map v -> 4 (v - min) / (max - min) - 3 produces the (Z, 1024, 1024)
-    frame stack in HBM (the host version spends ~25 ms per slice in numpy).  Same restrictions as the host version."""
+    frame stack in HBM (the host version spends ~25 ms per slice in numpy); tomograms larger than 1024 px go through the Gaussian filter first."""
     t = torch.from_numpy(np.ascontiguousarray(tomogram, dtype=np.float32)).to(device)
     Z, H, W = t.shape
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    mn, mx = (float(v) for v in torch.aminmax(t))              # of the tomogram as loaded: the reference normalises before it resizes
     if H > image_size or W > image_size:
-        raise NotImplementedError("tomograms larger than the model's 1024 px are down-sampled by skimage with Gaussian anti-aliasing in "
-                                  "the reference; resample them first (saber's Fourier cropping) - not restated here")
-    mn, mx = (float(v) for v in torch.aminmax(t))
+        # the Gaussian anti-aliasing of skimage's down-sampling resize (saber_k_gauss_mirror: scipy's gaussian_filter, mode 'mirror'), per
+        # down-sampled axis; its taps sum to one, so it commutes with the affine normalisation applied by the resize launch below
+        for axis, n in ((0, H), (1, W)):
+            sigma = (n / image_size - 1) / 2
+            if sigma > 0:
+                tmp = torch.empty_like(t)
+                if lib.saber_k_gauss_mirror(C.c_void_p(t.data_ptr()), C.c_void_p(tmp.data_ptr()), Z, H, W, axis, float(sigma), stream) != 0:
+                    raise RuntimeError(lib.saber_k_last_error().decode())
+                t = tmp
     a = 4.0 / (mx - mn)
     out = torch.empty((Z, image_size, image_size), dtype=torch.float32, device=device)
-    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     if lib.saber_k_resize_plane(C.c_void_p(t.data_ptr()), Z, H, W, C.c_void_p(out.data_ptr()), image_size, image_size, 0, 3, a, -a * mn - 3.0, stream) != 0:
         raise RuntimeError(lib.saber_k_last_error().decode())
     if light_modality:

@@ -147,6 +147,9 @@ extern "C" int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, 
 extern "C" int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream) {
     return kcheck(launch_resize_plane(in, n_planes, H, W, out, Ho, Wo, antialias, post, a, c, (hipStream_t)stream));
 }
+extern "C" int saber_k_gauss_mirror(const float* in, float* out, int n_planes, int H, int W, int axis, double sigma, void* stream) {
+    return kcheck(launch_gauss_mirror(in, out, n_planes, H, W, axis, sigma, (hipStream_t)stream));
+}
 extern "C" int saber_k_axpy(const float* x, const float* y, const float* g, float alpha, int64_t rows, int C, float* out, void* stream) {
     return kcheck(launch_axpy(x, y, g, alpha, rows, C, out, (hipStream_t)stream));
 }

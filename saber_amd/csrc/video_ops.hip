@@ -288,3 +288,44 @@ const char* launch_paint_nearest(const float* logits, int Hv, int Wv, float thr,
     hipLaunchKernelGGL(paint_nearest_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, logits, Hv, Wv, thr, label, plane, H, W, any_flag);
     return nullptr;
 }
+
+// ------------------------------------------------------------------------------------------------ Gaussian anti-aliasing filter
+// One axis of scipy.ndimage.gaussian_filter(mode="mirror") on n planes of H x W: out[y][x] = sum_k w[k] in[mirror(y + k - r)][x] (axis 0)
+// or along x (axis 1); mirror = reflection about the centre of the edge pixel (index -1 -> 1).  skimage.transform.resize(anti_aliasing=True)
+// applies it with sigma = (factor - 1) / 2 before a down-sampling interpolation (saber/adapters/preprocessing.py:21).
+#define GM_MAX_R 64
+struct GaussTaps { float w[2 * GM_MAX_R + 1]; };
+__global__ __launch_bounds__(256) void gauss_mirror_kernel(const float* __restrict__ in, float* __restrict__ out, int n_planes, int H, int W, int axis, int r, GaussTaps taps) {
+    const int64_t total = (int64_t)n_planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const float* pl = in + (i / ((int64_t)H * W)) * H * W;
+        const int n = axis == 0 ? H : W, c = axis == 0 ? y : x;
+        float acc = 0.f;
+        for (int k = -r; k <= r; ++k) {
+            int j = c + k;
+            // mirror (period 2 n - 2); n == 1: the only pixel
+            if (n == 1) j = 0;
+            else {
+                const int per = 2 * n - 2;
+                j %= per; if (j < 0) j += per;
+                if (j >= n) j = per - j;
+            }
+            acc = fmaf(taps.w[k + r], axis == 0 ? pl[(int64_t)j * W + x] : pl[(int64_t)y * W + j], acc);
+        }
+        out[i] = acc;
+    }
+}
+const char* launch_gauss_mirror(const float* in, float* out, int n_planes, int H, int W, int axis, double sigma, hipStream_t s) {
+    if (n_planes <= 0 || H <= 0 || W <= 0 || (axis != 0 && axis != 1) || !(sigma > 0.0)) return "gauss_mirror: bad argument";
+    const int r = (int)(4.0 * sigma + 0.5);                  // scipy: truncate = 4.0
+    if (r > GM_MAX_R) return "gauss_mirror: sigma too large (radius > 64)";
+    GaussTaps t;
+    double sum = 0.0;
+    for (int k = -r; k <= r; ++k) sum += exp(-0.5 * k * k / (sigma * sigma));
+    for (int k = -r; k <= r; ++k) t.w[k + r] = (float)(exp(-0.5 * k * k / (sigma * sigma)) / sum);
+    const int64_t total = (int64_t)n_planes * H * W;
+    hipLaunchKernelGGL(gauss_mirror_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536 * 4)), dim3(256), 0, s, in, out, n_planes, H, W, axis, r, t);
+    return nullptr;
+}

@@ -336,3 +336,19 @@ def test_window_encodes_sharded_over_ranks(tmp_path):
         got = np.load(str(tmp_path / f"r{r}.npz"))
         assert int(got["sharded"]) == 2
         assert np.array_equal(got["vol"], one["vol"]) and np.array_equal(got["scores"], one["scores"]), r
+
+
+def test_frames_larger_than_1024_px_on_the_device(gpu_lib):
+    """load_tomogram_frames_device on a tomogram above the model's resolution (Gaussian anti-aliasing as skimage's down-sampling resize
+    applies it, saber/adapters/preprocessing.py:21) against the oracle's scipy restatement; mixed case: one axis down-, one up-sampled."""
+    from oracle import sam2_video_ref as V
+    from saber_amd.adapters.sam2.video import load_tomogram_frames_device
+    rng = np.random.default_rng(5)
+    for shape in ((2, 1536, 1300), (1, 2048, 2048), (2, 1100, 700)):
+        tomo = rng.normal(0, 1, shape).astype(np.float32)
+        ref = V.load_tomogram_frames(tomo)[:, 0]
+        got = load_tomogram_frames_device(tomo, gpu_lib, torch.device("cuda:0"))
+        torch.cuda.synchronize()
+        err = (got.cpu() - ref).abs().max().item()
+        print(shape, "frames max abs diff", err)
+        assert got.shape == (shape[0], 1024, 1024) and err < 2e-5
