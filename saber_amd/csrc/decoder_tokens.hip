@@ -118,18 +118,26 @@ __device__ __forceinline__ void fold_operand(const TokCtx& c, const char* F, int
     *hi = pack8(v); *lo = pack8(l);
 }
 // out[p][8 h + t][d] = scale sum_j a[t][16 h + j] W(16 h + j, d), W given TRANSPOSED as WT bf16 [256][128]  (dec_fold_kernel mode 0)
+// (the wave's 8 weight fragments - 4 head pairs x 2 channel tiles - are loaded once, ahead of the loop over the prompts: fetched inside it
+// they cost one L2 round trip per (prompt, head pair), 16 in a row)
 __device__ __forceinline__ void fold_rows(const TokCtx& c, const char* F, const bf16_t* WT, float scale, bf16_t* out, int p0, int P) {
+    bf16x8 w[4][2];
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            w[hp][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(WT + (16 * (c.wave * 2 + i) + c.fi) * 128 + 32 * hp + 8 * c.fg));
     for (int pi = 0; pi < TK_G; ++pi) {
         if (p0 + pi >= P) break;
+#pragma unroll
         for (int hp = 0; hp < 4; ++hp) {
             bf16x8 hi, lo;
             fold_operand(c, F, pi, hp, scale, &hi, &lo);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int dt = c.wave * 2 + i;
-                const bf16x8 w = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(WT + (16 * dt + c.fi) * 128 + 32 * hp + 8 * c.fg));
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hi, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, lo, acc, 0, 0, 0);
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[hp][i], hi, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[hp][i], lo, acc, 0, 0, 0);
                 // D[d = 16 dt + 4 fg + r][(hsel, t) = fi]
                 bf16_t* o = out + ((int64_t)(p0 + pi) * 64 + 8 * (2 * hp + (c.fi >> 3)) + (c.fi & 7)) * 256 + 16 * dt + 4 * c.fg;
                 *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]));
@@ -139,17 +147,23 @@ __device__ __forceinline__ void fold_rows(const TokCtx& c, const char* F, const 
 }
 // out[p][d][8 h + t] = sum_j a[t][16 h + j] W[d][16 h + j], W bf16 [256][128]  (dec_fold_kernel mode 1: transposed output)
 __device__ __forceinline__ void fold_cols(const TokCtx& c, const char* F, const bf16_t* W, int ldw, bf16_t* out, int p0, int P) {
+    bf16x8 w[4][2];
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            w[hp][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W + (int64_t)(16 * (c.wave * 2 + i) + c.fi) * ldw + 32 * hp + 8 * c.fg));
     for (int pi = 0; pi < TK_G; ++pi) {
         if (p0 + pi >= P) break;
+#pragma unroll
         for (int hp = 0; hp < 4; ++hp) {
             bf16x8 hi, lo;
             fold_operand(c, F, pi, hp, 1.0f, &hi, &lo);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int dt = c.wave * 2 + i;
-                const bf16x8 w = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W + (int64_t)(16 * dt + c.fi) * ldw + 32 * hp + 8 * c.fg));
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, w, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, w, acc, 0, 0, 0);
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, w[hp][i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, w[hp][i], acc, 0, 0, 0);
                 // D[(hsel, t) = 4 fg + r][d = 16 dt + fi]  ->  columns 16 hp + 4 fg + r of row d
                 bf16_t* o = out + ((int64_t)(p0 + pi) * 256 + 16 * dt + c.fi) * 64 + 16 * hp + 4 * c.fg;
                 *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]));
