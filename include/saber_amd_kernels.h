@@ -85,6 +85,11 @@ int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const 
 int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False, antialias) of n planes, fused post transform: 0 none, 1 a*sigmoid(v)+c, 2 a*(v>0)+c, 3 a*v+c, 4 (v>=a) */
 int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream);
+/* one-head attention of 256 channels, flash style (the memory attention of the video path, upstream MemoryAttentionLayer self / cross attention):
+ * out = bf16(softmax(scale Q K^T) V + bias_v); Q [n_q][256], K, V [n_keys][256] bf16 row-major, n_q a multiple of 64; ws: scratch of at least
+ * (n_q / 64) * 8 * 64 * 258 floats for the split over the keys, or NULL */
+int saber_k_flash256(const uint16_t* Q, const uint16_t* K, const uint16_t* V, int n_q, int n_keys, float scale, const float* bias_v, uint16_t* out, float* ws,
+                    int64_t ws_floats, void* stream);
 /* one axis (0: rows, 1: columns) of scipy.ndimage.gaussian_filter(sigma, mode="mirror", truncate=4) on n planes of H x W: the anti-aliasing filter
  * skimage.transform.resize applies before it down-samples a tomogram slice to the model's 1024 px (saber/adapters/preprocessing.py:21) */
 int saber_k_gauss_mirror(const float* in, float* out, int n_planes, int H, int W, int axis, double sigma, void* stream);

@@ -110,6 +110,7 @@ SIGNATURES = {
     "saber_k_dwconv7": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "saber_k_flash256": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, C.c_int64, _vp]),
     "saber_k_gauss_mirror": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_double, _vp]),
     "saber_k_axpy": (_i, [_vp, _vp, _vp, _f, C.c_int64, _i, _vp, _vp]),
     "saber_k_add_to_bf16": (_i, [_vp, _vp, _i, _vp, _vp, C.c_int64, _i, _vp]),

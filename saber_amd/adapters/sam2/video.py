@@ -170,6 +170,7 @@ class VideoPredictor:
         self.conv_t = {j: torch.from_numpy(np.ascontiguousarray(np.asarray(W[f"memory_encoder.mask_downsampler.encoder.{3 * j}.weight"], dtype=np.float32)
                                                                 .transpose(2, 3, 1, 0))).to(self.dev) for j in range(4)}
         self._pe1d_cache: Dict[tuple, torch.Tensor] = {}
+        self._flash_ws = None
         self.hook = None
         self.images = None
 
@@ -542,13 +543,14 @@ class VideoPredictor:
         self._ck(self.lib.saber_k_axpy(self._p(raw), self._p(self.curr_pos), None, 0.1, 4096, 256, self._p(x), self._s()))
         scale = 1.0 / 16.0
 
-        def attend(q_bf, k_bf, vT_bf, n_keys, n_keys_p, bv, ldk):
-            S = self._new(4096, n_keys)
-            self._gemm(q_bf, k_bf, None, 4096, n_keys, 256, out_f32=S)
-            Pm = self._new(4096, n_keys_p, dtype=torch.uint16)
-            self._ck(self.lib.saber_k_softmax_rows(self._p(S), n_keys, 4096, n_keys, scale, self._p(Pm), n_keys_p, self._s()))
+        def attend(q_bf, k_bf, v_bf, n_keys, bv):
+            # flash-style (csrc/flash256.hip): no materialised (4096, n_keys) scores; the value bias is added after the product (softmax
+            # rows sum to 1)
             O = self._new(4096, 256, dtype=torch.uint16)
-            self._gemm(Pm, vT_bf, bv, 4096, 256, n_keys_p, out_bf=O)          # softmax rows sum to 1: the value bias is added after the product
+            if self._flash_ws is None:
+                self._flash_ws = self._new(64 * 8 * 64 * 258)
+            self._ck(self.lib.saber_k_flash256(self._p(q_bf), self._p(k_bf), self._p(v_bf), 4096, n_keys, scale, self._p(bv), self._p(O),
+                                               self._p(self._flash_ws), self._flash_ws.numel(), self._s()))
             return O
 
         def rope(x_f32, rows, n_rot):
@@ -561,22 +563,18 @@ class VideoPredictor:
             tb = self._ln(x, L + "norm1", 4096, 256, 1e-5)
             q = rope(self._lin(tb, L + "self_attn.q_proj", 4096), 4096, 4096)
             k = rope(self._lin(tb, L + "self_attn.k_proj", 4096), 4096, 4096)
-            vT = self._new(256, 4096, dtype=torch.uint16)
-            self._gemm(self.bf[L + "self_attn.v_proj.weight"], tb, None, 256, 4096, 256, out_bf=vT)       # V^T = W_v . t^T
-            O = attend(q, k, vT, 4096, 4096, self.f32[L + "self_attn.v_proj.bias"], 256)
+            v = self._new(4096, 256, dtype=torch.uint16)
+            self._gemm(tb, self.bf[L + "self_attn.v_proj.weight"], None, 4096, 256, 256, out_bf=v)
+            O = attend(q, k, v, 4096, self.f32[L + "self_attn.v_proj.bias"])
             x = self._lin(O, L + "self_attn.out_proj", 4096, res=x)
             tb = self._ln(x, L + "norm2", 4096, 256, 1e-5)
             q = rope(self._lin(tb, L + "cross_attn_image.q_proj", 4096), 4096, 4096)
             kf = self._new(Nkp, 256, zero=True)
             self._gemm(kin_bf, self.bf[L + "cross_attn_image.k_proj.weight"], self.f32[L + "cross_attn_image.k_proj.bias"], Nk, 256, 64, out_f32=kf)
             k = rope(kf, Nkp, n_spatial)
-            vT = self._new(256, Nkp, dtype=torch.uint16, zero=True)
-            self._gemm(self.bf[L + "cross_attn_image.v_proj.weight"], mem_bf, None, 256, Nk, 64, out_bf=vT, ldw=64)
-            vT2 = vT
-            if Nk != Nkp:          # the GEMM wrote Nk columns per row with leading dimension Nk: re-lay to the padded leading dimension
-                vT2 = self._new(256, Nkp, dtype=torch.uint16, zero=True)
-                vT2[:, :Nk].copy_(vT.view(-1)[:256 * Nk].view(256, Nk))
-            O = attend(q, k, vT2, Nk, Nkp, self.f32[L + "cross_attn_image.v_proj.bias"], 256)
+            v = self._new(Nk, 256, dtype=torch.uint16)
+            self._gemm(mem_bf, self.bf[L + "cross_attn_image.v_proj.weight"], None, Nk, 256, 64, out_bf=v)
+            O = attend(q, k, v, Nk, self.f32[L + "cross_attn_image.v_proj.bias"])
             x = self._lin(O, L + "cross_attn_image.out_proj", 4096, res=x)
             tb = self._ln(x, L + "norm3", 4096, 256, 1e-5)
             h = self._lin(tb, L + "linear1", 4096, out_bf=True, act=ACT_RELU)

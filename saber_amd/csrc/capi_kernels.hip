@@ -147,6 +147,10 @@ extern "C" int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, 
 extern "C" int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream) {
     return kcheck(launch_resize_plane(in, n_planes, H, W, out, Ho, Wo, antialias, post, a, c, (hipStream_t)stream));
 }
+extern "C" int saber_k_flash256(const uint16_t* Q, const uint16_t* K, const uint16_t* V, int n_q, int n_keys, float scale, const float* bias_v, uint16_t* out, float* ws,
+                                int64_t ws_floats, void* stream) {
+    return kcheck(launch_flash256(Q, K, V, n_q, n_keys, scale, bias_v, out, ws, (size_t)ws_floats, (hipStream_t)stream));
+}
 extern "C" int saber_k_gauss_mirror(const float* in, float* out, int n_planes, int H, int W, int axis, double sigma, void* stream) {
     return kcheck(launch_gauss_mirror(in, out, n_planes, H, W, axis, sigma, (hipStream_t)stream));
 }

@@ -192,6 +192,10 @@ const char* launch_conv3x3s2_t(const float* in, int H, int W, int Cin, const flo
 const char* launch_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, hipStream_t s);
 const char* launch_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, hipStream_t s);
 const char* launch_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, hipStream_t s);
+// softmax(scale Q K^T) V + bias_v for ONE head of 256 channels (memory attention of the video path): Q [n_q][256], K / V [n_keys][256] bf16
+// row-major, out bf16 [n_q][256]; ws: >= (n_q / 64) * 8 * 64 * 258 floats of scratch for the split over the keys (may be NULL: no split)
+const char* launch_flash256(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int n_q, int n_keys, float scale, const float* bias_v, bf16_t* out, float* ws,
+                            size_t ws_floats, hipStream_t s);
 const char* launch_gauss_mirror(const float* in, float* out, int n_planes, int H, int W, int axis, double sigma, hipStream_t s);
 const char* launch_axpy(const float* x, const float* y, const float* g, float alpha, int64_t rows, int C, float* out, hipStream_t s);
 const char* launch_bf16_to_f32(const bf16_t* x, int64_t n, float* out, hipStream_t s);

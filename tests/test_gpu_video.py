@@ -352,3 +352,25 @@ def test_frames_larger_than_1024_px_on_the_device(gpu_lib):
         err = (got.cpu() - ref).abs().max().item()
         print(shape, "frames max abs diff", err)
         assert got.shape == (shape[0], 1024, 1024) and err < 2e-5
+
+
+def test_flash256_attention_kernel(gpu_lib):
+    """csrc/flash256.hip against torch: one head of 256 channels, 4096 queries, key counts that are and are not multiples of the 64-key
+    blocks (the memory bank: 2 x 4096 spatial tokens + 4 tokens per object pointer), with and without the split over the keys."""
+    g = torch.Generator().manual_seed(3)
+    for n_q, n_keys in ((4096, 4096), (4096, 8212), (128, 100), (64, 31)):
+        Q = (torch.randn(n_q, 256, generator=g) * 0.7).to(torch.bfloat16)
+        K = (torch.randn(n_keys, 256, generator=g) * 0.7).to(torch.bfloat16)
+        V = torch.randn(n_keys, 256, generator=g).to(torch.bfloat16)
+        bv = torch.randn(256, generator=g)
+        ref = torch.softmax((Q.float() @ K.float().T) * 0.0625, -1) @ V.float() + bv
+        out = torch.empty(n_q, 256, dtype=torch.uint16, device="cuda")
+        ws = torch.empty((n_q // 64) * 8 * 64 * 258, device="cuda")
+        for w in (ws, None):
+            ck(gpu_lib, gpu_lib.saber_k_flash256(ptr(dev(Q.view(torch.uint16))), ptr(dev(K.view(torch.uint16))), ptr(dev(V.view(torch.uint16))), n_q, n_keys, 0.0625,
+                                                 ptr(dev(bv)), ptr(out), ptr(w), 0 if w is None else w.numel(), None))
+            torch.cuda.synchronize()
+            got = bf_to_f(out.cpu())
+            err = (got - ref).abs().max().item()
+            print(f"flash256 n_q={n_q} n_keys={n_keys} split={'yes' if w is not None else 'no'}: max abs diff {err:.3e} (|ref| max {ref.abs().max().item():.2f})")
+            assert err < 0.03        # bf16 P and bf16 output
