@@ -82,6 +82,8 @@ int saber_k_unpack_masks(const uint32_t* bits, int n, int H, int W, uint8_t* out
 /* depth-wise Conv2d(k7, p3) of the memory fuser's ConvNeXt blocks; w (C,1,7,7) */
 int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream);
 /* the video predictor's mask_downsample: Conv2d(1, 1, k4, s4) */
+/* saber_k_dwconv7 with the weights given as (7,7,C) [tap][channel] */
+int saber_k_dwconv7_t(const float* in, int H, int W, int C, const float* wt, const float* b, float* out, void* stream);
 int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False, antialias) of n planes, fused post transform: 0 none, 1 a*sigmoid(v)+c, 2 a*(v>0)+c, 3 a*v+c, 4 (v>=a) */
 int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream);

@@ -108,6 +108,7 @@ SIGNATURES = {
     "saber_k_paint_nearest": (_i, [_vp, _i, _i, _f, _i, _vp, _i, _i, _vp, _vp]),
     "saber_k_unpack_masks": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "saber_k_dwconv7": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "saber_k_dwconv7_t": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "saber_k_flash256": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, C.c_int64, _vp]),

@@ -169,6 +169,9 @@ class VideoPredictor:
         # mask down-sampler convolutions with the weights laid out (3,3,Cin,Cout) for saber_k_conv3x3s2_t
         self.conv_t = {j: torch.from_numpy(np.ascontiguousarray(np.asarray(W[f"memory_encoder.mask_downsampler.encoder.{3 * j}.weight"], dtype=np.float32)
                                                                 .transpose(2, 3, 1, 0))).to(self.dev) for j in range(4)}
+        # depth-wise 7x7 weights of the fuser laid out (49, C) for saber_k_dwconv7_t
+        self.dw_t = {i: torch.from_numpy(np.ascontiguousarray(np.asarray(W[f"memory_encoder.fuser.layers.{i}.dwconv.weight"], dtype=np.float32).reshape(256, 49).T)).to(self.dev)
+                     for i in range(2)}
         self._pe1d_cache: Dict[tuple, torch.Tensor] = {}
         self._flash_ws = None
         self.hook = None
@@ -351,7 +354,7 @@ class VideoPredictor:
         for i in range(2):
             f = f"memory_encoder.fuser.layers.{i}."
             h = self._new(4096, 256)
-            self._ck(self.lib.saber_k_dwconv7(self._p(p), 64, 64, 256, self._p(self.f32[f + "dwconv.weight"]), self._p(self.f32[f + "dwconv.bias"]), self._p(h), self._s()))
+            self._ck(self.lib.saber_k_dwconv7_t(self._p(p), 64, 64, 256, self._p(self.dw_t[i]), self._p(self.f32[f + "dwconv.bias"]), self._p(h), self._s()))
             hn = self._ln(h, f + "norm", 4096, 256, 1e-6)
             h1 = self._lin(hn, f + "pwconv1", 4096, out_bf=True, act=ACT_GELU)
             h2 = self._lin(h1, f + "pwconv2", 4096)

@@ -141,6 +141,9 @@ extern "C" int saber_k_unpack_masks(const uint32_t* bits, int n, int H, int W, u
 extern "C" int saber_k_dwconv7(const float* in, int H, int W, int C, const float* w, const float* b, float* out, void* stream) {
     return kcheck(launch_dwconv7(in, H, W, C, w, b, out, (hipStream_t)stream));
 }
+extern "C" int saber_k_dwconv7_t(const float* in, int H, int W, int C, const float* wt, const float* b, float* out, void* stream) {
+    return kcheck(launch_dwconv7_t(in, H, W, C, wt, b, out, (hipStream_t)stream));
+}
 extern "C" int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream) {
     return kcheck(launch_conv4x4s4(in, H, W, w, b, out, (hipStream_t)stream));
 }
