@@ -151,6 +151,43 @@ def tail_mode(eng, pool, a, segment_slice_to_plane, make_amg_params):
             "ms_per_slice_default_thresholds_same_handle": dt0 * 1e3, "tail_ms": (dt - dt0) * 1e3, "host_syncs_per_slice": syncs}
 
 
+def precision_check(weights, img):
+    """One encode + 64 grid prompts (+ their m2m refinement) on a handle that carries both precisions: relative RMS difference of the bf16
+    production arithmetic from the exact fp32 mode (saber_engine_set_precision; tests/test_gpu_exact.py pins that mode to the fp32 CPU
+    oracle at ~1e-6), and the time the exact mode takes."""
+    import numpy as np
+    import torch
+    from saber_amd.engine import Engine
+
+    def rel(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float(((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item())
+    e = Engine("large", device=0, weights=weights, max_images=1, max_prompts=64, precision="exact")
+    try:
+        g = np.linspace(1 / 16, 1 - 1 / 16, 8, dtype=np.float32) * 1024
+        pts = torch.from_numpy(np.stack(np.meshgrid(g, g), -1).reshape(-1, 2).copy()).cuda()
+        res = {}
+        for mode in ("exact", "bf16"):
+            e.set_precision(mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e.encode(img)
+            f = {k: v.clone() for k, v in e.get_features(0).items()}
+            low, iou, _ = e.decode_points(pts, slot=0, multimask=True)
+            mi = torch.clamp(low[:, 0], -32, 32).contiguous()
+            low2, iou2, _ = e.decode_points(pts, slot=0, multimask=False, mask_input=mi)
+            torch.cuda.synchronize()
+            res[mode] = (f, low, iou, low2, iou2, time.perf_counter() - t0)
+        x, b = res["exact"], res["bf16"]
+        return {"what": "bf16 production arithmetic vs the engine's exact (fp32-operand) mode, same handle, same slice: 1 encoder pass + 64 grid prompts (3 masks) + their m2m refinement",
+                "rel_rms": {"image_embed": rel(b[0]["image_embed"], x[0]["image_embed"]), "feat_s1": rel(b[0]["feat_s1"], x[0]["feat_s1"]),
+                            "feat_s0": rel(b[0]["feat_s0"], x[0]["feat_s0"]), "low_res_logits": rel(b[1], x[1]), "m2m_low_res_logits": rel(b[3], x[3])},
+                "pred_iou_max_abs": float((b[2] - x[2]).abs().max().item()), "mask_sign_agreement": float(((b[1] > 0) == (x[1] > 0)).float().mean().item()),
+                "seconds": {"exact": x[5], "bf16": b[5]}}
+    finally:
+        e.close()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -301,6 +338,8 @@ def main():
             run_steps(0, 6)
             torch.cuda.synchronize()
             ab[f"ms_per_slice_{name}"] = (time.perf_counter() - t0) / 6 * 1e3
+        for e_ in engines:             # back to the setting the headline ran with (the A/B loop left replay on)
+            e_.set_graphs(os.environ.get("SABER_AMD_GRAPHS", "1") != "0")
         cap, rep = eng.graph_stats()
         out["hipgraph"] = dict(ab, what=f"same step, 6 slices each over the {len(engines)} engine handle(s) of the headline, launch sequences issued eagerly vs replayed from hipGraphs (encoder pass + each decoder batch)",
                                sequences_captured=cap, replays_so_far=rep, headline_uses_graphs=os.environ.get("SABER_AMD_GRAPHS", "1") != "0")
@@ -317,7 +356,7 @@ def main():
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": alg_bytes, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic and alg_bytes else None,
                            "mfma_busy_frac": mfma_busy, "mfma_busy_unit": "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), rocprofv3 PMC, same summary file",
-                           "kernel": "gemm_bf16 (gemm_bf16_glds2_kernel + gemm_bf16_p256s_kernel + gemm_rowln_kernel + gemm_bf16_glds_kernel<4> + gemm_bf16_kernel<T>)", "launches_per_slice": g["launches"],
+                           "kernel": "gemm_bf16 (gemm_bf16_glds2_kernel + gemm_bf16_p256s_kernel + gemm_rowln_kernel + gemm_bf16_glds_kernel<4> + gemm_bf16_kernel<T>; since round 3 the ~300 token-side GEMM launches of the decoder are part of dec_tokens_kernel, class decoder_attention)", "launches_per_slice": g["launches"],
                            "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]),
                            "algorithmic_gflop_per_launch": g["flops"] / max(1, g["launches"]) / 1e9,
                            "kernel_ms_per_slice": g["ms"], "share_of_kernel_time": g["ms"] / total_ms if total_ms else None,
@@ -356,6 +395,11 @@ def main():
             out["propagation"] = video_bench.run("large", 32)
         except Exception as ex:
             out["propagation"] = {"error": str(ex)[:300]}
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail and a.dtype == "bf16":
+        try:        # what the bf16 operands of the headline cost against the engine's exact (fp32) mode on this slice; never part of `value`
+            out["precision"] = precision_check(weights, eng.prepare(pool[0]))
+        except Exception as ex:
+            out["precision"] = {"error": str(ex)[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         img01 = eng.prepare(pool[0]).cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(cfg, weights, img01, a.crop_n_layers)

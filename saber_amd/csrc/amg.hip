@@ -186,7 +186,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         {
             const float* img = e->amg_img;
             // the crop boxes go through the pinned buffer the (possibly replayed) H2D copy of eng_encode reads at execution time
-            if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 4 * 64));
+            if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 256 * 8));
             std::copy(cb.begin(), cb.begin() + 4 * ncb, e->crops_pin);
             TRY(eng_graphed(e, "enc," + key_of({(long long)(uintptr_t)img, H, W, channels, ncb, c0, prm->crop_n_layers, (long long)(prm->crop_overlap_ratio * 1e6)}), s,
                             [&]() { return eng_encode(e, img, H, W, channels, e->crops_pin, ncb, 0, s); }));

@@ -120,7 +120,12 @@ struct saber_engine {
     std::set<std::string> graph_seen, graph_bad;
     int graph_replays = 0, graph_captures = 0;
     float* amg_img = nullptr; size_t amg_img_elems = 0;     // engine-owned copy of the caller's image: a stable address for the captured launches
-    int* crops_pin = nullptr;                                // pinned host copy of the crop boxes of an encoder pass (read by the captured H2D copy)
+    int* crops_pin = nullptr;                                // pinned host copies of the crop boxes of encoder passes: 8 slots of 256 ints.  Slot 0 belongs
+                                                             // to the AMG driver (its H2D copy is captured into a hipGraph and reads the slot at replay time);
+                                                             // saber_encode cycles through slots 1..7, each guarded by an event recorded behind its H2D copy, so
+                                                             // back-to-back calls without a stream synchronisation never overwrite boxes a queued copy has yet to read
+    hipEvent_t crops_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int crops_next = 1;
     int *rm_to_eng = nullptr, *eng_to_rm = nullptr;   // 64x64 grid: row-major (y * 64 + x) <-> engine token order (video path, on demand)
     int amg_last_syncs = 0;           // host synchronisations of the last saber_amg_generate call (saber_amg_last_syncs)
 

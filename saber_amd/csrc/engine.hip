@@ -200,6 +200,7 @@ extern "C" void saber_engine_destroy(saber_engine* e) {
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     exact_release(e);
     if (e->crops_pin) (void)hipHostFree(e->crops_pin);
+    for (hipEvent_t ev : e->crops_ev) if (ev) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
@@ -787,9 +788,19 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         if (c[0] < 0 || c[1] < 0 || c[2] > W || c[3] > H || c[2] <= c[0] || c[3] <= c[1]) return eng_fail(e, SABER_ERR_INVALID, "encode: crop box outside the image");
     }
     // (through a pinned engine-owned buffer: when this pass is captured into a hipGraph the copy node reads its source at replay time)
-    if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 4 * 64));
-    if (crops_host != e->crops_pin) memcpy(e->crops_pin, crops_host, sizeof(int) * 4 * n);
-    ENG_HIP(e, hipMemcpyAsync(e->crops_dev, e->crops_pin, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
+    if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 256 * 8));
+    const int* src = crops_host;
+    int slot = 0;
+    if (crops_host != e->crops_pin) {      // not the AMG driver's own slot: take the next ring slot once its previous copy has run
+        slot = e->crops_next;
+        e->crops_next = slot == 7 ? 1 : slot + 1;
+        if (!e->crops_ev[slot]) ENG_HIP(e, hipEventCreateWithFlags(&e->crops_ev[slot], hipEventDisableTiming));
+        else ENG_HIP(e, hipEventSynchronize(e->crops_ev[slot]));
+        memcpy(e->crops_pin + 256 * slot, crops_host, sizeof(int) * 4 * n);
+        src = e->crops_pin + 256 * slot;
+    }
+    ENG_HIP(e, hipMemcpyAsync(e->crops_dev, src, sizeof(int) * 4 * n, hipMemcpyHostToDevice, s));
+    if (slot) ENG_HIP(e, hipEventRecord(e->crops_ev[slot], s));
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_resize_normalize(img_dev, H, W, channels, e->crops_dev, n, e->pix, 1024, s));
     ENG_KP(e, PC_IMAGE, 0.0, 0.0, launch_patch_embed(e->pix, e->pe_wt, e->pe_bias, e->pos_table, e->xa, n, e->embed_dim, 1024, s));
     if (e->precision == SABER_PRECISION_EXACT) {

@@ -208,3 +208,22 @@ def test_m2m_src_assembled_in_kernel_equals_materialised(engine):
                 del os.environ["SABER_AMD_XBUILD"]
             for a, b in zip(got, ref):
                 assert torch.equal(a, b), (n, slot)
+
+
+def test_back_to_back_encodes_keep_their_own_crop_boxes(engine):
+    """saber_encode stages the crop boxes in pinned memory and copies them asynchronously; two calls without a stream
+    synchronisation in between must not see each other's boxes (ring of pinned slots guarded by events)."""
+    rng = np.random.default_rng(33)
+    img = torch.from_numpy(rng.uniform(0, 1, (1024, 1024)).astype(np.float32)).cuda()
+    a, b = [0, 0, 512, 512], [300, 200, 1024, 900]
+    engine.encode(img, [a], slot0=0)
+    ref_a = engine.get_features(0)["image_embed"].clone()
+    engine.encode(img, [b], slot0=0)
+    ref_b = engine.get_features(0)["image_embed"].clone()
+    torch.cuda.synchronize()
+    for _ in range(3):                       # (more calls than would fit one slot)
+        engine.encode(img, [a], slot0=0)
+        engine.encode(img, [b], slot0=1)      # no synchronisation between the two
+    fa, fb = engine.get_features(0)["image_embed"], engine.get_features(1)["image_embed"]
+    torch.cuda.synchronize()
+    assert torch.equal(fa, ref_a) and torch.equal(fb, ref_b)
