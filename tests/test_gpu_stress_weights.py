@@ -64,8 +64,10 @@ def test_precision_modes_on_stress_weights():
         e8 = {k: rel_rms(f8[k], fx[k]) for k in fx}
         print("price of e4m3 weights on stress weights (vs exact): features", e8, f"low-res logits {rel_rms(l8, lx):.2e}, iou abs {(i8 - ix).abs().max().item():.2e}, "
               f"mask sign agreement {((l8 > 0) == (lx > 0)).float().mean().item():.5f}")
-        # bounds: 2x the values measured on an MI355X
-        assert eb["image_embed"] < 0.1 and e8["image_embed"] < 0.3
+        # bounds: 2x the values measured on an MI355X: bf16 4.4e-3 / 4.9e-3 / 6.1e-3 (image_embed / feat_s0 / feat_s1),
+        # low-res logits 8.0e-3; e4m3 weights: image_embed 2.8e-2, low-res logits 2.2e-2
+        assert eb["image_embed"] < 9e-3 and eb["feat_s0"] < 1e-2 and eb["feat_s1"] < 1.25e-2 and rel_rms(lb, lx) < 1.6e-2
+        assert e8["image_embed"] < 6e-2 and rel_rms(l8, lx) < 4.5e-2
     finally:
         eng.close()
         eng8.close()
