@@ -151,9 +151,16 @@ int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int 
  * saber_engine_finalize.  SABER_WEIGHTS_FP8_E4M3 (BASELINE configs[4], "fp8 weights"): every output row is quantised to OCP e4m3fn with
  * one power-of-two scale per row (round to nearest even, saturating at 448).  The MFMA operands stay bf16 (activations are bf16, and the
  * quantised value times its scale is exact in bf16), accumulation fp32: this is the numerics of an fp8-weight checkpoint, not an
- * fp8-operand kernel (none is built).  Narrower than the reference's precision: never the default. */
+ * fp8-operand kernel.
+ * SABER_WEIGHTS_MXFP8 (BASELINE configs[4], "fp8 weights on CDNA4 fp8 MFMA"; Hiera-L): qkv of the blocks that keep their width and both MLP
+ * layers of every stage-2 / stage-3 block are stored in the OCP MX format (e4m3fn elements, one e8m0 power-of-two scale per 32
+ * K-elements: the smallest with amax <= 448 * scale) and RUN on v_mfma_scale_f32_16x16x128_f8f6f4 (csrc/gemm_fp8.hip, twice the bf16
+ * MFMA rate): their activation operands are quantised to the same format where they are produced (LayerNorm -> MX, GELU epilogue ->
+ * MX), accumulation and the residual stream stay fp32, attention and attn.proj stay bf16.
+ * Both are narrower than the reference's precision: never the default; their price against fp32 is reported by tests/test_gpu_fp8.py. */
 #define SABER_WEIGHTS_BF16 0
 #define SABER_WEIGHTS_FP8_E4M3 1
+#define SABER_WEIGHTS_MXFP8 2
 int saber_engine_set_weight_format(saber_engine* e, int format);
 
 /* Arithmetic precision of the model (encoder + prompt / mask decoder; everything around them is fp32 or integer in either mode).

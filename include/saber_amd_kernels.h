@@ -87,6 +87,19 @@ int saber_k_dwconv7_t(const float* in, int H, int W, int C, const float* wt, con
 int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float* b, float* out, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False, antialias) of n planes, fused post transform: 0 none, 1 a*sigmoid(v)+c, 2 a*(v>0)+c, 3 a*v+c, 4 (v>=a) */
 int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream);
+/* MXFP8 GEMM on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 (row g-1): out = act(A . W^T + bias) (+ res).  Operands in the OCP MX
+ * format: e4m3fn elements ([M][lda] / [N][ldw] bytes, K contiguous, zero-padded to Kp, a multiple of 128) + one e8m0 scale byte per 32
+ * K-elements, stored K-step-major: S[Kp / 128][rows][4] (rows >= the operand's rows rounded up to the tile: 256 for A, 192 for W).
+ * Exactly one output: out_f32 (+ res, both with leading dimension ldc; out_bf16 may be given too and receives a copy) | out_bf16 | out_mx
+ * (+ out_mx_scales [N / 128][out_mx_rows][4]: the result as the next GEMM's MX operand, N % 128 == 0).  act: 0 none, 1 GELU. */
+int saber_k_gemm_mx(const uint8_t* A, int64_t lda, const uint8_t* SA, int64_t sa_rows, const uint8_t* W, int64_t ldw, const uint8_t* SW, int64_t sw_rows, const float* bias,
+                    const float* res, float* out_f32, uint16_t* out_bf16, uint8_t* out_mx, uint8_t* out_mx_scales, int64_t out_mx_rows, int64_t ldc, int64_t M, int N, int Kp,
+                    int act, void* stream);
+/* bf16 [M][C] -> MX (C % 32 == 0): per 32-element block the smallest power-of-two scale with amax <= 448 * scale, elements round to nearest even */
+int saber_k_quant_mx(const uint16_t* x, int64_t ldx, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* scales, int64_t scale_rows, int64_t M, void* stream);
+/* LayerNorm over C of fp32 rows, written straight as an MX operand */
+int saber_k_ln_mx(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* scales, int64_t scale_rows,
+                  int64_t M, void* stream);
 /* one-head attention of 256 channels, flash style (the memory attention of the video path, upstream MemoryAttentionLayer self / cross attention):
  * out = bf16(softmax(scale Q K^T) V + bias_v); Q [n_q][256], K, V [n_keys][256] bf16 row-major, n_q a multiple of 64; ws: scratch of at least
  * (n_q / 64) * 8 * 64 * 258 floats for the split over the keys, or NULL */

@@ -113,12 +113,30 @@ def attn_emul(q, k, v, scale: float, block: Optional[int]):
 
 
 # ----------------------------------------------------------------------------- Hiera-L encoder
-def hiera_block_emul(W, i, spec, x, tokens_per_image, eps):
-    """x: (B, N, din) fp32 residual stream, rows in engine order.  Returns (B, Nq, dout)."""
+def lin_mx(x_mx: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """engine MXFP8 GEMM (gemm_fp8.hip): both operands already carry MX-quantised values (exact products, fp32 accumulate), fp32 bias"""
+    y = F.linear(x_mx, w)
+    return y if b is None else y + b
+
+
+def hiera_block_emul(W, i, spec, x, tokens_per_image, eps, mx: bool = False, embed_dim: int = 144):
+    """x: (B, N, din) fp32 residual stream, rows in engine order.  Returns (B, Nq, dout).
+    mx: the MXFP8 weight format (engine.hip eng_encode): in stages 2 / 3 the LayerNorm outputs feeding qkv (blocks that keep their width)
+    and mlp.layers.0, and the GELU output feeding mlp.layers.1, are MX-quantised (oracle/fp8_ref.mx_quantise) instead of bf16-rounded;
+    W must hold the MX-quantised weights (fp8_ref.mx_quantise_encoder_weights)."""
     din, dout, heads, win, qs = spec
     p = f"image_encoder.trunk.blocks.{i}."
     B, N, _ = x.shape
     hd = dout // heads
+    mx_mlp = mx and dout >= 4 * embed_dim
+    mx_qkv = mx_mlp and din == dout
+    if mx_mlp:
+        from oracle.fp8_ref import mx_quantise
+    if mx_qkv:
+        xn8 = mx_quantise(ln(x, W[p + "norm1.weight"], W[p + "norm1.bias"], eps))[0]
+        qkv = bf(lin_mx(xn8, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"]))
+        shortcut = x
+        return _hiera_block_tail(W, p, spec, x, shortcut, qkv, eps, mx_mlp)
     xn = bf(ln(x, W[p + "norm1.weight"], W[p + "norm1.bias"], eps))
     if din != dout:
         sc = lin(xn, W[p + "proj.weight"], W[p + "proj.bias"])                       # fp32
@@ -126,6 +144,13 @@ def hiera_block_emul(W, i, spec, x, tokens_per_image, eps):
     else:
         shortcut = x
     qkv = bf(lin(xn, W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"]))             # stored bf16
+    return _hiera_block_tail(W, p, spec, x, shortcut, qkv, eps, mx_mlp)
+
+
+def _hiera_block_tail(W, p, spec, x, shortcut, qkv, eps, mx_mlp):
+    din, dout, heads, win, qs = spec
+    B, N, _ = x.shape
+    hd = dout // heads
     nk = win * win if win > 0 else N
     nwin = N // nk
     qkv = qkv.view(B * nwin, nk, 3, heads, hd)
@@ -140,14 +165,20 @@ def hiera_block_emul(W, i, spec, x, tokens_per_image, eps):
     a = attn_emul(q, k, v, hd ** -0.5, block)
     a = a.view(B * nwin, heads, nq, hd).permute(0, 2, 1, 3).reshape(B, nwin * nq, dout)
     x = shortcut + lin(a, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"])
+    if mx_mlp:
+        from oracle.fp8_ref import mx_quantise
+        y = mx_quantise(ln(x, W[p + "norm2.weight"], W[p + "norm2.bias"], eps))[0]
+        h = mx_quantise(gelu_fit(lin_mx(y, W[p + "mlp.layers.0.weight"], W[p + "mlp.layers.0.bias"])))[0]
+        return x + lin_mx(h, W[p + "mlp.layers.1.weight"], W[p + "mlp.layers.1.bias"])
     y = bf(ln(x, W[p + "norm2.weight"], W[p + "norm2.bias"], eps))
     h = bf(gelu_fit(lin(y, W[p + "mlp.layers.0.weight"], W[p + "mlp.layers.0.bias"])))
     return x + lin(h, W[p + "mlp.layers.1.weight"], W[p + "mlp.layers.1.bias"])
 
 
 @torch.no_grad()
-def encode_image_emul(W: Dict[str, torch.Tensor], cfg: HieraConfig, pixels: torch.Tensor):
-    """pixels (B,3,1024,1024) fp32 -> dict image_embed (B,256,64,64), feat_s0 (B,32,256,256), feat_s1 (B,64,128,128)."""
+def encode_image_emul(W: Dict[str, torch.Tensor], cfg: HieraConfig, pixels: torch.Tensor, mx: bool = False, taps: Optional[list] = None):
+    """pixels (B,3,1024,1024) fp32 -> dict image_embed (B,256,64,64), feat_s0 (B,32,256,256), feat_s1 (B,64,128,128).
+    mx: emulate the MXFP8 weight format (hiera_block_emul); taps: list that receives the residual stream after every block."""
     assert cfg.name == "large", "the bf16-emulating restatement covers Hiera-L only (no window padding)"
     from oracle.sam2_ref import hiera_pos_embed
     t = "image_encoder.trunk."
@@ -157,7 +188,9 @@ def encode_image_emul(W: Dict[str, torch.Tensor], cfg: HieraConfig, pixels: torc
     x = to_engine_order(x, 0)
     outs = []
     for i, spec in enumerate(cfg.block_specs()):
-        x = hiera_block_emul(W, i, spec, x, x.shape[1], cfg.ln_eps)
+        x = hiera_block_emul(W, i, spec, x, x.shape[1], cfg.ln_eps, mx=mx, embed_dim=cfg.embed_dim)
+        if taps is not None:
+            taps.append(x)
         if i in cfg.stage_ends:
             outs.append(bf(x))                                                          # sb[stage]: bf16 copy of the stream
     nk = "image_encoder.neck.convs."

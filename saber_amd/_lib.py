@@ -111,6 +111,9 @@ SIGNATURES = {
     "saber_k_dwconv7_t": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "saber_k_gemm_mx": (_i, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _vp]),
+    "saber_k_quant_mx": (_i, [_vp, C.c_int64, _i, _vp, C.c_int64, _i, _vp, C.c_int64, C.c_int64, _vp]),
+    "saber_k_ln_mx": (_i, [_vp, C.c_int64, _vp, _vp, _f, _i, _vp, C.c_int64, _i, _vp, C.c_int64, C.c_int64, _vp]),
     "saber_k_flash256": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, C.c_int64, _vp]),
     "saber_k_gauss_mirror": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_double, _vp]),
     "saber_k_axpy": (_i, [_vp, _vp, _vp, _f, C.c_int64, _i, _vp, _vp]),

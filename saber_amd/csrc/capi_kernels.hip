@@ -150,6 +150,22 @@ extern "C" int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, 
 extern "C" int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream) {
     return kcheck(launch_resize_plane(in, n_planes, H, W, out, Ho, Wo, antialias, post, a, c, (hipStream_t)stream));
 }
+extern "C" int saber_k_gemm_mx(const uint8_t* A, int64_t lda, const uint8_t* SA, int64_t sa_rows, const uint8_t* W, int64_t ldw, const uint8_t* SW, int64_t sw_rows, const float* bias,
+                               const float* res, float* out_f32, uint16_t* out_bf16, uint8_t* out_mx, uint8_t* out_mx_scales, int64_t out_mx_rows, int64_t ldc, int64_t M, int N, int Kp,
+                               int act, void* stream) {
+    GemmMxParams p;
+    p.A = A; p.lda = lda; p.SA = SA; p.sa_rows = sa_rows; p.W = W; p.ldw = ldw; p.SW = SW; p.sw_rows = sw_rows; p.bias = bias;
+    p.res = res; p.ldres = ldc; p.Cf = out_f32; p.ldcf = ldc; p.Cb = out_bf16; p.ldcb = ldc; p.C8 = out_mx; p.ldc8 = ldc; p.SC = out_mx_scales; p.sc_rows = out_mx_rows;
+    p.M = M; p.N = N; p.Kp = Kp; p.act = act;
+    return kcheck(launch_gemm_mx(p, (hipStream_t)stream));
+}
+extern "C" int saber_k_quant_mx(const uint16_t* x, int64_t ldx, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* scales, int64_t scale_rows, int64_t M, void* stream) {
+    return kcheck(launch_quant_mx_bf16(x, ldx, C, out, ldo, Kp, scales, scale_rows, M, (hipStream_t)stream));
+}
+extern "C" int saber_k_ln_mx(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* scales,
+                             int64_t scale_rows, int64_t M, void* stream) {
+    return kcheck(launch_ln_mx(x, ldx, gamma, beta, eps, C, out, ldo, Kp, scales, scale_rows, M, (hipStream_t)stream));
+}
 extern "C" int saber_k_flash256(const uint16_t* Q, const uint16_t* K, const uint16_t* V, int n_q, int n_keys, float scale, const float* bias_v, uint16_t* out, float* ws,
                                 int64_t ws_floats, void* stream) {
     return kcheck(launch_flash256(Q, K, V, n_q, n_keys, scale, bias_v, out, ws, (size_t)ws_floats, (hipStream_t)stream));

@@ -14,7 +14,8 @@ struct BlockSpec { int din, dout, heads, window, q_stride; };
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
-struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; const float* wf = nullptr; };   // wf: dense fp32 [out][in] copy, kept only when the exact-precision mode was requested before finalize (exact.hip)   // wpk: K-step-packed copy (gemm_rowln.hip)  // rows zero-padded to ldw = ceil(in/64)*64
+struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; const float* wf = nullptr;
+              const uint8_t* w8 = nullptr; const uint8_t* sw8 = nullptr; int kp8 = 0, sw_rows = 0; };   // w8 / sw8: MXFP8 copy (e4m3 [out][kp8] + e8m0 [kp8 / 128][sw_rows][4], gemm_fp8.hip), weight format SABER_WEIGHTS_MXFP8 only   // wf: dense fp32 [out][in] copy, kept only when the exact-precision mode was requested before finalize (exact.hip)   // wpk: K-step-packed copy (gemm_rowln.hip)  // rows zero-padded to ldw = ceil(in/64)*64
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
 
 struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
@@ -77,6 +78,7 @@ struct saber_engine {
     // encoder workspace
     float *pix = nullptr, *xa = nullptr, *xb = nullptr, *lat3 = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    uint8_t *xn8_s = nullptr, *hid8_s = nullptr; int64_t mx_rows = 0;   // MXFP8 weight format: scale panels of the MX activations (their e4m3 bytes reuse xn / hid); mx_rows = panel rows
     bf16_t* sb[4] = {nullptr, nullptr, nullptr, nullptr};
     int* crops_dev = nullptr;
     // resident features per slot

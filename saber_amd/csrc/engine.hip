@@ -131,7 +131,7 @@ void eng_graphs_flush(saber_engine* e) {
 extern "C" int saber_engine_set_weight_format(saber_engine* e, int format) {
     if (!e) return SABER_ERR_INVALID;
     if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "set_weight_format after finalize");
-    if (format != SABER_WEIGHTS_BF16 && format != SABER_WEIGHTS_FP8_E4M3) return eng_fail(e, SABER_ERR_INVALID, "set_weight_format: unknown format");
+    if (format != SABER_WEIGHTS_BF16 && format != SABER_WEIGHTS_FP8_E4M3 && format != SABER_WEIGHTS_MXFP8) return eng_fail(e, SABER_ERR_INVALID, "set_weight_format: unknown format");
     e->weight_format = format;
     return SABER_OK;
 }
@@ -282,11 +282,56 @@ struct Finalizer {
             for (int c = 0; c < cols; ++c) w[(size_t)r * cols + c] = e4m3_round(w[(size_t)r * cols + c] / scale) * scale;
         }
     }
+    // MXFP8 weight format (SABER_WEIGHTS_MXFP8): e4m3 elements + one e8m0 scale per 32 K-elements, the operand format of
+    // v_mfma_scale_f32_16x16x128_f8f6f4 (gemm_fp8.hip; the rule of oracle/fp8_ref.py: mx_quantise).  w is replaced by the de-quantised
+    // values (exact in bf16), so every other path of the engine (bf16 kernels, exact mode) sees the same weights.
+    bool mx8 = false;
+    static uint8_t e4m3_byte(float q) {          // q already on the e4m3 grid, |q| <= 448
+        const float a = std::fabs(q);
+        if (!(a > 0.f)) return 0;
+        int ex; const float f = std::frexp(a, &ex);            // a = f 2^ex, f in [0.5, 1)
+        const int E = ex - 1;
+        uint8_t body;
+        if (E < -6) body = (uint8_t)std::lrint(std::ldexp(a, 9));                                   // subnormal: multiples of 2^-9
+        else body = (uint8_t)(((E + 7) << 3) | (int)std::lrint((f * 2.0f - 1.0f) * 8.0f));
+        return (q < 0.f ? 0x80 : 0) | body;
+    }
+    void quantise_mx(LinW* l, std::vector<float>& w, int rows, int cols) {
+        const int kp = (cols + 127) / 128 * 128, rp = (rows + 191) / 192 * 192, nb = cols / 32;
+        if (cols % 32) { status = eng_fail(e, SABER_ERR_INVALID, "mxfp8: weight K must be a multiple of 32"); return; }
+        std::vector<uint8_t> q((size_t)rows * kp, 0), sc((size_t)(kp / 128) * rp * 4, 127);
+        for (int r = 0; r < rows; ++r)
+            for (int b = 0; b < nb; ++b) {
+                float* v = &w[(size_t)r * cols + 32 * b];
+                float mx = 0.f;
+                for (int k = 0; k < 32; ++k) mx = std::max(mx, std::fabs(v[k]));
+                int ex = -127;
+                if (mx > 0.f) {
+                    int fe; const float f = std::frexp(mx, &fe);                                      // mx = f 2^fe
+                    ex = std::max(fe - 1 - 8 + (f * 2.0f > 1.75f ? 1 : 0), -127);
+                }
+                for (int k = 0; k < 32; ++k) {
+                    const float qv = e4m3_round(std::ldexp(v[k], -ex));
+                    q[(size_t)r * kp + 32 * b + k] = e4m3_byte(qv);
+                    v[k] = std::ldexp(qv, ex);
+                }
+                sc[((size_t)(b >> 2) * rp + r) * 4 + (b & 3)] = (uint8_t)(ex + 127);
+            }
+        void* d = nullptr;
+        status = eng_alloc_bytes(e, &d, q.size());
+        if (status == SABER_OK && hipMemcpy(d, q.data(), q.size(), hipMemcpyHostToDevice) != hipSuccess) status = eng_fail(e, SABER_ERR_HIP, "weight upload failed");
+        l->w8 = (const uint8_t*)d;
+        if (status != SABER_OK) return;
+        status = eng_alloc_bytes(e, &d, sc.size());
+        if (status == SABER_OK && hipMemcpy(d, sc.data(), sc.size(), hipMemcpyHostToDevice) != hipSuccess) status = eng_fail(e, SABER_ERR_HIP, "weight upload failed");
+        l->sw8 = (const uint8_t*)d; l->kp8 = kp; l->sw_rows = rp;
+    }
     // [rows][cols] fp32 -> bf16 with every row zero-padded to a multiple of 64 (direct-to-LDS GEMM contract)
     void up_lin(LinW* l, const std::vector<float>& w_in, int rows, int cols) {
         std::vector<float> wq;
         if (q8) { wq = w_in; quantise_rows_e4m3(wq, rows, cols); }
-        const std::vector<float>& w = q8 ? wq : w_in;
+        if (mx8) { wq = w_in; quantise_mx(l, wq, rows, cols); if (status != SABER_OK) return; }
+        const std::vector<float>& w = (q8 || mx8) ? wq : w_in;
         const int ld = (cols + 63) / 64 * 64;
         std::vector<float> padded((size_t)rows * ld, 0.0f);
         for (int r = 0; r < rows; ++r) std::copy(w.begin() + (size_t)r * cols, w.begin() + (size_t)(r + 1) * cols, padded.begin() + (size_t)r * ld);
@@ -403,12 +448,17 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         BlockW& w = e->bw[i];
         w.n1 = F.ln(b + "norm1", bs.din);
         F.q8 = e->weight_format == SABER_WEIGHTS_FP8_E4M3 && bs.dout >= 4 * e->embed_dim;      // stages 2 and 3: 94 % of the encoder's weights
+        // MXFP8: the GEMMs that run on the fp8 MFMA (stages 2 and 3: qkv of the blocks that keep their width, both MLP layers of all)
+        const bool mxs = e->weight_format == SABER_WEIGHTS_MXFP8 && bs.dout >= 4 * e->embed_dim;
+        F.mx8 = mxs && bs.din == bs.dout;
         w.qkv = F.lin(b + "attn.qkv", 3 * bs.dout, bs.din);
+        F.mx8 = false;
         w.proj = F.lin(b + "attn.proj", bs.dout, bs.dout);
         w.n2 = F.ln(b + "norm2", bs.dout);
+        F.mx8 = mxs;
         w.fc1 = F.lin(b + "mlp.layers.0", 4 * bs.dout, bs.dout);
         w.fc2 = F.lin(b + "mlp.layers.1", bs.dout, 4 * bs.dout);
-        F.q8 = false;                                   // (the stage-transition shortcut projection stays bf16)
+        F.q8 = false; F.mx8 = false;                    // (the stage-transition shortcut projection stays bf16)
         if (bs.din != bs.dout) w.sc = F.lin(b + "proj", bs.dout, bs.din);
         if (F.status != SABER_OK) return F.status;
         // qkv / fc1 run on the persistent 256x256 kernel: the same K-step-packed copy makes each of its W pieces one contiguous KB
@@ -628,6 +678,13 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     TRY(eng_alloc(e, &e->qkv, B * 65536 * 6 * C0s));
     TRY(eng_alloc(e, &e->att, B * 65536 * C0s));
     TRY(eng_alloc(e, &e->hid, B * 65536 * 4 * C0s));
+    if (e->weight_format == SABER_WEIGHTS_MXFP8) {
+        if (e->padded) return eng_fail(e, SABER_ERR_INVALID, "the MXFP8 weight format is built for the unpadded trunk layout (Hiera-L, BASELINE configs[4])");
+        // scale panels of the MX activations (K-step-major, [K / 128][mx_rows][4]); the e4m3 bytes themselves reuse xn / hid
+        e->mx_rows = (int64_t)((B * 4096 + 255) / 256 * 256);
+        TRY(eng_alloc(e, &e->xn8_s, (size_t)(8 * C0s / 128 + 1) * e->mx_rows * 4));
+        TRY(eng_alloc(e, &e->hid8_s, (size_t)(32 * C0s / 128 + 1) * e->mx_rows * 4));
+    }
     for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &e->sb[s], B * e->tok_rows[s] * (C0s << s)));
     TRY(eng_alloc(e, &e->lat3, B * e->tok_rows[3] * 256));
     TRY(eng_alloc(e, &e->crops_dev, B * 4));
@@ -779,6 +836,14 @@ extern "C" int saber_prepare_rgb(saber_engine* e, const float* img_dev, int H, i
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
+static inline int mx_kp(int k) { return (k + 127) / 128 * 128; }
+static GemmMxParams mk_gemm_mx(saber_engine* e, const uint8_t* A, const uint8_t* SA, int64_t M, const LinW& l) {
+    GemmMxParams g;
+    g.A = A; g.lda = l.kp8; g.SA = SA; g.sa_rows = e->mx_rows; g.W = l.w8; g.ldw = l.kp8; g.SW = l.sw8; g.sw_rows = l.sw_rows; g.bias = l.b;
+    g.M = M; g.N = l.out; g.Kp = l.kp8;
+    return g;
+}
+
 int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crops_host, int n, int slot0, hipStream_t s) {
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
     if (!img_dev || !crops_host || n < 1 || n > e->max_images || slot0 < 0 || slot0 + n > e->max_images)
@@ -826,6 +891,8 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
     // the tensor in between is larger than the cache: qkv (297 MB in stage 3) -> window attention 10.73 -> 10.23 ms per slice; neutral
     // for the GEMM consumers.  Development flag 512 restores the forward walks.
     const int snake = (g_saber_debug_flags & 512) ? 0 : 1;
+    uint8_t* const xn8 = reinterpret_cast<uint8_t*>(e->xn);     // MX activations (weight format MXFP8) live in the bf16 buffers they replace
+    uint8_t* const hid8 = reinterpret_cast<uint8_t*>(e->hid);
     for (size_t i = 0; i < nblocks; ++i) {
         const BlockSpec& bs = e->blocks[i];
         const BlockW& w = e->bw[i];
@@ -840,7 +907,11 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             xres = xalt;
             Nq = N / 4;
         }
-        {
+        if (w.qkv.w8) {      // MXFP8: xn arrived as an MX operand (ln_mx below / at the end of the previous block)
+            GemmMxParams g = mk_gemm_mx(e, xn8, e->xn8_s, N, w.qkv);
+            g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * w.qkv.in, (double)g.M * (g.Kp + 2.0 * g.N), launch_gemm_mx(g, s));
+        } else {
             GemmParams g = mk_gemm(e->xn, bs.din, N, w.qkv);
             g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
             g.rev = snake;               // attention walks forward: it starts on the rows qkv wrote last
@@ -856,7 +927,11 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             g.Cf = xres; g.ldcf = bs.dout; g.res = xres; g.ldres = bs.dout;
             g.ln_gamma = w.n2.g; g.ln_beta = w.n2.b; g.ln_eps = 1e-6f; g.ln_out = e->xn; g.ldln = bs.dout;
             g.rev = snake;               // against the attention kernel that wrote its operand
-            if (fuse && gemm_rowln_supported(g)) {
+            if (w.fc1.w8) {  // MXFP8 MLP: norm2 is written straight as the MX operand of mlp.layers.0
+                g.ln_gamma = nullptr; g.ln_beta = nullptr; g.ln_out = nullptr;
+                ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
+                ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, launch_ln_mx(xres, bs.dout, w.n2.g, w.n2.b, 1e-6f, bs.dout, xn8, mx_kp(bs.dout), mx_kp(bs.dout), e->xn8_s, e->mx_rows, Nq, s));
+            } else if (fuse && gemm_rowln_supported(g)) {
                 ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g, true), launch_gemm_rowln(g, s));
             } else {
                 ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
@@ -864,14 +939,29 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             }
         }
         if (bs.din != bs.dout) { std::swap(x, xalt); tokens /= 4; ++stage; }
-        {
+        if (w.fc1.w8) {      // hidden activations leave the epilogue as the MX operand of mlp.layers.1
+            GemmMxParams g = mk_gemm_mx(e, xn8, e->xn8_s, Nq, w.fc1);
+            g.C8 = hid8; g.ldc8 = 4 * bs.dout; g.SC = e->hid8_s; g.sc_rows = e->mx_rows; g.act = ACT_GELU;
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * w.fc1.in, (double)g.M * (g.Kp + 1.0 * g.N), launch_gemm_mx(g, s));
+        } else {
             GemmParams g = mk_gemm(e->xn, bs.dout, Nq, w.fc1);
             g.Cb = e->hid; g.ldcb = 4 * bs.dout; g.act = ACT_GELU;
             ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
         }
         const bool to_padded = e->padded && bs.din != bs.dout && stage == 2;
         const bool has_next = i + 1 < nblocks;
-        {
+        if (w.fc2.w8) {
+            GemmMxParams g = mk_gemm_mx(e, hid8, e->hid8_s, Nq, w.fc2);
+            g.Cf = x; g.ldcf = bs.dout; g.res = x; g.ldres = bs.dout;
+            if ((int)i == e->stage_ends[stage]) { g.Cb = e->sb[stage]; g.ldcb = bs.dout; }
+            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * w.fc2.in, (double)g.M * (g.Kp + 8.0 * g.N), launch_gemm_mx(g, s));
+            if (has_next) {   // norm1 of the next block: as an MX operand when its qkv runs on the fp8 MFMA, bf16 for the stage-transition block
+                if (e->bw[i + 1].qkv.w8)
+                    ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, launch_ln_mx(x, bs.dout, e->bw[i + 1].n1.g, e->bw[i + 1].n1.b, 1e-6f, bs.dout, xn8, mx_kp(bs.dout), mx_kp(bs.dout), e->xn8_s, e->mx_rows, Nq, s));
+                else
+                    ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, e->bw[i + 1].n1, 1e-6f, n * tokens, bs.dout, nullptr, e->xn, ACT_NONE, s));
+            }
+        } else {
             GemmParams g = mk_gemm(e->hid, 4 * bs.dout, Nq, w.fc2);
             g.Cf = x; g.ldcf = bs.dout; g.res = x; g.ldres = bs.dout;
             g.rev = snake;               // fc1 walked forward: the last 256 MB of the hidden tensor are still in the Infinity Cache

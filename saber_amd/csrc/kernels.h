@@ -47,6 +47,27 @@ const char* gemm_w1_init_device();
 size_t gemm_rowln_packed_elems(int N, int K);
 const char* launch_pack_w_kstep(const bf16_t* W, int ldw, int N, int K, bf16_t* out, hipStream_t s);
 
+// ------------------------------------------------------------------ gemm_fp8.hip
+// C = act((A8 . W8^T) * sa[m] * sw[n] + bias) (+ res): e4m3 operands on the block-scaled fp8 MFMA, see the file header
+struct GemmMxParams {
+    const uint8_t* A = nullptr; int64_t lda = 0;      // [M][lda] e4m3, rows zero-padded to Kp
+    const uint8_t* SA = nullptr; int64_t sa_rows = 0; // e8m0 block scales [Kp / 128][sa_rows][4], sa_rows >= ceil(M / 256) * 256
+    const uint8_t* W = nullptr; int64_t ldw = 0;      // [N][ldw] e4m3, rows zero-padded to Kp
+    const uint8_t* SW = nullptr; int64_t sw_rows = 0; // [Kp / 128][sw_rows][4], sw_rows >= ceil(N / 192) * 192
+    const float* bias = nullptr;
+    // exactly one output form: bf16 (Cb alone) | MX (C8 + SC: e4m3 [M][ldc8] + [N / 128][sc_rows][4], the next GEMM's A operand) | fp32 + residual (Cf, + optional bf16 copy Cb)
+    bf16_t* Cb = nullptr; int64_t ldcb = 0;
+    uint8_t* C8 = nullptr; int64_t ldc8 = 0; uint8_t* SC = nullptr; int64_t sc_rows = 0;
+    float* Cf = nullptr; int64_t ldcf = 0; const float* res = nullptr; int64_t ldres = 0;
+    int64_t M = 0; int N = 0, Kp = 0, act = ACT_NONE;
+};
+const char* launch_gemm_mx(const GemmMxParams& p, hipStream_t s);
+// bf16 [M][C] -> MX: e4m3 [M][Kp] (zero-padded) + e8m0 block scales SC[Kp / 128][sc_rows][4]
+const char* launch_quant_mx_bf16(const bf16_t* x, int64_t ldx, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* SC, int64_t sc_rows, int64_t M, hipStream_t s);
+// LayerNorm of fp32 rows straight into MX
+const char* launch_ln_mx(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* SC, int64_t sc_rows,
+                         int64_t M, hipStream_t s);
+
 // ------------------------------------------------------------------ layernorm.hip
 struct LayerNormParams {
     const float* x = nullptr; int64_t ldx = 0;

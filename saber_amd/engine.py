@@ -44,11 +44,11 @@ class Engine:
             raise (ValueError if st == -1 else RuntimeError)(msg)
         self.h = h
         self.max_images, self.max_prompts = max_images, max_prompts
-        if weight_format not in ("bf16", "fp8"):
-            raise ValueError(f"weight_format must be 'bf16' or 'fp8', got '{weight_format}'")
+        if weight_format not in ("bf16", "fp8", "mxfp8"):
+            raise ValueError(f"weight_format must be 'bf16', 'fp8' or 'mxfp8', got '{weight_format}'")
         self.weight_format = weight_format
-        if weight_format == "fp8":       # e4m3 stage-2/3 block weights (include/saber_amd.h: saber_engine_set_weight_format)
-            self._check(self.lib.saber_engine_set_weight_format(self.h, 1))
+        if weight_format != "bf16":      # fp8: e4m3 storage of the stage-2/3 block weights; mxfp8: MX operands on the fp8 MFMA (include/saber_amd.h: saber_engine_set_weight_format)
+            self._check(self.lib.saber_engine_set_weight_format(self.h, {"fp8": 1, "mxfp8": 2}[weight_format]))
         if precision not in ("bf16", "exact"):
             raise ValueError(f"precision must be 'bf16' or 'exact', got '{precision}'")
         self.precision = precision
