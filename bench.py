@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--max-prompts", type=int, default=1024, help="prompts decoded per batched pass")
     ap.add_argument("--workers", type=int, default=2, help="engine handles per GPU, each on its own thread and HIP stream, slices dealt round-robin "
                     "(the reference's GPUPool runs one thread per GPU; kernels of two slices in flight fill each other's idle issue slots)")
-    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16", help="fp8: e4m3 weights (per-row power-of-two scales) for the stage-2/3 block GEMMs, "
+    ap.add_argument("--dtype", choices=("bf16", "fp8", "mxfp8"), default="bf16", help="fp8: e4m3 weights (per-row power-of-two scales) for the stage-2/3 block GEMMs, "
                     "bf16 activations and MFMA operands, fp32 accumulate (BASELINE configs[4]); a SEPARATE line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -300,12 +300,15 @@ def main():
         out = {
             "metric": "EM slices/sec (1024^2, Hiera-L)", "value": world * a.steps / dt, "unit": "slices/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "bf16 operands, e4m3 weights (stage-2/3 block GEMMs)", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp8": "bf16 operands, e4m3 weights (stage-2/3 block GEMMs)",
+                                         "mxfp8": "mxfp8 operands on the fp8 MFMA (qkv / fc1 / fc2 of stages 2-3), bf16 elsewhere"}[a.dtype], "data": "synthetic",
             "config": {"workload": f"1024x1024 uint16 EM slice -> prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults: npoints={a.npoints}, "
                                    f"crop_n_layers={a.crop_n_layers} -> {n_crops} crops, {n_first} grid prompts + {3 * n_first} m2m refinements, multimask) "
                                    f"-> dedup/sort -> uint16 label plane; BASELINE configs[1]",
-                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)" + ("" if a.dtype == "bf16" else "; qkv / proj / fc1 / fc2 of stages 2-3 quantised to OCP e4m3fn with "
-                                  "per-row power-of-two scales at load, expanded to bf16 MFMA operands (no fp8-operand kernel is built: the roofline stays the bf16 one)"), "slices_per_rank": a.steps, "engine_handles_per_gpu": a.workers,
+                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)" + {"bf16": "", "fp8": "; qkv / proj / fc1 / fc2 of stages 2-3 quantised to OCP e4m3fn with "
+                                  "per-row power-of-two scales at load, expanded to bf16 MFMA operands (storage format: the roofline stays the bf16 one)",
+                                  "mxfp8": "; qkv (blocks that keep their width) / fc1 / fc2 of stages 2-3 in OCP MXFP8 (e4m3 + e8m0 per 32 K-elements), activations quantised to the same "
+                                  "format where produced, products on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE configs[4]); NOT the headline precision"}[a.dtype], "slices_per_rank": a.steps, "engine_handles_per_gpu": a.workers,
                        "parallelism": (f"REHEARSAL on one GPU (gloo), not a multi-GPU measurement, x{world}" if rehearsal else
                                        f"WEAK scaling: every one of the {world} ranks (one process per GPU) segments its own {a.steps} slices "
                                        f"(slices are independent units, no data-path collective); one RCCL all_gather of the {world} x {a.steps} uint16 "
@@ -364,6 +367,16 @@ def main():
                            # round-to-round comparable form: since round 2 the class's time contains the LayerNorm work that round 1 ran as
                            # separate layernorm-class launches (same FLOPs); FLOPs over (gemm + layernorm) class time: r01 0.204, see DESIGN.md 4
                            "frac_with_layernorm_class": (g["flops"] / ((g["ms"] + prof["layernorm"]["ms"]) * 1e-3) / 1e12 / 2500.0) if g["ms"] > 0 else None}
+        if a.dtype == "mxfp8":
+            # the fp8-MFMA line's own roofline: the MXFP8 GEMM launches against the dense fp8 peak; the bf16 class keeps its key
+            g8 = prof["gemm_mxfp8"]
+            ach8 = g8["flops"] / (g8["ms"] * 1e-3) / 1e12 if g8["ms"] > 0 else 0.0
+            out["roofline_bf16_gemms"] = out["roofline"]
+            out["roofline"] = {"bound": "mfma", "achieved": ach8, "peak": 5000.0, "unit": "TFLOP/s", "frac": ach8 / 5000.0, "traffic": None,
+                               "kernel": "gemm_mx_kernel (csrc/gemm_fp8.hip: v_mfma_scale_f32_16x16x128_f8f6f4, persistent 256x192 tiles)", "launches_per_slice": g8["launches"],
+                               "avg_launch_us": g8["ms"] * 1e3 / max(1, g8["launches"]), "algorithmic_gflop_per_launch": g8["flops"] / max(1, g8["launches"]) / 1e9,
+                               "kernel_ms_per_slice": g8["ms"], "share_of_kernel_time": g8["ms"] / total_ms if total_ms else None,
+                               "note": "dense fp8 peak 5 PFLOP/s; HBM traffic counters are collected for the headline (bf16) configuration only"}
         out["kernel_classes_ms_per_slice"] = {k: round(v["ms"], 3) for k, v in prof.items()}
         out["kernel_classes_launches"] = {k: v["launches"] for k, v in prof.items()}
         mp = prof["mask_post"]

@@ -244,9 +244,10 @@ int saber_classifier_get_crops(saber_classifier* c, int n, float* crops_out_dev,
 
 /* Per-launch HIP-event profiling of the engine's own kernels, by kernel class (events are recorded on the
  * stream the kernels are launched on).  Class order: 0 gemm_bf16, 1 hiera_attention, 2 layernorm,
- * 3 decoder_attention, 4 elementwise, 5 image_ops, 6 mask_post, 7 decoder_t2i, 8 decoder_i2t, 9 decoder_upscale.  flops / bytes are ALGORITHMIC. */
+ * 3 decoder_attention, 4 elementwise, 5 image_ops, 6 mask_post, 7 decoder_t2i, 8 decoder_i2t, 9 decoder_upscale, 10 gemm_mxfp8 (the GEMMs on the
+ * fp8 MFMA, weight format SABER_WEIGHTS_MXFP8 only).  flops / bytes are ALGORITHMIC. */
 typedef struct saber_profile_class { int64_t launches; double ms; double flops; double bytes; } saber_profile_class;
-#define SABER_PROFILE_CLASSES 10
+#define SABER_PROFILE_CLASSES 11
 int saber_profile_begin(saber_engine* e);
 int saber_profile_end(saber_engine* e, saber_profile_class* out, int n_classes);
 

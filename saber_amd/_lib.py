@@ -45,7 +45,7 @@ class ProfileClass(C.Structure):
     _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-PROFILE_CLASSES = ("gemm_bf16", "hiera_attention", "layernorm", "decoder_attention", "elementwise", "image_ops", "mask_post", "decoder_t2i", "decoder_i2t", "decoder_upscale")
+PROFILE_CLASSES = ("gemm_bf16", "hiera_attention", "layernorm", "decoder_attention", "elementwise", "image_ops", "mask_post", "decoder_t2i", "decoder_i2t", "decoder_upscale", "gemm_mxfp8")
 
 # name -> (restype, argtypes); mirrors include/*.h one-to-one (tests/test_abi.py checks the symbol list)
 _vp, _i, _f, _i64p = C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_int64)

@@ -23,7 +23,7 @@ struct BlockW { LnW n1, n2; LinW qkv, proj, fc1, fc2, sc; };
 struct AttnW { LinW q, k, v, o; const bf16_t* pe_proj = nullptr; const bf16_t* img_wT = nullptr; };  // img_wT: the image-side projection weight transposed, bf16 [256][128] (k_proj of tokens->image, q_proj of image->tokens): operand of the folds in decoder_tokens.hip  // pe_proj: dense PE projected by the image-side weight (k: tokens->image, q: image->tokens), bf16 [4096][128]
 struct DecLayerW { AttnW self_attn, t2i, i2t; LnW n1, n2, n3, n4; LinW mlp1, mlp2; };
 
-enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_DEC_T2I, PC_DEC_I2T, PC_DEC_UPSCALE, PC_N };
+enum { PC_GEMM = 0, PC_HIERA_ATTN, PC_LAYERNORM, PC_DEC_ATTN, PC_ELEMENTWISE, PC_IMAGE, PC_MASK_POST, PC_DEC_T2I, PC_DEC_I2T, PC_DEC_UPSCALE, PC_GEMM_MX, PC_N };
 struct ProfRec { int cls; double flops; double bytes; hipEvent_t a, b; };
 
 struct saber_engine {

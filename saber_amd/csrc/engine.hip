@@ -910,7 +910,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         if (w.qkv.w8) {      // MXFP8: xn arrived as an MX operand (ln_mx below / at the end of the previous block)
             GemmMxParams g = mk_gemm_mx(e, xn8, e->xn8_s, N, w.qkv);
             g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * w.qkv.in, (double)g.M * (g.Kp + 2.0 * g.N), launch_gemm_mx(g, s));
+            ENG_KP(e, PC_GEMM_MX, 2.0 * g.M * (double)g.N * w.qkv.in, (double)g.M * (g.Kp + 2.0 * g.N), launch_gemm_mx(g, s));
         } else {
             GemmParams g = mk_gemm(e->xn, bs.din, N, w.qkv);
             g.Cb = e->qkv; g.ldcb = 3 * bs.dout;
@@ -942,7 +942,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         if (w.fc1.w8) {      // hidden activations leave the epilogue as the MX operand of mlp.layers.1
             GemmMxParams g = mk_gemm_mx(e, xn8, e->xn8_s, Nq, w.fc1);
             g.C8 = hid8; g.ldc8 = 4 * bs.dout; g.SC = e->hid8_s; g.sc_rows = e->mx_rows; g.act = ACT_GELU;
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * w.fc1.in, (double)g.M * (g.Kp + 1.0 * g.N), launch_gemm_mx(g, s));
+            ENG_KP(e, PC_GEMM_MX, 2.0 * g.M * (double)g.N * w.fc1.in, (double)g.M * (g.Kp + 1.0 * g.N), launch_gemm_mx(g, s));
         } else {
             GemmParams g = mk_gemm(e->xn, bs.dout, Nq, w.fc1);
             g.Cb = e->hid; g.ldcb = 4 * bs.dout; g.act = ACT_GELU;
@@ -954,7 +954,7 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
             GemmMxParams g = mk_gemm_mx(e, hid8, e->hid8_s, Nq, w.fc2);
             g.Cf = x; g.ldcf = bs.dout; g.res = x; g.ldres = bs.dout;
             if ((int)i == e->stage_ends[stage]) { g.Cb = e->sb[stage]; g.ldcb = bs.dout; }
-            ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * w.fc2.in, (double)g.M * (g.Kp + 8.0 * g.N), launch_gemm_mx(g, s));
+            ENG_KP(e, PC_GEMM_MX, 2.0 * g.M * (double)g.N * w.fc2.in, (double)g.M * (g.Kp + 8.0 * g.N), launch_gemm_mx(g, s));
             if (has_next) {   // norm1 of the next block: as an MX operand when its qkv runs on the fp8 MFMA, bf16 for the stage-transition block
                 if (e->bw[i + 1].qkv.w8)
                     ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, launch_ln_mx(x, bs.dout, e->bw[i + 1].n1.g, e->bw[i + 1].n1.b, 1e-6f, bs.dout, xn8, mx_kp(bs.dout), mx_kp(bs.dout), e->xn8_s, e->mx_rows, Nq, s));

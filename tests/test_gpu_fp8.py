@@ -166,7 +166,8 @@ def test_mxfp8_engine_vs_oracle_quantising_at_the_same_points(large_weights):
         e_emul, e_fp32, b_fp32, w_fp32, bf_fp32 = rel_rms(g8[k], emul[k][0]), rel_rms(g8[k], f0[k][0]), rel_rms(emul[k][0], f0[k][0]), rel_rms(fq[k][0], f0[k][0]), rel_rms(g16[k], f0[k][0])
         print(f"{k}: mxfp8 engine vs MX emulation {e_emul:.3e} (emulation's realisation spread {MX_SPREAD[k]:.1e}); vs fp32 oracle: mxfp8 engine {e_fp32:.3e}, "
               f"MX emulation {b_fp32:.3e}, MX weights alone (fp32 arithmetic) {w_fp32:.3e}, bf16 engine {bf_fp32:.3e}")
-        assert e_emul < 2 * MX_SPREAD[k]
+        if k == "image_embed":                                        # (the two high-resolution features leave the trunk before stage 2: equality with the bf16 engine below)
+            assert e_emul < 2 * MX_SPREAD[k]
         assert e_fp32 < 1.15 * b_fp32 + 1e-4                          # no further from fp32 than the emulation is
     # feat_s0 / feat_s1 leave the trunk before stage 2: the format must not touch them
     assert rel_rms(g8["feat_s0"], g16["feat_s0"]) < 1e-6 and rel_rms(g8["feat_s1"], g16["feat_s1"]) < 1e-6
