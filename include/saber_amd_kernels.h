@@ -89,7 +89,7 @@ int saber_k_conv4x4s4(const float* in, int H, int W, const float* w, const float
 int saber_k_resize_plane(const float* in, int n_planes, int H, int W, float* out, int Ho, int Wo, int antialias, int post, float a, float c, void* stream);
 /* MXFP8 GEMM on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 (row g-1): out = act(A . W^T + bias) (+ res).  Operands in the OCP MX
  * format: e4m3fn elements ([M][lda] / [N][ldw] bytes, K contiguous, zero-padded to Kp, a multiple of 128) + one e8m0 scale byte per 32
- * K-elements, stored K-step-major: S[Kp / 128][rows][4] (rows >= the operand's rows rounded up to the tile: 256 for A, 192 for W).
+ * K-elements, stored K-step-major: S[Kp / 128][rows][4] (rows >= the operand's rows rounded up to whole tiles: a multiple of 768 for A, of 192 for W).
  * Exactly one output: out_f32 (+ res, both with leading dimension ldc; out_bf16 may be given too and receives a copy) | out_bf16 | out_mx
  * (+ out_mx_scales [N / 128][out_mx_rows][4]: the result as the next GEMM's MX operand, N % 128 == 0).  act: 0 none, 1 GELU. */
 int saber_k_gemm_mx(const uint8_t* A, int64_t lda, const uint8_t* SA, int64_t sa_rows, const uint8_t* W, int64_t ldw, const uint8_t* SW, int64_t sw_rows, const float* bias,

@@ -681,7 +681,7 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     if (e->weight_format == SABER_WEIGHTS_MXFP8) {
         if (e->padded) return eng_fail(e, SABER_ERR_INVALID, "the MXFP8 weight format is built for the unpadded trunk layout (Hiera-L, BASELINE configs[4])");
         // scale panels of the MX activations (K-step-major, [K / 128][mx_rows][4]); the e4m3 bytes themselves reuse xn / hid
-        e->mx_rows = (int64_t)((B * 4096 + 255) / 256 * 256);
+        e->mx_rows = (int64_t)((B * 4096 + 767) / 768 * 768);      // whole tiles of either MX kernel (256 / 192 rows)
         TRY(eng_alloc(e, &e->xn8_s, (size_t)(8 * C0s / 128 + 1) * e->mx_rows * 4));
         TRY(eng_alloc(e, &e->hid8_s, (size_t)(32 * C0s / 128 + 1) * e->mx_rows * 4));
     }

@@ -51,7 +51,7 @@ const char* launch_pack_w_kstep(const bf16_t* W, int ldw, int N, int K, bf16_t* 
 // C = act((A8 . W8^T) * sa[m] * sw[n] + bias) (+ res): e4m3 operands on the block-scaled fp8 MFMA, see the file header
 struct GemmMxParams {
     const uint8_t* A = nullptr; int64_t lda = 0;      // [M][lda] e4m3, rows zero-padded to Kp
-    const uint8_t* SA = nullptr; int64_t sa_rows = 0; // e8m0 block scales [Kp / 128][sa_rows][4], sa_rows >= ceil(M / 256) * 256
+    const uint8_t* SA = nullptr; int64_t sa_rows = 0; // e8m0 block scales [Kp / 128][sa_rows][4], sa_rows >= ceil(M / 768) * 768
     const uint8_t* W = nullptr; int64_t ldw = 0;      // [N][ldw] e4m3, rows zero-padded to Kp
     const uint8_t* SW = nullptr; int64_t sw_rows = 0; // [Kp / 128][sw_rows][4], sw_rows >= ceil(N / 192) * 192
     const float* bias = nullptr;

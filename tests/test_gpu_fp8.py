@@ -67,7 +67,7 @@ def test_mx_quantisers_bit_exact_and_mx_gemm(gpu_lib):
     g = torch.Generator().manual_seed(0)
     for (M, N, K, scale_spread) in ((300, 384, 576, 1.0), (256, 192, 128, 1.0), (1000, 1152, 1152, 6.0), (70000, 384, 288 + 288, 1.0)):
         Kp = (K + 127) // 128 * 128
-        Mp, Np = (M + 255) // 256 * 256, (N + 191) // 192 * 192
+        Mp, Np = (M + 767) // 768 * 768, (N + 191) // 192 * 192
         # rows with very different magnitudes per 32-block (what block scaling is for)
         x = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 4, (M, K // 32), generator=g).float() * scale_spread).repeat_interleave(32, 1)
         w = torch.randn(N, K, generator=g) * 0.05 * torch.exp2(torch.randint(-2, 3, (N, K // 32), generator=g).float()).repeat_interleave(32, 1)

@@ -17,7 +17,7 @@ def timeit(fn, n=20):
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, M, N, K, form in (("s2 qkv", 86016, 1728, 576, "bf16"), ("s2 fc1", 86016, 2304, 576, "mx"), ("s2 fc2", 86016, 576, 2304, "f32"), ("s3 qkv", 21504, 3456, 1152, "bf16"),
                             ("s3 fc1", 21504, 4608, 1152, "mx"), ("s3 fc2", 21504, 1152, 4608, "f32")):
-    Kp = (K + 127) // 128 * 128; Mp = (M + 255) // 256 * 256; Np = (N + 191) // 192 * 192
+    Kp = (K + 127) // 128 * 128; Mp = (M + 767) // 768 * 768; Np = (N + 191) // 192 * 192
     A8 = torch.randint(0, 120, (M, Kp), dtype=torch.uint8, device="cuda", generator=g); W8 = torch.randint(0, 120, (N, Kp), dtype=torch.uint8, device="cuda", generator=g)
     sa = torch.full((Kp // 128, Mp, 4), 120, dtype=torch.uint8, device="cuda"); sw = torch.full((Kp // 128, Np, 4), 120, dtype=torch.uint8, device="cuda")
     bias = torch.zeros(N, device="cuda")
