@@ -4,7 +4,8 @@ configs[3]: the 512-slice tomogram (1024 x 1024 x 512 uint16, oracle.saber_ref.s
 product's z-loop (propagationSegmenter.slice_by_slice_device: Hiera-L, cfgAMG's default grid and crop pyramid, two slices in flight, label
 planes painted and stitched on the device).  The 8-GPU form differs only in which rank owns which z-chunk and in one all-gather
 (tests/test_distributed_cpu.py: sharding + gather on gloo; tests/test_gpu_round2.py: the RCCL call path).
-configs[4]: one of the batch's 256-slice tomograms with e4m3 weights and hipGraph replay of the per-slice encode + decode sequences.
+configs[4]: one of the batch's 256-slice tomograms with MXFP8 weights on the fp8 MFMA (weight_format="mxfp8") and hipGraph replay of the per-slice
+encode + decode sequences.
 
 The score thresholds are those of tests/test_gpu_config2_volume.py (the seeded, untrained decoder leaves nothing at cfgAMG's own), so the
 paint / gather / stitch steps run on real labels.  Full-size checks are size-independent properties of slice_by_slice's contract
@@ -85,7 +86,7 @@ def test_config3_512_slices_full_size(segmenter):
     assert len(np.unique(pairs[:, 0])) == len(pairs)                   # each window component maps to ONE global label
 
 
-def test_config4_256_slices_fp8_weights_hipgraph(large_weights):
+def test_config4_256_slices_mxfp8_hipgraph(large_weights):
     from oracle import saber_ref
     from saber_amd.engine import Engine, make_amg_params
     from saber_amd.segmenters.slice_driver import segment_slice_to_plane
@@ -93,7 +94,7 @@ def test_config4_256_slices_fp8_weights_hipgraph(large_weights):
     vol = saber_ref.synthetic_volume(seed=3, depth=256)
     dev = torch.from_numpy(vol).cuda()
     params = make_amg_params(dict(pred_iou_thresh=0.5, stability_score_thresh=0.8))
-    eng = Engine("large", device=0, weights=W, max_images=21, max_prompts=1024, weight_format="fp8")
+    eng = Engine("large", device=0, weights=W, max_images=21, max_prompts=1024, weight_format="mxfp8")
     try:
         st = torch.cuda.Stream()
         planes = torch.zeros((256, 1024, 1024), dtype=torch.int16, device="cuda")
@@ -106,11 +107,11 @@ def test_config4_256_slices_fp8_weights_hipgraph(large_weights):
             st.synchronize()
         dt = time.perf_counter() - t0
         cap, rep = eng.graph_stats()
-        print(f"configs[4] on one GPU: 256 slices, e4m3 weights, hipGraph replay ({cap} sequences captured, {rep} replays) in {dt:.1f} s = {256 / dt:.2f} slices/s")
+        print(f"configs[4] on one GPU: 256 slices, MXFP8 weights on the fp8 MFMA, hipGraph replay ({cap} sequences captured, {rep} replays) in {dt:.1f} s = {256 / dt:.2f} slices/s")
         assert cap >= 7 and rep >= 7 * 250                             # encoder pass + 6 decoder batches per slice, replayed from the third slice on
         n_fg = int((planes.view(256, -1).max(1).values > 0).sum())
         assert n_fg > 128
-        # eager fp8 run of a z-subsample: planes identical to the replayed run's
+        # eager mxfp8 run of a z-subsample: planes identical to the replayed run's
         eng.set_graphs(False)
         with torch.cuda.stream(st):
             for z in (0, 1, 2, 77, 128, 255):

@@ -9,7 +9,7 @@ from saber_amd.weights import seeded_weights
 from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
 from oracle import saber_ref   # synthetic input recipe only
 Z = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-FMT = sys.argv[2] if len(sys.argv) > 2 else "bf16"          # "fp8": e4m3 stage-2/3 block weights (BASELINE configs[4])
+FMT = sys.argv[2] if len(sys.argv) > 2 else "bf16"          # "mxfp8": MXFP8 stage-2/3 block GEMMs on the fp8 MFMA (BASELINE configs[4]); "fp8": the e4m3 storage format
 W_ = seeded_weights(get_config("large"), 0)
 eng = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024, weight_format=FMT)
 eng2 = Engine("large", device=0, weights=W_, max_images=21, max_prompts=1024, weight_format=FMT)   # two slices in flight per GPU, as slice_by_slice_device does
