@@ -139,6 +139,14 @@ int saber_import_slots(saber_engine* e, int slot0, int n, const float* emb_dev, 
 int saber_decode_points(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                         const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream);
 
+/* The same with SEVERAL points per prompt (reference: upstream SAM2's prompt encoder as SAM2VideoPredictor.add_new_points_or_box feeds it -
+ * clicks with labels 1 / 0, a box as its two corners with labels 2 / 3 in front of the clicks, label -1 = not a point; one padding point is
+ * appended by the engine as upstream does when no box tensor is passed).  pts_dev: (n, points_per_prompt, 2), labels_dev: (n, points_per_prompt).
+ * points_per_prompt == 1 is saber_decode_points.  More than one point makes 8 + (points_per_prompt - 1) decoder tokens per prompt: the bf16
+ * kernels are built for 8, so such prompts are decoded in the EXACT precision mode only (SABER_ERR_STATE otherwise). */
+int saber_decode_prompts(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int points_per_prompt, int multimask,
+                         const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream);
+
 /* Automatic mask generation for one image.  out_bits_dev: (max_masks, H, ceil(W/32)) uint32, bit b of word w of row y
  * = pixel (y, 32w+b).  out_meta_host: max_masks records.  Synchronises the stream before returning (a count is returned).
  * More than max_masks results: SABER_ERR_CAPACITY with *out_count = the capacity needed (nothing is written).

@@ -65,6 +65,7 @@ SIGNATURES = {
     "saber_import_slots": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_get_decoder_tokens": (_i, [_vp, _i, _vp, _vp]),
     "saber_decode_points": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "saber_decode_prompts": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),
     "saber_amg_last_syncs": (_i, [_vp]),
     "saber_engine_set_graphs": (_i, [_vp, _i]),

@@ -33,6 +33,37 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(const float* __restr
     t[7 * DEC_C + c] = w.not_a_point[c];
 }
 
+// tokens[p] = [obj, iou, mask0..3, point(p, 0) .. point(p, K - 1), pad]  ((7 + K) x 256 fp32): K points per prompt (clicks; a box is its two
+// corners with labels 2 / 3, as upstream's SAM2VideoPredictor.add_new_points_or_box hands it to the prompt encoder), then the padding point
+__global__ __launch_bounds__(256) void prompt_tokens_multi_kernel(const float* __restrict__ pts, const int* __restrict__ labels, int P, int K,
+                                                                  PromptWeights w, float* __restrict__ tokens) {
+    const int p = blockIdx.x, c = threadIdx.x;
+    float* t = tokens + (int64_t)p * (7 + K) * DEC_C;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k * DEC_C + c] = w.out_tokens[k * DEC_C + c];
+    for (int k = 0; k < K; ++k) {
+        const int label = labels ? labels[p * K + k] : 1;
+        float e;
+        if (label >= 0) {
+            const float x = 2.0f * ((pts[2 * (p * K + k)] + 0.5f) / 1024.0f) - 1.0f;
+            const float y = 2.0f * ((pts[2 * (p * K + k) + 1] + 0.5f) / 1024.0f) - 1.0f;
+            const int f = c & 127;
+            const float a = 6.283185307179586f * (x * w.gauss[f] + y * w.gauss[128 + f]);
+            e = (c < 128 ? sinf(a) : cosf(a)) + w.point_embed[(label & 3) * DEC_C + c];
+        } else {
+            e = w.not_a_point[c];
+        }
+        t[(6 + k) * DEC_C + c] = e;
+    }
+    t[(6 + K) * DEC_C + c] = w.not_a_point[c];
+}
+const char* launch_prompt_tokens_multi(const float* pts, const int* labels, int P, int K, PromptWeights w, float* tokens, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    if (K < 1) return "prompt_tokens: at least one point per prompt";
+    hipLaunchKernelGGL(prompt_tokens_multi_kernel, dim3(P), dim3(256), 0, s, pts, labels, P, K, w, tokens);
+    return nullptr;
+}
+
 const char* launch_prompt_tokens(const float* pts, const int* labels, int P, PromptWeights w, float* tokens, hipStream_t s) {
     if (P <= 0) return nullptr;
     hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, s, pts, labels, P, w, tokens);

@@ -78,6 +78,7 @@ struct saber_engine {
     // encoder workspace
     float *pix = nullptr, *xa = nullptr, *xb = nullptr, *lat3 = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    int decode_n_pts = 1;           // points per prompt of the decode call in progress (saber_decode_prompts; exact precision only when > 1)
     uint8_t *xn8_s = nullptr, *hid8_s = nullptr; int64_t mx_rows = 0;   // MXFP8 weight format: scale panels of the MX activations (their e4m3 bytes reuse xn / hid); mx_rows = panel rows
     bf16_t* sb[4] = {nullptr, nullptr, nullptr, nullptr};
     int* crops_dev = nullptr;
@@ -194,7 +195,7 @@ int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev,
 // exact-precision mode (exact.hip): the Hiera blocks + neck of n images already patch-embedded in e->xa; one chunk of the decoder
 int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s);
 int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, const float* mask_in,
-                      float mask_clamp, int mask_in_q0, float* out_obj, float* masks4, hipStream_t s);
+                      float mask_clamp, int mask_in_q0, float* out_obj, float* masks4, hipStream_t s, int n_pts = 1);
 int exact_chunk_prompts(const saber_engine* e);
 void exact_release(saber_engine* e);
 template <typename T> int eng_alloc(saber_engine* e, T** p, size_t count);

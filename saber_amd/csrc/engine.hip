@@ -1140,13 +1140,14 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
                         float* raw4_out = nullptr, int* out_sel = nullptr, int mask_in_q0 = -1) {
     if (e->precision == SABER_PRECISION_EXACT) {
         float* m4 = raw4_out ? raw4_out : e->masks4;
-        TRY(exact_decode_core(e, slot0, per_slot, p_base, pts, labels, P, mask_in, mask_clamp, mask_in_q0, out_obj, m4, s));
+        TRY(exact_decode_core(e, slot0, per_slot, p_base, pts, labels, P, mask_in, mask_clamp, mask_in_q0, out_obj, m4, s, e->decode_n_pts));
         float* oi = out_iou ? out_iou : e->dec_out_iou;
         if (raw4_out) { ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s)); return SABER_OK; }
         float* om = out_lowres ? out_lowres : e->dec_out_masks;
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_select(e->masks4, e->iou4, P, multimask, om, oi, e->counts_ws, s));
         return SABER_OK;
     }
+    if (e->decode_n_pts != 1) return eng_fail(e, SABER_ERR_STATE, "prompts of several points (clicks, boxes) are decoded in the exact precision mode only: the bf16 kernels are built for 8 decoder tokens per prompt");
     const int T = 8;
     const int PT = P * T;
     const size_t o256 = (size_t)slot0 * 4096 * 256;
@@ -1337,11 +1338,12 @@ int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev,
     for (int sl = slot; sl < slot + nslots; ++sl)
         if (sl < 0 || sl >= e->max_images || !e->slot_valid[sl]) return eng_fail(e, SABER_ERR_STATE, "decode: slot holds no encoded image; call saber_encode first");
     const int M = multimask ? 3 : 1;
-    const int chunk = e->precision == SABER_PRECISION_EXACT ? exact_chunk_prompts(e) : e->max_prompts;
+    const int K = e->decode_n_pts;                  // points per prompt (1 except under saber_decode_prompts)
+    const int chunk = e->precision == SABER_PRECISION_EXACT ? std::max(1, exact_chunk_prompts(e) * 8 / (7 + K)) : e->max_prompts;
     for (int p0 = 0; p0 < n; p0 += chunk) {
         const int P = std::min(chunk, n - p0);
         const float* min_ = !mask_in_dev ? nullptr : mask_in_raw4 ? mask_in_dev : mask_in_dev + (size_t)p0 * 65536;
-        TRY(decode_chunk(e, slot, per_slot, p0, pts_dev + 2 * (size_t)p0, labels_dev ? labels_dev + p0 : nullptr, P, multimask,
+        TRY(decode_chunk(e, slot, per_slot, p0, pts_dev + 2 * (size_t)p0 * K, labels_dev ? labels_dev + (size_t)p0 * K : nullptr, P, multimask,
                          min_, mask_clamp,
                          out_lowres && !out_raw4 ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
                          out_obj ? out_obj + p0 : nullptr, s, out_raw4 ? out_lowres + (size_t)p0 * 4 * 65536 : nullptr,
@@ -1356,6 +1358,18 @@ extern "C" int saber_decode_points(saber_engine* e, int slot, const float* pts_d
     if (!e) return SABER_ERR_INVALID;
     ENG_DEVICE(e);
     return eng_decode(e, slot, 0, pts_dev, labels_dev, n, multimask, mask_in_dev, 0.f, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
+}
+
+extern "C" int saber_decode_prompts(saber_engine* e, int slot, const float* pts_dev, const int* labels_dev, int n, int points_per_prompt, int multimask,
+                                    const float* mask_in_dev, float* out_lowres_dev, float* out_iou_dev, float* out_obj_dev, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (points_per_prompt < 1 || points_per_prompt > 9) return eng_fail(e, SABER_ERR_INVALID, "decode_prompts: 1..9 points per prompt (16 decoder tokens)");
+    if (points_per_prompt > 1 && !labels_dev) return eng_fail(e, SABER_ERR_INVALID, "decode_prompts: labels are required with several points per prompt");
+    ENG_DEVICE(e);
+    e->decode_n_pts = points_per_prompt;
+    const int st = eng_decode(e, slot, 0, pts_dev, labels_dev, n, multimask, mask_in_dev, 0.f, out_lowres_dev, out_iou_dev, out_obj_dev, (hipStream_t)stream);
+    e->decode_n_pts = 1;
+    return st;
 }
 
 // ------------------------------------------------------------------------------------------------ label plane

@@ -542,15 +542,19 @@ int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s) {
 // upscaling.  Leaves: e->queries (the 8 output tokens per prompt), e->iou4 [P][4], out_obj [P] (optional), masks4 [P][4][256 x 256]
 // (row-major pixels); the caller applies the same mask selection as the production path.
 int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, const float* mask_in,
-                      float mask_clamp, int mask_in_q0, float* out_obj, float* masks4, hipStream_t s) {
+                      float mask_clamp, int mask_in_q0, float* out_obj, float* masks4, hipStream_t s, int n_pts) {
     TRY(ensure_ws(e));
     ExactWs* w = ws_of(e);
     if (P > w->pc) return eng_fail(e, SABER_ERR_INVALID, "exact decode: chunk larger than the exact-mode workspace");
     if (!e->dl[0].t2i.q.wf) return eng_fail(e, SABER_ERR_STATE, "exact mode: the engine was finalized without fp32 weights (set the precision before finalize)");
-    const int T = 8, PT = P * T;
+    // n_pts points per prompt (several clicks, a box as its two corners): 6 output tokens + the points + upstream's padding point.  Every
+    // kernel below takes the token count as a parameter; the workspaces are sized for 8 tokens x the chunk.
+    const int T = 7 + n_pts, PT = P * T;
+    if (n_pts < 1 || (size_t)PT > (size_t)w->pc * 8 || (size_t)PT > (size_t)e->max_prompts * 8)
+        return eng_fail(e, SABER_ERR_INVALID, "exact decode: prompts x tokens exceed the workspace (8 tokens x the prompt chunk)");
     const XMap slots{(int64_t)4096 * 256, per_slot, p_base};
     const float* emb0 = e->emb + (size_t)slot0 * 4096 * 256;
-    XK(launch_prompt_tokens(pts, labels, P, e->pw, e->tok_pe, s));
+    XK(launch_prompt_tokens_multi(pts, labels, P, n_pts, e->pw, e->tok_pe, s));
     ENG_HIP(e, hipMemcpyAsync(e->queries, e->tok_pe, sizeof(float) * PT * 256, hipMemcpyDeviceToDevice, s));
     // src = image_embed + dense prompt embedding
     if (!mask_in) {

@@ -109,6 +109,7 @@ struct PromptWeights {
     const float* out_tokens;    // [6][256]: obj, iou, mask0..3
 };
 const char* launch_prompt_tokens(const float* pts, const int* labels, int P, PromptWeights w, float* tokens, hipStream_t s);
+const char* launch_prompt_tokens_multi(const float* pts, const int* labels, int P, int K, PromptWeights w, float* tokens, hipStream_t s);   // K points per prompt: 7 + K tokens
 
 struct MaskEmbedWeights {
     const float *w1, *b1, *g1, *be1;   // conv 1->4 k2s2 [4][4], LN2d(4)

@@ -159,6 +159,23 @@ class Engine:
                                                  _ptr(low), _ptr(iou), _ptr(obj), _stream()))
         return low, iou, obj
 
+    def decode_prompts(self, pts: torch.Tensor, labels: torch.Tensor, slot: int = 0, multimask: bool = False, mask_input: Optional[torch.Tensor] = None):
+        """Prompts of several points each (clicks with labels 1 / 0; a box = its two corners with labels 2 / 3 first; -1 = not a point).
+        pts: (n,k,2) float32 model-pixel coords, labels: (n,k) int32, both on the device.  With k > 1 the handle must be in the exact
+        precision mode (the bf16 decoder kernels carry 8 tokens per prompt).  Returns (lowres (n,M,256,256), iou (n,M), obj (n,))."""
+        assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous() and pts.dim() == 3 and pts.shape[2] == 2
+        n, k = pts.shape[:2]
+        assert labels.is_cuda and labels.dtype == torch.int32 and labels.is_contiguous() and tuple(labels.shape) == (n, k)
+        M = 3 if multimask else 1
+        low = torch.empty((n, M, 256, 256), dtype=torch.float32, device=self.device)
+        iou = torch.empty((n, M), dtype=torch.float32, device=self.device)
+        obj = torch.empty((n,), dtype=torch.float32, device=self.device)
+        if mask_input is not None:
+            assert mask_input.is_cuda and mask_input.dtype == torch.float32 and mask_input.is_contiguous() and mask_input.numel() == n * 65536
+        self._check(self.lib.saber_decode_prompts(self.h, slot, _ptr(pts), _ptr(labels), n, k, int(multimask), _ptr(mask_input),
+                                                  _ptr(low), _ptr(iou), _ptr(obj), _stream()))
+        return low, iou, obj
+
     # ------------------------------------------------------------------ AMG
     def amg_generate(self, img: torch.Tensor, params: "_lib.AmgParams", max_masks: int = 1024):
         """img: (H,W) or (H,W,3) float32 in [0,1].  Returns (bits uint32 (n,H,W32) device tensor, list of MaskMeta)."""

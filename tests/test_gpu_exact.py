@@ -218,3 +218,35 @@ def test_exact_default_grid_amg_golden(large_weights):
         assert np.abs(piou - G["predicted_iou"]).max() < TOL
     finally:
         eng.close()
+
+
+def test_exact_mode_prompts_of_several_points_and_boxes(engine_exact, image, oracle_feats, oracle_large):
+    """saber_decode_prompts (a box = its two corner points with labels 2 / 3, then clicks, then upstream's padding point: 9 / 10 decoder
+    tokens) against oracle/sam2_ref.prompt_encoder + mask_decoder on the oracle's own features; the bf16 precision refuses such prompts
+    loudly; one point per prompt is saber_decode_points."""
+    from oracle import sam2_ref
+    eng = engine_exact
+    cfg, Wt = oracle_large
+    eng.set_precision("exact")
+    eng.encode(torch.from_numpy(image).cuda())
+    for pts, lab, multimask in (
+            ([[[200.0, 240.0], [700.0, 820.0], [450.0, 500.0]], [[100.0, 90.0], [400.0, 380.0], [250.0, 300.0]]], [[2, 3, 1], [2, 3, 0]], False),     # box + click
+            ([[[300.0, 300.0], [340.0, 310.0]], [[800.0, 200.0], [760.0, 260.0]], [[512.0, 512.0], [10.0, 1000.0]]], [[1, 1], [1, 0], [1, -1]], False),   # two clicks
+            ([[[128.0, 900.0], [600.0, 1010.0]]], [[2, 3]], True)):                                                                        # box alone
+        p = torch.tensor(pts, dtype=torch.float32)
+        l = torch.tensor(lab, dtype=torch.int64)
+        with torch.no_grad():
+            sp, de = sam2_ref.prompt_encoder(Wt, p, l, None)
+            o_low, o_iou, o_obj, _, _ = sam2_ref.mask_decoder(Wt, oracle_feats, sp, de, multimask)
+        low, iou, obj = eng.decode_prompts(p.cuda(), l.to(torch.int32).cuda(), slot=0, multimask=multimask)
+        e_low = rel_rms(low.cpu(), o_low)
+        e_iou = (iou.cpu() - o_iou).abs().max().item()
+        print(f"{p.shape[1]} points per prompt, multimask={multimask}: low-res logits {e_low:.2e}, iou abs {e_iou:.2e}, obj abs {(obj.cpu() - o_obj.reshape(-1)).abs().max().item():.2e}")
+        assert e_low < 1e-3 and e_iou < 1e-3
+    eng.set_precision("bf16")
+    with pytest.raises(RuntimeError, match="exact precision"):
+        eng.decode_prompts(torch.zeros(1, 2, 2, device="cuda"), torch.ones(1, 2, dtype=torch.int32, device="cuda"), slot=0)
+    p1 = torch.tensor([[[300.0, 400.0]]], device="cuda"); l1 = torch.ones(1, 1, dtype=torch.int32, device="cuda")
+    a = eng.decode_prompts(p1, l1, slot=0, multimask=True)[0]
+    b = eng.decode_points(p1[:, 0].contiguous(), slot=0, multimask=True)[0]
+    assert torch.equal(a, b)
