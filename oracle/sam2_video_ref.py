@@ -240,6 +240,7 @@ class VideoPredictorRef:
         self.obj_ids = []
         self.out = {}            # obj_id -> {"cond": {t: out}, "non_cond": {t: out}}
         self.temp = {}           # obj_id -> {t: out} (prompted frames awaiting the preflight)
+        self._points = {}        # (obj_id, t) -> (points in model pixels (1,k,2), labels (1,k)): upstream's point_inputs_per_obj
 
     @torch.no_grad()
     def _feats(self, t: int):
@@ -326,19 +327,23 @@ class VideoPredictorRef:
 
     @torch.no_grad()
     def add_new_points_or_box(self, frame_idx: int, obj_id: int, points=None, labels=None, clear_old_points: bool = True, normalize_coords: bool = True, box=None):
-        """upstream SAM2VideoPredictor.add_new_points_or_box for ONE click on a frame that has not been tracked yet (an initial conditioning
-        frame: the SAM heads run on the frame's own features + no_mem_embed, multimask output because there is a single point, the best mask by
-        predicted IoU becomes the frame's output; a previous output on the frame enters as the mask prompt, clamped to +-32)."""
+        """upstream SAM2VideoPredictor.add_new_points_or_box on a frame that has not been tracked yet (an initial conditioning frame: the SAM heads
+        run on the frame's own features + no_mem_embed; a previous output on the frame enters as the mask prompt, clamped to +-32).  A box is
+        its two corners with labels 2 / 3 in front of the clicks (only with clear_old_points, as upstream); clicks accumulate over calls unless
+        clear_old_points; multimask output (best mask by predicted IoU) only while there is at most ONE point (SAM2Base._use_multimask with
+        multimask_min_pt_num 0 / multimask_max_pt_num 1), otherwise the single-mask output with dynamic_multimask_via_stability."""
         if (points is not None) != (labels is not None):
             raise ValueError("points and labels must be provided together")
         if points is None and box is None:
             raise ValueError("at least one of points or box must be provided as input")
+        pts = torch.zeros(1, 0, 2) if points is None else torch.as_tensor(np.asarray(points), dtype=torch.float32).reshape(1, -1, 2)
+        lab = torch.zeros(1, 0, dtype=torch.int64) if labels is None else torch.as_tensor(np.asarray(labels), dtype=torch.int64).reshape(1, -1)
         if box is not None:
-            raise NotImplementedError("box prompts are not restated")
-        pts = torch.as_tensor(np.asarray(points), dtype=torch.float32).reshape(1, -1, 2)
-        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int64).reshape(1, -1)
-        if pts.shape[1] != 1:
-            raise NotImplementedError("one click per call")
+            if not clear_old_points:
+                raise ValueError("cannot add box without clearing old points, since box prompt must be provided before any point prompt "
+                                 "(please use clear_old_points=True instead)")
+            pts = torch.cat([torch.as_tensor(np.asarray(box), dtype=torch.float32).reshape(1, 2, 2), pts], 1)
+            lab = torch.cat([torch.tensor([[2, 3]], dtype=torch.int64), lab], 1)
         if obj_id not in self.obj_ids:
             self.obj_ids.append(obj_id)
             self.out[obj_id] = {"cond": {}, "non_cond": {}}
@@ -348,10 +353,15 @@ class VideoPredictorRef:
         if normalize_coords:
             pts = pts / torch.tensor([self.video_hw[1], self.video_hw[0]], dtype=torch.float32)
         pts = pts * self.image_size
+        held = self._points
+        old = None if clear_old_points else held.get((obj_id, frame_idx))
+        if old is not None:
+            pts, lab = torch.cat([old[0], pts], 1), torch.cat([old[1], lab], 1)
+        held[(obj_id, frame_idx)] = (pts, lab)
         prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx)
         mask_in = torch.clamp(prev["pred_masks"], -32.0, 32.0) if prev is not None else None
         pix, pos, s0, s1 = self._feats(frame_idx)
-        low, high, ptr, obj = self._sam_heads(pix + self.W["no_mem_embed"].view(1, -1, 1, 1), s0, s1, mask_in, multimask_output=True, pts=pts, lab=lab)
+        low, high, ptr, obj = self._sam_heads(pix + self.W["no_mem_embed"].view(1, -1, 1, 1), s0, s1, mask_in, multimask_output=pts.shape[1] <= 1, pts=pts, lab=lab)
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
         return frame_idx, list(self.obj_ids), F.interpolate(low, size=self.video_hw, mode="bilinear", align_corners=False)
 

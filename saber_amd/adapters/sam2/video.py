@@ -227,9 +227,11 @@ class VideoPredictor:
         self._raw: Dict[int, torch.Tensor] = {}
         self._win = (0, 0)
         self._frames_dev = None
+        self._points = {}                # (obj_id, frame_idx) -> (points in model pixels (k,2), labels (k,)): the clicks a frame has accumulated
 
     def reset_state(self):
         self.obj_ids, self.out, self.temp, self._raw, self._win = [], {}, {}, {}, (0, 0)
+        self._points = {}
 
     def _frame(self, t: int, reverse: bool = False) -> torch.Tensor:
         """RAW top-level features of frame t (without no_mem_embed) as (4096,256) fp32 row-major tokens.  Frames are encoded a WINDOW at a
@@ -303,13 +305,30 @@ class VideoPredictor:
 
     # ------------------------------------------------------------------ SAM heads on a given (4096,256) embedding
     def _sam_heads(self, embed_tokens: torch.Tensor, mask_in: Optional[torch.Tensor], multimask: bool, slot: int = 0,
-                   point: Optional[Tuple[float, float]] = None, label: int = -1):
+                   point: Optional[Tuple[float, float]] = None, label: int = -1, points=None, labels=None):
         """returns (low (256,256) device fp32, obj logit float, obj_ptr (1,256) device fp32); slot: the engine slot that holds the frame;
-        point / label: one click in the model's 1024-px frame (None: upstream's padding point with label -1)"""
+        point / label: one click in the model's 1024-px frame (None: upstream's padding point with label -1); points (k,2) / labels (k,),
+        k > 1: several clicks / a box's corners - decoded in the engine's exact precision mode (saber_decode_prompts), which the handle must
+        have been created with (Engine(..., precision="exact"); the production precision is restored afterwards)"""
         self.eng._check(self.lib.saber_set_embed_tokens(self.eng.h, slot, self._p(embed_tokens), self._s()))
-        pts = torch.zeros(1, 2, device=self.dev) if point is None else torch.tensor([[float(point[0]), float(point[1])]], dtype=torch.float32, device=self.dev)
-        lab = torch.full((1,), -1 if point is None else int(label), dtype=torch.int32, device=self.dev)
-        low, iou, obj = self.eng.decode_points(pts, slot=slot, multimask=multimask, mask_input=mask_in, labels=lab)
+        if points is not None and len(points) > 1:
+            was = self.eng.precision
+            if not getattr(self.eng, "has_exact", was == "exact"):
+                raise NotImplementedError("several points / a box per prompt make more than 8 decoder tokens: they are decoded in the exact precision mode - "
+                                          "create the Engine with precision='exact' (it can run in bf16 between such calls: Engine.set_precision)")
+            pts = torch.as_tensor(np.asarray(points, np.float32).reshape(1, -1, 2)).to(self.dev)
+            lab = torch.as_tensor(np.asarray(labels, np.int32).reshape(1, -1)).to(self.dev)
+            self.eng.set_precision("exact")
+            try:
+                low, iou, obj = self.eng.decode_prompts(pts, lab, slot=slot, multimask=multimask, mask_input=mask_in)
+            finally:
+                self.eng.set_precision(was)
+        else:
+            if points is not None and len(points) == 1:
+                point, label = (float(points[0][0]), float(points[0][1])), int(labels[0])
+            pts = torch.zeros(1, 2, device=self.dev) if point is None else torch.tensor([[float(point[0]), float(point[1])]], dtype=torch.float32, device=self.dev)
+            lab = torch.full((1,), -1 if point is None else int(label), dtype=torch.int32, device=self.dev)
+            low, iou, obj = self.eng.decode_points(pts, slot=slot, multimask=multimask, mask_input=mask_in, labels=lab)
         toks = self._new(8, 256)
         self.eng._check(self.lib.saber_get_decoder_tokens(self.eng.h, 1, self._p(toks), self._s()))
         host = torch.cat([obj.reshape(-1)[:1], iou[0].reshape(-1)]).cpu()       # the one synchronisation of a tracked frame: object score + IoUs
@@ -396,23 +415,29 @@ class VideoPredictor:
     @torch.inference_mode()
     def add_new_points_or_box(self, frame_idx: int, obj_id: int, points=None, labels=None, clear_old_points: bool = True,
                               normalize_coords: bool = True, box=None):
-        """upstream SAM2VideoPredictor.add_new_points_or_box for ONE click on a frame that has not been tracked yet: the SAM heads run on
-        the frame's own features (+ no_mem_embed: an initial conditioning frame sees no memory) with the click as the point prompt and the
-        frame's previous output, if any, as the mask prompt (clamped to +-32); one point => multimask output, the best mask by predicted
-        IoU becomes the frame's output.  The engine decodes prompts of one point + the padding point (8 decoder tokens): boxes (two corner
-        points) and several clicks in one call are not built, nor are corrections of frames that have already been tracked."""
+        """upstream SAM2VideoPredictor.add_new_points_or_box on a frame that has not been tracked yet: the SAM heads run on the frame's own
+        features (+ no_mem_embed: an initial conditioning frame sees no memory) with the accumulated clicks as the point prompt and the
+        frame's previous output, if any, as the mask prompt (clamped to +-32).  A box is its two corners with labels 2 / 3 in front of the
+        clicks (only with clear_old_points, as upstream); clicks accumulate over calls unless clear_old_points.  At most one point =>
+        multimask output, the best mask by predicted IoU becomes the frame's output (the production bf16 decoder: 8 tokens per prompt);
+        more points (or a box) => the single-mask output with dynamic selection, decoded in the engine's exact precision mode (the handle
+        must have been created with precision="exact").  Corrections of frames that have already been tracked are not built."""
         if self.images is None:
             raise RuntimeError("call init_state() first")
         if (points is not None) != (labels is not None):
             raise ValueError("points and labels must be provided together")
         if points is None and box is None:
             raise ValueError("at least one of points or box must be provided as input")
+        pts = np.zeros((0, 2), np.float32) if points is None else np.asarray(points, dtype=np.float32).reshape(-1, 2)
+        lab = np.zeros((0,), np.int32) if labels is None else np.asarray(labels).reshape(-1).astype(np.int32)
+        if len(pts) != len(lab):
+            raise ValueError("points and labels must have the same length")
         if box is not None:
-            raise NotImplementedError("box prompts (two corner points + padding = 9 decoder tokens) are not built; seed with a mask or a click")
-        pts = np.asarray(points, dtype=np.float32).reshape(-1, 2)
-        lab = np.asarray(labels).reshape(-1)
-        if len(pts) != 1 or len(lab) != 1:
-            raise NotImplementedError("one click per call (several clicks need more prompt tokens than the engine's decoder batches carry)")
+            if not clear_old_points:
+                raise ValueError("cannot add box without clearing old points, since box prompt must be provided before any point prompt "
+                                 "(please use clear_old_points=True instead)")
+            pts = np.concatenate([np.asarray(box, np.float32).reshape(2, 2), pts], 0)
+            lab = np.concatenate([np.array([2, 3], np.int32), lab], 0)
         if obj_id not in self.obj_ids:
             self.obj_ids.append(obj_id)
             self.out[obj_id] = {"cond": {}, "non_cond": {}}
@@ -420,14 +445,21 @@ class VideoPredictor:
         if frame_idx in self.out[obj_id]["non_cond"]:
             raise NotImplementedError("correcting a frame that has already been tracked is not built")
         Hv, Wv = self.video_hw
-        xy = pts[0] / np.array([Wv, Hv], np.float32) if normalize_coords else pts[0]
-        xy = xy * np.float32(self.image_size)
+        xy = pts / np.array([Wv, Hv], np.float32) if normalize_coords else pts
+        xy = (xy * np.float32(self.image_size)).astype(np.float32)
+        held = self.__dict__.setdefault("_points", {})
+        old = None if clear_old_points else held.get((obj_id, frame_idx))
+        if old is not None:
+            xy, lab = np.concatenate([old[0], xy], 0), np.concatenate([old[1], lab], 0)
+        if len(xy) > 9:
+            raise NotImplementedError("at most 9 points per object and frame (16 decoder tokens)")
+        held[(obj_id, frame_idx)] = (xy, lab)
         prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx)
         mask_in = prev["pred_masks"].clamp(-32.0, 32.0).view(1, 256, 256).contiguous() if prev is not None else None
         raw = self._frame(frame_idx)
         emb = self._new(4096, 256)
         self._ck(self.lib.saber_k_add_to_bf16(self._p(raw), self._p(self.pos_no_mem), 1, None, self._p(emb), 4096, 256, self._s()))
-        low, obj_v, ptr = self._sam_heads(emb, mask_in, multimask=True, slot=self._slot(frame_idx), point=(xy[0], xy[1]), label=int(lab[0]))
+        low, obj_v, ptr = self._sam_heads(emb, mask_in, multimask=len(xy) <= 1, slot=self._slot(frame_idx), points=xy, labels=lab)
         self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": None, "raw": raw}
         return frame_idx, list(self.obj_ids), self._resize(low, 256, 256, Hv, Wv)[None, None]
 
@@ -454,6 +486,7 @@ class VideoPredictor:
         if obj_id not in self.obj_ids:
             raise RuntimeError(f"Cannot clear prompts for object id {obj_id}: it does not exist. All existing object ids: {self.obj_ids}.")
         self.temp[obj_id].pop(frame_idx, None)
+        self.__dict__.setdefault("_points", {}).pop((obj_id, frame_idx), None)
         out = self.out[obj_id]["cond"].pop(frame_idx, None)
         if out is not None:
             self.out[obj_id]["non_cond"][frame_idx] = out
@@ -473,6 +506,7 @@ class VideoPredictor:
         self.obj_ids.remove(obj_id)
         self.out.pop(obj_id, None)
         self.temp.pop(obj_id, None)
+        self._points = {k: v for k, v in self.__dict__.get("_points", {}).items() if k[0] != obj_id}
         if not need_output or not self.obj_ids:
             return list(self.obj_ids), []
         return list(self.obj_ids), [(t, self._frame_output(t)[2]) for t in input_frames]

@@ -52,6 +52,7 @@ class Engine:
         if precision not in ("bf16", "exact"):
             raise ValueError(f"precision must be 'bf16' or 'exact', got '{precision}'")
         self.precision = precision
+        self.has_exact = precision == "exact"      # fp32 weight copies are kept only when the handle was created in the exact mode
         if precision == "exact":         # fp32 operands everywhere (include/saber_amd.h: saber_engine_set_precision); keeps fp32 weight copies
             self._check(self.lib.saber_engine_set_precision(self.h, 1))
         if weights is None:

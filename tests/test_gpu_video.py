@@ -252,7 +252,8 @@ def test_reference_script_assertions_shape_dtype_and_reset(video_case):
 
 def test_add_new_points_single_click_against_oracle(video_case):
     """add_new_points_or_box with one positive click on an untracked frame (initial conditioning frame: SAM heads on the frame's own
-    features, multimask, best IoU), then two tracked frames, against the oracle; boxes / several clicks raise NotImplementedError."""
+    features, multimask, best IoU), then two tracked frames, against the oracle; on a handle without the exact precision mode boxes /
+    several clicks raise NotImplementedError (test_box_and_several_clicks_against_oracle runs them)."""
     from oracle import sam2_video_ref as V
     from saber_amd.adapters.sam2.video import load_tomogram_frames
     cfg, W, vp, tomo, seed = video_case
@@ -283,6 +284,58 @@ def test_add_new_points_single_click_against_oracle(video_case):
     with pytest.raises(ValueError):
         vp.add_new_points_or_box(0, 2, points=[[1, 1]])
     vp.reset_state()
+
+
+def test_box_and_several_clicks_against_oracle():
+    """add_new_points_or_box with a box, a box + a click, and clicks accumulated over two calls (clear_old_points=False), on an untracked
+    frame: the oracle's restatement of upstream's point handling (box corners as labels 2 / 3 in front, single-mask output beyond one point)
+    against the product, whose engine decodes such prompts in its exact precision mode (the handle is created with precision="exact" and
+    runs everything else - encoder, tracked frames - in bf16); then two tracked frames."""
+    from oracle import sam2_video_ref as V
+    from saber_amd.adapters.sam2.video import VideoPredictor, load_tomogram_frames
+    from saber_amd.engine import Engine
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import param_specs, seeded_weights
+    cfg = get_config("tiny")
+    W = seeded_weights(cfg, 0, video=True)
+    W["sam_mask_decoder.pred_obj_score_head.layers.2.bias"] = W["sam_mask_decoder.pred_obj_score_head.layers.2.bias"] + np.float32(3.0)
+    img_keys = set(param_specs(cfg).keys())
+    eng = Engine("tiny", device=0, weights={k: v for k, v in W.items() if k in img_keys}, max_images=3, max_prompts=8, precision="exact")
+    eng.set_precision("bf16")
+    try:
+        vp = VideoPredictor(eng, W, num_maskmem=2)
+        rng = np.random.default_rng(5)
+        tomo = rng.uniform(-1, 1, (5, 128, 128)).astype(np.float32)
+        P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+        for case in ("box", "box+click", "two calls"):
+            P.init_state(V.load_tomogram_frames(tomo), video_hw=(1024, 1024))
+            vp.init_state(load_tomogram_frames(tomo), video_hw=(1024, 1024))
+            for pred in (P, vp):
+                if case == "box":
+                    out = pred.add_new_points_or_box(1, 7, box=[300.0, 280.0, 720.0, 700.0])
+                elif case == "box+click":
+                    out = pred.add_new_points_or_box(1, 7, points=[[500.0, 480.0]], labels=[1], box=[300.0, 280.0, 720.0, 700.0])
+                else:
+                    pred.add_new_points_or_box(1, 7, points=[[500.0, 480.0]], labels=[1])
+                    out = pred.add_new_points_or_box(1, 7, points=[[650.0, 300.0]], labels=[0], clear_old_points=False)
+                assert out[1] == [7] and tuple(out[2].shape) == (1, 1, 1024, 1024)
+            assert eng.precision == "bf16"                                  # restored after the exact-mode decode
+            e0 = _rel(vp.temp[7][1]["pred_masks"].cpu(), P.temp[7][1]["pred_masks"][0, 0])
+            ep = _rel(vp.temp[7][1]["obj_ptr"].cpu(), P.temp[7][1]["obj_ptr"])
+            print(f"{case}: prompted frame low-res rel-rms {e0:.3e}, pointer {ep:.3e}")
+            assert e0 < 2.2e-2 and ep < 1.4e-2                              # (the frame's features come from the bf16 encoder: the bounds of the single-click test)
+            ref = {t: lg for t, _, lg in P.propagate_in_video(1, max_frame_num_to_track=2)}
+            got = {t: lg for t, _, lg in vp.propagate_in_video(1, max_frame_num_to_track=2)}
+            assert sorted(ref) == sorted(got) == [1, 2, 3]
+            for t in ref:
+                g, r = got[t][0, 0].cpu() > 0, ref[t][0, 0] > 0
+                iou = float((g & r).sum()) / max(1.0, float((g | r).sum()))
+                print(f"{case}: frame {t} mask IoU {iou:.4f}")
+                assert iou > 0.97 or (not g.any() and not r.any())
+        with pytest.raises(ValueError):
+            vp.add_new_points_or_box(0, 9, box=[1, 1, 5, 5], clear_old_points=False)
+    finally:
+        eng.close()
 
 
 def test_two_objects_segment_volume_against_oracle(video_case):
