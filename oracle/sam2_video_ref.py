@@ -241,6 +241,7 @@ class VideoPredictorRef:
         self.out = {}            # obj_id -> {"cond": {t: out}, "non_cond": {t: out}}
         self.temp = {}           # obj_id -> {t: out} (prompted frames awaiting the preflight)
         self._points = {}        # (obj_id, t) -> (points in model pixels (1,k,2), labels (1,k)): upstream's point_inputs_per_obj
+        self._tracked = {}       # (obj_id, t) -> reverse flag of the propagation that last went over the frame: upstream's frames_tracked_per_obj
 
     @torch.no_grad()
     def _feats(self, t: int):
@@ -348,8 +349,6 @@ class VideoPredictorRef:
             self.obj_ids.append(obj_id)
             self.out[obj_id] = {"cond": {}, "non_cond": {}}
             self.temp[obj_id] = {}
-        if frame_idx in self.out[obj_id]["non_cond"]:
-            raise NotImplementedError("corrections of tracked frames are not restated")
         if normalize_coords:
             pts = pts / torch.tensor([self.video_hw[1], self.video_hw[0]], dtype=torch.float32)
         pts = pts * self.image_size
@@ -358,11 +357,19 @@ class VideoPredictorRef:
         if old is not None:
             pts, lab = torch.cat([old[0], pts], 1), torch.cat([old[1], lab], 1)
         held[(obj_id, frame_idx)] = (pts, lab)
-        prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx)
+        # A frame a propagation has already gone over is CORRECTED (upstream: is_init_cond_frame False): its features are conditioned on the
+        # memory bank in the direction it was tracked, and its new output stays a non-conditioning one (add_all_frames_to_correct_as_cond False)
+        is_init = (obj_id, frame_idx) not in self._tracked
+        prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx) or self.out[obj_id]["non_cond"].get(frame_idx)
         mask_in = torch.clamp(prev["pred_masks"], -32.0, 32.0) if prev is not None else None
         pix, pos, s0, s1 = self._feats(frame_idx)
-        low, high, ptr, obj = self._sam_heads(pix + self.W["no_mem_embed"].view(1, -1, 1, 1), s0, s1, mask_in, multimask_output=pts.shape[1] <= 1, pts=pts, lab=lab)
-        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None}
+        if is_init:
+            feat = pix + self.W["no_mem_embed"].view(1, -1, 1, 1)
+        else:
+            feat = self._memory_conditioned(obj_id, frame_idx, pix, pos, self._tracked[(obj_id, frame_idx)])
+        low, high, ptr, obj = self._sam_heads(feat, s0, s1, mask_in, multimask_output=pts.shape[1] <= 1, pts=pts, lab=lab)
+        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "object_score_logits": obj, "maskmem_features": None, "maskmem_pos_enc": None,
+                                        "is_cond": is_init}
         return frame_idx, list(self.obj_ids), F.interpolate(low, size=self.video_hw, mode="bilinear", align_corners=False)
 
     @torch.no_grad()
@@ -374,7 +381,11 @@ class VideoPredictorRef:
                     high = out.pop("high_res_for_memory", high)
                     pix = self._feats(t)[0]
                     out["maskmem_features"], out["maskmem_pos_enc"] = self._encode_memory(pix, high, out["object_score_logits"], is_mask_from_pts=True)
-                self.out[oid]["cond"][t] = out
+                if out.pop("is_cond", True):
+                    self.out[oid]["cond"][t] = out
+                else:
+                    self.out[oid]["non_cond"][t] = out
+            for t in self.out[oid]["cond"]:              # upstream keeps the two dictionaries disjoint (a corrected conditioning frame keeps its old output)
                 self.out[oid]["non_cond"].pop(t, None)
             self.temp[oid] = {}
             if not self.out[oid]["cond"]:
@@ -447,6 +458,7 @@ class VideoPredictorRef:
         for t in order:
             lows = []
             for oid in self.obj_ids:
+                self._tracked[(oid, t)] = reverse
                 if t in self.out[oid]["cond"]:
                     lows.append(self.out[oid]["cond"][t]["pred_masks"])
                 else:

@@ -228,10 +228,11 @@ class VideoPredictor:
         self._win = (0, 0)
         self._frames_dev = None
         self._points = {}                # (obj_id, frame_idx) -> (points in model pixels (k,2), labels (k,)): the clicks a frame has accumulated
+        self._tracked = {}               # (obj_id, frame_idx) -> reverse flag of the propagation that last went over the frame (upstream: frames_tracked_per_obj)
 
     def reset_state(self):
         self.obj_ids, self.out, self.temp, self._raw, self._win = [], {}, {}, {}, (0, 0)
-        self._points = {}
+        self._points, self._tracked = {}, {}
 
     def _frame(self, t: int, reverse: bool = False) -> torch.Tensor:
         """RAW top-level features of frame t (without no_mem_embed) as (4096,256) fp32 row-major tokens.  Frames are encoded a WINDOW at a
@@ -421,7 +422,9 @@ class VideoPredictor:
         clicks (only with clear_old_points, as upstream); clicks accumulate over calls unless clear_old_points.  At most one point =>
         multimask output, the best mask by predicted IoU becomes the frame's output (the production bf16 decoder: 8 tokens per prompt);
         more points (or a box) => the single-mask output with dynamic selection, decoded in the engine's exact precision mode (the handle
-        must have been created with precision="exact").  Corrections of frames that have already been tracked are not built."""
+        must have been created with precision="exact").  On a frame a propagation has already gone over the call is a CORRECTION, as upstream:
+        the frame's features are conditioned on the memory bank (in the direction the frame was tracked), its previous output is the mask
+        prompt, and the new output replaces the frame's tracked (non-conditioning) output at the next propagation's preflight."""
         if self.images is None:
             raise RuntimeError("call init_state() first")
         if (points is not None) != (labels is not None):
@@ -442,8 +445,6 @@ class VideoPredictor:
             self.obj_ids.append(obj_id)
             self.out[obj_id] = {"cond": {}, "non_cond": {}}
             self.temp[obj_id] = {}
-        if frame_idx in self.out[obj_id]["non_cond"]:
-            raise NotImplementedError("correcting a frame that has already been tracked is not built")
         Hv, Wv = self.video_hw
         xy = pts / np.array([Wv, Hv], np.float32) if normalize_coords else pts
         xy = (xy * np.float32(self.image_size)).astype(np.float32)
@@ -454,13 +455,20 @@ class VideoPredictor:
         if len(xy) > 9:
             raise NotImplementedError("at most 9 points per object and frame (16 decoder tokens)")
         held[(obj_id, frame_idx)] = (xy, lab)
-        prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx)
+        # a frame a propagation has already gone over is CORRECTED (upstream: is_init_cond_frame False): features conditioned on the memory bank
+        # in the direction the frame was tracked, and the new output stays a non-conditioning one (add_all_frames_to_correct_as_cond False)
+        is_init = (obj_id, frame_idx) not in self._tracked
+        prev = self.temp[obj_id].get(frame_idx) or self.out[obj_id]["cond"].get(frame_idx) or self.out[obj_id]["non_cond"].get(frame_idx)
         mask_in = prev["pred_masks"].clamp(-32.0, 32.0).view(1, 256, 256).contiguous() if prev is not None else None
-        raw = self._frame(frame_idx)
-        emb = self._new(4096, 256)
-        self._ck(self.lib.saber_k_add_to_bf16(self._p(raw), self._p(self.pos_no_mem), 1, None, self._p(emb), 4096, 256, self._s()))
+        reverse = False if is_init else self._tracked[(obj_id, frame_idx)]
+        raw = self._frame(frame_idx, reverse)
+        if is_init:
+            emb = self._new(4096, 256)
+            self._ck(self.lib.saber_k_add_to_bf16(self._p(raw), self._p(self.pos_no_mem), 1, None, self._p(emb), 4096, 256, self._s()))
+        else:
+            emb = self._memory_conditioned(obj_id, frame_idx, raw, reverse)
         low, obj_v, ptr = self._sam_heads(emb, mask_in, multimask=len(xy) <= 1, slot=self._slot(frame_idx), points=xy, labels=lab)
-        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": None, "raw": raw}
+        self.temp[obj_id][frame_idx] = {"pred_masks": low, "obj_ptr": ptr, "obj": obj_v, "mem": None, "raw": raw, "is_cond": is_init}
         return frame_idx, list(self.obj_ids), self._resize(low, 256, 256, Hv, Wv)[None, None]
 
     NO_OBJ_SCORE = -1024.0
@@ -507,6 +515,7 @@ class VideoPredictor:
         self.out.pop(obj_id, None)
         self.temp.pop(obj_id, None)
         self._points = {k: v for k, v in self.__dict__.get("_points", {}).items() if k[0] != obj_id}
+        self._tracked = {k: v for k, v in self._tracked.items() if k[0] != obj_id}
         if not need_output or not self.obj_ids:
             return list(self.obj_ids), []
         return list(self.obj_ids), [(t, self._frame_output(t)[2]) for t in input_frames]
@@ -518,7 +527,11 @@ class VideoPredictor:
                     mfm = self._resize(o["pred_masks"], 256, 256, 1024, 1024, antialias=0, post=2, a=20.0, c=-10.0)     # binarised: is_mask_from_pts
                     o["mem"] = self._encode_memory(o["raw"], mfm, o["obj"] > 0)
                     o["raw"] = None
-                self.out[oid]["cond"][t] = o
+                if o.pop("is_cond", True):
+                    self.out[oid]["cond"][t] = o
+                else:
+                    self.out[oid]["non_cond"][t] = o
+            for t in self.out[oid]["cond"]:              # upstream keeps the two dictionaries disjoint (a corrected conditioning frame keeps its old output)
                 self.out[oid]["non_cond"].pop(t, None)
             self.temp[oid] = {}
             if not self.out[oid]["cond"]:
@@ -644,6 +657,7 @@ class VideoPredictor:
         for t in order:
             outs = []
             for oid in self.obj_ids:
+                self._tracked[(oid, t)] = reverse
                 if t in self.out[oid]["cond"]:
                     low = self.out[oid]["cond"][t]["pred_masks"]
                 else:

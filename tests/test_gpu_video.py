@@ -334,6 +334,34 @@ def test_box_and_several_clicks_against_oracle():
                 assert iou > 0.97 or (not g.any() and not r.any())
         with pytest.raises(ValueError):
             vp.add_new_points_or_box(0, 9, box=[1, 1, 5, 5], clear_old_points=False)
+        # ---- corrections of a frame that a propagation has already gone over (upstream: is_init_cond_frame False): memory-conditioned
+        # features in the direction the frame was tracked, previous output as the mask prompt, the result stays a non-conditioning output
+        yy, xx = np.mgrid[:128, :128]
+        seed = ((yy - 64) ** 2 + (xx - 64) ** 2 < (128 // 6) ** 2).astype(np.float32)
+        P.init_state(V.load_tomogram_frames(tomo), video_hw=(1024, 1024))
+        vp.init_state(load_tomogram_frames(tomo), video_hw=(1024, 1024))
+        for pred in (P, vp):
+            pred.add_new_mask(1, 1, seed)
+            for _ in pred.propagate_in_video(1, max_frame_num_to_track=3):
+                pass
+        for step, kw in (("one click (bf16 decoder, multimask)", dict(points=[[600.0, 500.0]], labels=[0])),
+                         ("second click (exact-mode decoder, single mask)", dict(points=[[420.0, 430.0]], labels=[1], clear_old_points=False))):
+            r = P.add_new_points_or_box(3, 1, **kw)
+            g = vp.add_new_points_or_box(3, 1, **kw)
+            e0 = _rel(vp.temp[1][3]["pred_masks"].cpu(), P.temp[1][3]["pred_masks"][0, 0])
+            ep = _rel(vp.temp[1][3]["obj_ptr"].cpu(), P.temp[1][3]["obj_ptr"])
+            gi, ri = g[2][0, 0].cpu() > 0, r[2][0, 0] > 0
+            iou = float((gi & ri).sum()) / max(1.0, float((gi | ri).sum()))
+            print(f"correction of tracked frame 3, {step}: low-res rel-rms {e0:.3e}, pointer {ep:.3e}, returned mask IoU {iou:.4f}")
+            assert e0 < 3e-2 and ep < 2e-2 and (iou > 0.97 or (not gi.any() and not ri.any()))
+            assert vp.temp[1][3]["is_cond"] is False and P.temp[1][3]["is_cond"] is False
+        ref = {t: lg for t, _, lg in P.propagate_in_video(4, max_frame_num_to_track=0)}        # preflight: frame 3's corrected output + its memory replace the tracked one
+        got = {t: lg for t, _, lg in vp.propagate_in_video(4, max_frame_num_to_track=0)}
+        assert 3 in vp.out[1]["non_cond"] and 3 not in vp.out[1]["cond"] and sorted(ref) == sorted(got) == [4]
+        g4, r4 = got[4][0, 0].cpu() > 0, ref[4][0, 0] > 0
+        iou = float((g4 & r4).sum()) / max(1.0, float((g4 | r4).sum()))
+        print(f"frame 4 re-tracked on the corrected memory of frame 3: mask IoU {iou:.4f}")
+        assert iou > 0.97 or (not g4.any() and not r4.any())
     finally:
         eng.close()
 
