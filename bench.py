@@ -234,6 +234,11 @@ def main():
 
     engines = [eng] + [Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, weight_format=a.dtype) for _ in range(a.workers - 1)]
     streams = [torch.cuda.Stream() for _ in engines]
+    # The headline runs with the m2m IoU pruning OFF (every one of the 9 216 refined candidates is upscaled, as in rounds 1-2): with the seeded
+    # synthetic weights nearly every candidate falls below cfgAMG's pred_iou_thresh, so the production default (pruning on, identical results)
+    # would skip almost all of that work - a property of the random IoU head, not of EM data.  The pruned time is reported beside it (`iou_pruning`).
+    for e_ in engines:
+        e_.set_iou_pruning(False)
 
     def run_steps(first, count, planes=None):
         """`count` slices starting at index `first`; with several workers they are dealt round-robin to the engine handles, each driven
@@ -346,6 +351,23 @@ def main():
         cap, rep = eng.graph_stats()
         out["hipgraph"] = dict(ab, what=f"same step, 6 slices each over the {len(engines)} engine handle(s) of the headline, launch sequences issued eagerly vs replayed from hipGraphs (encoder pass + each decoder batch)",
                                sequences_captured=cap, replays_so_far=rep, headline_uses_graphs=os.environ.get("SABER_AMD_GRAPHS", "1") != "0")
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail:
+        # the production default: IoU pruning of the m2m pass on (results identical, tests/test_gpu_graphs.py); NOT the headline, see above
+        for e_ in engines:
+            e_.set_iou_pruning(True)
+        run_steps(0, 2 * len(engines))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(0, 6)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / 6
+        pruned, seen = eng.last_pruning()
+        out["iou_pruning"] = {"what": "same step with saber_engine_set_iou_pruning on (the engine's default): m2m candidates whose four IoU predictions are all <= pred_iou_thresh skip "
+                                      "the mask upscaling; identical masks.  The fraction pruned is a property of the weights: the seeded IoU head puts nearly every candidate below cfgAMG's "
+                                      "threshold, a trained one does not - this is why the headline runs with pruning off",
+                              "ms_per_slice": dtp * 1e3, "slices_per_s": 1.0 / dtp, "m2m_candidates": seen, "pruned": pruned, "pruned_fraction": (pruned / seen) if seen else None}
+        for e_ in engines:
+            e_.set_iou_pruning(False)
     if rank == 0 and world == 1 and not a.no_profile:
         eng.profile_begin()
         step(0)

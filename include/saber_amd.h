@@ -193,6 +193,13 @@ int saber_engine_graph_stats(const saber_engine* e, int* captures, int* replays)
 /* Host synchronisations (hipStreamSynchronize) the last saber_amg_generate call on this handle needed: 2 per group of crops decoded
  * together + 1 at the end (7 for cfgAMG's default 1 + 4 + 16 crop pyramid), more only when a scratch buffer had to grow. */
 int saber_amg_last_syncs(const saber_engine* e);
+/* IoU pruning of the m2m pass (on by default; results are identical either way): a refined candidate reports its mask 0's IoU prediction or
+ * the best of the other three (dynamic multimask selection, upstream sam2 MaskDecoder._dynamic_multimask_via_stability); when all four
+ * predictions are <= params->pred_iou_thresh it cannot pass the `predicted_iou > pred_iou_thresh` filter of the mask generator
+ * (upstream automatic_mask_generator._process_batch), so its masks are neither upscaled nor read.  saber_amg_last_pruning: how many of the
+ * last saber_amg_generate call's m2m candidates were skipped. */
+int saber_engine_set_iou_pruning(saber_engine* e, int enable);
+int saber_amg_last_pruning(const saber_engine* e, int64_t* pruned, int64_t* m2m_candidates);
 
 /* plane[y][x] = (position in order_host)+1 of the LAST mask covering the pixel, 0 if none. */
 int saber_label_plane(saber_engine* e, const uint32_t* bits_dev, const int* order_host, int n, int H, int W,

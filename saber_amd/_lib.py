@@ -68,6 +68,8 @@ SIGNATURES = {
     "saber_decode_prompts": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),
     "saber_amg_last_syncs": (_i, [_vp]),
+    "saber_engine_set_iou_pruning": (_i, [_vp, _i]),
+    "saber_amg_last_pruning": (_i, [_vp, _vp, _vp]),
     "saber_engine_set_graphs": (_i, [_vp, _i]),
     "saber_engine_set_weight_format": (_i, [_vp, _i]),
     "saber_engine_set_precision": (_i, [_vp, _i]),

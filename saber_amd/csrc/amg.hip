@@ -75,6 +75,11 @@ static void gen_crop_boxes(int H, int W, int n_layers, float overlap_ratio, std:
 }
 
 extern "C" int saber_amg_last_syncs(const saber_engine* e) { return e ? e->amg_last_syncs : -1; }
+extern "C" int saber_amg_last_pruning(const saber_engine* e, int64_t* pruned, int64_t* m2m_candidates) {
+    if (!e || !pruned || !m2m_candidates) return SABER_ERR_INVALID;
+    *pruned = e->amg_last_pruned; *m2m_candidates = e->amg_last_m2m;
+    return SABER_OK;
+}
 
 extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, int W, int channels, const saber_amg_params* prm,
                                   uint32_t* out_bits_dev, int max_masks, saber_mask_meta* out_meta, int* out_count, void* stream) {
@@ -89,6 +94,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     hipStream_t s = (hipStream_t)stream;
     *out_count = 0;
     e->amg_last_syncs = 0;
+    ENG_HIP(e, hipMemsetAsync(e->prune_counters, 0, 16, (hipStream_t)stream));
     const int W32 = (W + 31) >> 5;
     const size_t mask_words = (size_t)H * W32;
     const int M = prm->multimask_output ? 3 : 1;
@@ -247,8 +253,9 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                 float* low2 = e->amg_low2 + gr.k0 * 4 * 65536;
                 float* iou2 = e->amg_iou2 + gr.k0;
                 int* sel2 = e->amg_sel + gr.k0;
-                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)pts2, G * nm, first_raw, (long long)(uintptr_t)low1, (long long)(uintptr_t)low2, (long long)(uintptr_t)iou2, (long long)(uintptr_t)sel2}), s,
-                                [&]() { return eng_decode_ex(e, ci, nm, pts2, nullptr, G * nm, 0, low1, first_raw, 32.0f, low2, 1, iou2, nullptr, sel2, s); }));
+                TRY(eng_graphed(e, "dec2," + key_of({ci, nm, (long long)(uintptr_t)pts2, G * nm, first_raw, (long long)(uintptr_t)low1, (long long)(uintptr_t)low2, (long long)(uintptr_t)iou2, (long long)(uintptr_t)sel2,
+                                                     (long long)(e->iou_prune ? std::lround(prm->pred_iou_thresh * 1e6f) + 1 : 0)}), s,
+                                [&]() { return eng_decode_ex(e, ci, nm, pts2, nullptr, G * nm, 0, low1, first_raw, 32.0f, low2, 1, iou2, nullptr, sel2, s, prm->pred_iou_thresh); }));
                 for (int g = 0; g < G; ++g) e->slot_embb_valid[ci + g] = 1;       // (bookkeeping of the m2m decode, for replays)
                 gr.masks = low2; gr.ious = iou2; gr.plane_mode = 2;
             }
@@ -399,7 +406,10 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         m.crop_box_xywh[0] = (float)cd.crop[0]; m.crop_box_xywh[1] = (float)cd.crop[1];
         m.crop_box_xywh[2] = (float)(cd.crop[2] - cd.crop[0]); m.crop_box_xywh[3] = (float)(cd.crop[3] - cd.crop[1]);
     }
+    unsigned long long h_pr[2] = {0, 0};
+    ENG_HIP(e, hipMemcpyAsync(h_pr, e->prune_counters, 16, hipMemcpyDeviceToHost, s));
     { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
+    e->amg_last_pruned = (int64_t)h_pr[0]; e->amg_last_m2m = (int64_t)h_pr[1];
     *out_count = nf;
     return SABER_OK;
 }

@@ -870,7 +870,8 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
                                                           const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
-                                                          const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups) {
+                                                          const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups,
+                                                          const uint8_t* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
     char* w2s = w1s + UP_W1S;
@@ -940,8 +941,12 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
     const int64_t obase = ((int64_t)fg * 256 + gy * 4 + dy1 * 2) * 256 + gx * 4 + dx1 * 2;
     const bool fb0 = fg & 1, fb1 = fg >> 1;
     __syncthreads();   // resident weights visible; the only workgroup barrier of the kernel
-    if (grp < P) xload(grp, xf);
-    for (int p = grp; p < P; p += groups) {
+    // live (optional): prompts whose flag is 0 are skipped altogether (their masks are never read: engine.hip decode_chunk, IoU pruning)
+    auto next_live = [&](int q) { while (live && q < P && !live[q]) q += groups; return q; };     // block-uniform
+    int p = next_live(grp);
+    if (p < P) xload(p, xf);
+    for (int pn; p < P; p = pn) {
+        pn = next_live(p + groups);
         // compiler fence: without it the loop-invariant weight fragments (32 + 16 ds_read_b128 per wave) are hoisted out of the
         // prompt loop and spill
         asm volatile("" ::: "memory");
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             }
         }
         // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
-        if (p + groups < P) xload(p + groups, xf);
+        if (pn < P) xload(pn, xf);
         // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
         bf16x8 uf[2];
         {
@@ -1072,11 +1077,11 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
 
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap sm, const float* hyper, float* masks4, int P,
-                               hipStream_t s) {
+                               hipStream_t s, const uint8_t* live) {
     if (P <= 0) return nullptr;
     if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
     const int groups = P >= 2 ? 2 : 1;   // 128 tiles x 2 groups = one resident block per CU
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups);
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups, live);
     return nullptr;
 }
 

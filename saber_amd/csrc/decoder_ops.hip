@@ -598,11 +598,16 @@ __global__ __launch_bounds__(1024) void mask_select_dynamic_kernel(const float* 
 // The selection alone, for callers that read the chosen planes in place (the AMG driver: K8 takes a plane index, the m2m pass reads the
 // first pass's planes through an index map): out_iou as mask_select*, out_sel[p] = chosen plane of prompt p (single-mask mode).
 __global__ __launch_bounds__(1024) void mask_pick_kernel(const float* __restrict__ masks4, const float* __restrict__ iou4, int multimask,
-                                                         float* __restrict__ out_iou, int* __restrict__ out_sel, float delta, float thresh) {
+                                                         float* __restrict__ out_iou, int* __restrict__ out_sel, float delta, float thresh,
+                                                         const uint8_t* __restrict__ live) {
     __shared__ int red[2][16];
     const int p = blockIdx.x, tid = threadIdx.x;
     if (multimask) {
         if (tid < 3) out_iou[p * 3 + tid] = iou4[p * 4 + 1 + tid];
+        return;
+    }
+    if (live && !live[p]) {      // pruned prompt: its planes were not computed; either choice fails the caller's IoU filter
+        if (tid == 0) { out_iou[p] = iou4[p * 4]; if (out_sel) out_sel[p] = 0; }
         return;
     }
     const float4* m0 = reinterpret_cast<const float4*>(masks4 + (int64_t)p * 4 * 65536);
@@ -632,9 +637,28 @@ __global__ __launch_bounds__(1024) void mask_pick_kernel(const float* __restrict
         if (out_sel) out_sel[p] = sel;
     }
 }
-const char* launch_mask_pick(const float* masks4, const float* iou4, int P, int multimask, float* out_iou, int* out_sel, hipStream_t s) {
+const char* launch_mask_pick(const float* masks4, const float* iou4, int P, int multimask, float* out_iou, int* out_sel, hipStream_t s, const uint8_t* live) {
     if (P <= 0) return nullptr;
-    hipLaunchKernelGGL(mask_pick_kernel, dim3(P), dim3(multimask ? 64 : 1024), 0, s, masks4, iou4, multimask, out_iou, out_sel, 0.05f, 0.98f);
+    hipLaunchKernelGGL(mask_pick_kernel, dim3(P), dim3(multimask ? 64 : 1024), 0, s, masks4, iou4, multimask, out_iou, out_sel, 0.05f, 0.98f, live);
+    return nullptr;
+}
+__global__ __launch_bounds__(256) void iou_live_flags_kernel(const float* __restrict__ iou4, int P, float thr, uint8_t* __restrict__ live,
+                                                             unsigned long long* __restrict__ counters) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool l = true;
+    if (p < P) {
+        const float4 v = *reinterpret_cast<const float4*>(iou4 + 4 * p);
+        l = v.x > thr || v.y > thr || v.z > thr || v.w > thr;
+        live[p] = l ? 1 : 0;
+    }
+    if (counters) {      // statistics: [0] += pruned prompts, [1] += prompts seen
+        const unsigned long long dead = __ballot(p < P && !l), seen = __ballot(p < P);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[0], (unsigned long long)__popcll(dead)); atomicAdd(&counters[1], (unsigned long long)__popcll(seen)); }
+    }
+}
+const char* launch_iou_live_flags(const float* iou4, int P, float thr, uint8_t* live, unsigned long long* counters, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    hipLaunchKernelGGL(iou_live_flags_kernel, dim3((P + 255) / 256), dim3(256), 0, s, iou4, P, thr, live, counters);
     return nullptr;
 }
 

@@ -78,6 +78,10 @@ struct saber_engine {
     // encoder workspace
     float *pix = nullptr, *xa = nullptr, *xb = nullptr, *lat3 = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    bool iou_prune = true;          // AMG m2m pass: skip the mask upscaling of candidates whose predicted IoUs cannot pass pred_iou_thresh (identical results)
+    uint8_t* live = nullptr;        // per-prompt flags of the decode chunk in progress
+    unsigned long long* prune_counters = nullptr;   // device: [0] pruned, [1] seen (accumulated by iou_live_flags_kernel)
+    int64_t amg_last_pruned = 0, amg_last_m2m = 0;    // statistics of the last saber_amg_generate call (bench.py)
     int decode_n_pts = 1;           // points per prompt of the decode call in progress (saber_decode_prompts; exact precision only when > 1)
     uint8_t *xn8_s = nullptr, *hid8_s = nullptr; int64_t mx_rows = 0;   // MXFP8 weight format: scale panels of the MX activations (their e4m3 bytes reuse xn / hid); mx_rows = panel rows
     bf16_t* sb[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -191,7 +195,7 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
 // buffer from a multimask decode and prompt q refines plane 1 + q % 3 of its prompt q / 3.
 int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                   const float* mask_in_dev, int mask_in_raw4, float mask_clamp, float* out_lowres, int out_raw4, float* out_iou, float* out_obj,
-                  int* out_sel, hipStream_t s);
+                  int* out_sel, hipStream_t s, float prune_iou_thr = 0.f);   // prune_iou_thr > 0 (single-mask raw-plane decodes): candidates whose four predicted IoUs are all <= it skip the mask upscaling
 // exact-precision mode (exact.hip): the Hiera blocks + neck of n images already patch-embedded in e->xa; one chunk of the decoder
 int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s);
 int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, const float* mask_in,

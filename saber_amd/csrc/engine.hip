@@ -144,6 +144,11 @@ extern "C" int saber_engine_set_precision(saber_engine* e, int precision) {
     e->precision = precision;
     return SABER_OK;
 }
+extern "C" int saber_engine_set_iou_pruning(saber_engine* e, int enable) {
+    if (!e) return SABER_ERR_INVALID;
+    if ((bool)enable != e->iou_prune) { e->iou_prune = enable != 0; eng_graphs_flush(e); }      // (captured decode sequences contain the choice)
+    return SABER_OK;
+}
 extern "C" int saber_engine_set_graphs(saber_engine* e, int enable) {
     if (!e) return SABER_ERR_INVALID;
     e->graphs_on = enable != 0;
@@ -697,6 +702,9 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     e->slot_shared_valid.assign(B, 0);
     e->slot_embb_valid.assign(B, 0);
 
+    TRY(eng_alloc(e, &e->live, P));
+    TRY(eng_alloc(e, &e->prune_counters, 2));
+    ENG_HIP(e, hipMemset(e->prune_counters, 0, 16));
     TRY(eng_alloc(e, &e->tok_pe, P * 8 * 256));
     TRY(eng_alloc(e, &e->queries, P * 8 * 256));
     TRY(eng_alloc(e, &e->tq, P * 8 * 256));
@@ -1137,7 +1145,7 @@ static int ensure_embb(saber_engine* e, int slot, hipStream_t s) {
 // mask_in_q0 >= 0: mask_in is the raw 4-plane output of a multimask decode, this chunk's first prompt refines global candidate mask_in_q0
 static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, const float* pts, const int* labels, int P, int multimask,
                         const float* mask_in, float mask_clamp, float* out_lowres, float* out_iou, float* out_obj, hipStream_t s,
-                        float* raw4_out = nullptr, int* out_sel = nullptr, int mask_in_q0 = -1) {
+                        float* raw4_out = nullptr, int* out_sel = nullptr, int mask_in_q0 = -1, float prune_iou_thr = 0.f) {
     if (e->precision == SABER_PRECISION_EXACT) {
         float* m4 = raw4_out ? raw4_out : e->masks4;
         TRY(exact_decode_core(e, slot0, per_slot, p_base, pts, labels, P, mask_in, mask_clamp, mask_in_q0, out_obj, m4, s, e->decode_n_pts));
@@ -1310,13 +1318,20 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, gemm_bytes(g), launch_gemm(g, s));
     }
     }   // (separate token-side launches)
+    // IoU pruning (the AMG m2m pass): a single-mask candidate reports iou[0] or max(iou[1..3]) (dynamic multimask selection); when all four are
+    // <= the caller's pred_iou_thresh it fails that filter whatever its masks look like, so its 1 MB of planes is neither computed nor read
+    const uint8_t* live = nullptr;
+    if (prune_iou_thr > 0.f && raw4_out && !multimask && e->iou_prune) {
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_iou_live_flags(e->iou4, P, prune_iou_thr, e->live, e->prune_counters, s));
+        live = e->live;
+    }
     // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
            launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot0 * 16384 * 64,
-                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, raw4_out ? raw4_out : e->masks4, P, s));
+                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, raw4_out ? raw4_out : e->masks4, P, s, live));
     float* oi = out_iou ? out_iou : e->dec_out_iou;
     if (raw4_out) {
-        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s));
+        ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s, live));
         return SABER_OK;
     }
     float* om = out_lowres ? out_lowres : e->dec_out_masks;
@@ -1330,7 +1345,7 @@ int eng_decode(saber_engine* e, int slot, int per_slot, const float* pts_dev, co
 }
 int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev, const int* labels_dev, int n, int multimask,
                   const float* mask_in_dev, int mask_in_raw4, float mask_clamp, float* out_lowres, int out_raw4, float* out_iou, float* out_obj,
-                  int* out_sel, hipStream_t s) {
+                  int* out_sel, hipStream_t s, float prune_iou_thr) {
     if (!e->finalized) return eng_fail(e, SABER_ERR_STATE, "engine not finalized");
     if (!pts_dev || n < 0 || per_slot < 0) return eng_fail(e, SABER_ERR_INVALID, "decode: bad argument");
     if (per_slot == 0 || per_slot > n) per_slot = n > 0 ? n : 1;      // every prompt reads slot `slot`
@@ -1347,7 +1362,7 @@ int eng_decode_ex(saber_engine* e, int slot, int per_slot, const float* pts_dev,
                          min_, mask_clamp,
                          out_lowres && !out_raw4 ? out_lowres + (size_t)p0 * M * 65536 : nullptr, out_iou ? out_iou + (size_t)p0 * M : nullptr,
                          out_obj ? out_obj + p0 : nullptr, s, out_raw4 ? out_lowres + (size_t)p0 * 4 * 65536 : nullptr,
-                         out_sel ? out_sel + p0 : nullptr, mask_in_dev && mask_in_raw4 ? p0 : -1));
+                         out_sel ? out_sel + p0 : nullptr, mask_in_dev && mask_in_raw4 ? p0 : -1, prune_iou_thr));
     }
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;

@@ -145,7 +145,9 @@ const char* launch_dec_attention(const float* q, const float* k, const float* v,
 // masks[p][k][y][x] = sum_c hyper[p][k][c] * up[p][perm(y,x)][c]  (up: bf16 [P][65536][32], engine token order)
 const char* launch_mask_dot(const bf16_t* up, const float* hyper, int P, float* masks4, hipStream_t s);
 // multimask: out[p][0..2] = masks4[p][1..3], iou_out = iou4[:,1:]; else dynamic single-mask selection (delta 0.05 / thr 0.98)
-const char* launch_mask_pick(const float* masks4, const float* iou4, int P, int multimask, float* out_iou, int* out_sel, hipStream_t s);
+const char* launch_mask_pick(const float* masks4, const float* iou4, int P, int multimask, float* out_iou, int* out_sel, hipStream_t s, const uint8_t* live = nullptr);
+// live[p] = iou4[p][0] > thr || max(iou4[p][1..3]) > thr: whether a single-mask (dynamic multimask) candidate can pass a `predicted IoU > thr` filter at all
+const char* launch_iou_live_flags(const float* iou4, int P, float thr, uint8_t* live, unsigned long long* counters, hipStream_t s);
 const char* launch_mask_select(const float* masks4, const float* iou4, int P, int multimask, float* out_masks, float* out_iou,
                                int* counts_ws, hipStream_t s);
 
@@ -159,7 +161,7 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s, const XBuild* build = nullptr);
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap slot_map, const float* hyper, float* masks4, int P,
-                               hipStream_t s);
+                               hipStream_t s, const uint8_t* live = nullptr);   // live: optional per-prompt flags, prompts with 0 are skipped
 const char* decoder_fused_init_device();
 
 // ------------------------------------------------------------------ decoder_tokens.hip

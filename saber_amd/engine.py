@@ -256,6 +256,16 @@ class Engine:
         self._check(self.lib.saber_engine_set_precision(self.h, 1 if precision == "exact" else 0))
         self.precision = precision
 
+    def set_iou_pruning(self, enable: bool):
+        """IoU pruning of the AMG m2m pass (include/saber_amd.h: saber_engine_set_iou_pruning); on by default, results identical."""
+        self._check(self.lib.saber_engine_set_iou_pruning(self.h, int(bool(enable))))
+
+    def last_pruning(self):
+        """(m2m candidates skipped, m2m candidates) of the last amg_generate call"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.saber_amg_last_pruning(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_graphs(self, enable: bool):
         """hipGraph replay of the AMG launch sequences (include/saber_amd.h: saber_engine_set_graphs)."""
         self._check(self.lib.saber_engine_set_graphs(self.h, int(bool(enable))))

@@ -70,3 +70,38 @@ def test_amg_result_does_not_depend_on_the_encoder_batch_size():
         eng.close()
     for b, m in results[1:]:
         assert m == results[0][1] and np.array_equal(b, results[0][0])
+
+
+def test_iou_pruning_of_the_m2m_pass_changes_nothing_but_the_time():
+    """saber_engine_set_iou_pruning: m2m candidates whose four IoU predictions are all <= pred_iou_thresh skip the mask upscaling (they cannot
+    pass the generator's IoU filter whichever plane the dynamic multimask selection picks).  Masks, order and metadata must be identical with
+    pruning on and off, at a threshold that prunes a part of the candidates (the quantile of the unfiltered IoUs), eagerly and under graph
+    replay; with the threshold at 0 nothing is pruned."""
+    from oracle import saber_ref
+    from saber_amd.engine import Engine, make_amg_params
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    cfg = get_config("tiny")
+    w = seeded_weights(cfg, 0)
+    eng = Engine("tiny", weights=w, max_images=5, max_prompts=256)
+    ref = Engine("tiny", weights=w, max_images=5, max_prompts=256)
+    ref.set_iou_pruning(False)
+    try:
+        img = eng.prepare(torch.from_numpy(saber_ref.synthetic_slice(seed=4, size=512)).cuda())
+        base = dict(npoints=8, crop_n_layers=1, stability_score_thresh=0.0, box_nms_thresh=1.0, crop_nms_thresh=1.0)
+        _, meta = eng.amg_generate(img, make_amg_params(dict(base, pred_iou_thresh=0.0)), max_masks=8192)
+        assert eng.last_pruning()[0] == 0                          # (no threshold: nothing can be pruned)
+        ious = np.sort(np.array([m.predicted_iou for m in meta]))
+        for q in (0.5, 0.9):
+            thr = float(ious[int(q * len(ious))])
+            params = make_amg_params(dict(base, pred_iou_thresh=thr))
+            for rep in range(3):                         # eager, captured, replayed
+                b, m = _run(eng, img, params)
+                pruned, seen = eng.last_pruning()
+                b0, m0 = _run(ref, img, params)
+                assert ref.last_pruning() == (0, 0)
+                assert m == m0 and np.array_equal(b, b0) and len(m) > 0
+                assert 0 < pruned < seen
+            print(f"pred_iou_thresh {thr:.4f} (quantile {q}): {len(m)} masks, {pruned} of {seen} m2m candidates pruned before the upscaling")
+    finally:
+        eng.close(); ref.close()
