@@ -146,9 +146,26 @@ def tail_mode(eng, pool, a, segment_slice_to_plane, make_amg_params):
         segment_slice_to_plane(eng, pool[i % len(pool)], params0, min_mask_area=50)
     torch.cuda.synchronize()
     dt0 = (time.perf_counter() - t0) / reps
+    # the same few-hundred-mask slice with the engine's IoU pruning of the m2m pass on (identical masks): what the pruning buys when the IoU head
+    # separates candidates the way a trained one does (a few hundred of 9 216 above the threshold)
+    eng.set_iou_pruning(True)
+    try:
+        segment_slice_to_plane(eng, pool[0], params, min_mask_area=50, max_masks=4096)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            segment_slice_to_plane(eng, pool[i % len(pool)], params, min_mask_area=50, max_masks=4096)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / reps
+        _, meta_p = eng.amg_generate(eng.prepare(pool[0]), params, max_masks=4096)
+        pruned, seen = eng.last_pruning()
+    finally:
+        eng.set_iou_pruning(False)
     return {"what": "same step with score filters that leave a few hundred masks (pred_iou_thresh = own quantile, stability / NMS off), one engine handle",
             "pred_iou_thresh": thr, "masks_per_slice": n_amg, "painted_per_slice": painted / reps, "ms_per_slice": dt * 1e3,
-            "ms_per_slice_default_thresholds_same_handle": dt0 * 1e3, "tail_ms": (dt - dt0) * 1e3, "host_syncs_per_slice": syncs}
+            "ms_per_slice_default_thresholds_same_handle": dt0 * 1e3, "tail_ms": (dt - dt0) * 1e3, "host_syncs_per_slice": syncs,
+            "with_iou_pruning": {"ms_per_slice": dtp * 1e3, "masks_per_slice": len(meta_p), "m2m_candidates": seen, "pruned": pruned,
+                                 "what": "saber_engine_set_iou_pruning(1), the engine's default: candidates that cannot pass pred_iou_thresh skip the mask upscaling; same masks"}}
 
 
 def precision_check(weights, img):
