@@ -193,6 +193,11 @@ int saber_engine_graph_stats(const saber_engine* e, int* captures, int* replays)
 /* Host synchronisations (hipStreamSynchronize) the last saber_amg_generate call on this handle needed: 2 per group of crops decoded
  * together + 1 at the end (7 for cfgAMG's default 1 + 4 + 16 crop pyramid), more only when a scratch buffer had to grow. */
 int saber_amg_last_syncs(const saber_engine* e);
+/* Where the generator's post-processing runs: 1 (default) = on the device - IoU / stability / crop-edge filters, the
+ * per-crop box NMS, the cross-crop NMS and the compaction of the survivors are kernels on the caller's stream and a slice costs ONE host
+ * synchronisation; 0 = the host restatement of round 1-2 (3 synchronisations).  Identical masks, order and records either way
+ * (tests/test_gpu_graphs.py); generators with more than 12 288 candidates per image use the host path. */
+int saber_engine_set_device_amg(saber_engine* e, int enable);
 /* IoU pruning of the m2m pass (on by default; results are identical either way): a refined candidate reports its mask 0's IoU prediction or
  * the best of the other three (dynamic multimask selection, upstream sam2 MaskDecoder._dynamic_multimask_via_stability); when all four
  * predictions are <= params->pred_iou_thresh it cannot pass the `predicted_iou > pred_iou_thresh` filter of the mask generator

@@ -100,6 +100,10 @@ int saber_k_quant_mx(const uint16_t* x, int64_t ldx, int C, uint8_t* out, int64_
 /* LayerNorm over C of fp32 rows, written straight as an MX operand */
 int saber_k_ln_mx(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* scales, int64_t scale_rows,
                   int64_t M, void* stream);
+/* torchvision.ops.nms as the mask generator's device path runs it (csrc/amg_device.hip: stable descending score order, suppress box IoU >
+ * iou_thresh, fp32): boxes (n,4) xyxy, scores (n), n <= 12288; scratch: n * 64 bytes; keep_out (n) receives the kept indices in score order,
+ * count_out their number.  One workgroup. */
+int saber_k_box_nms(const float* boxes_xyxy, const float* scores, int n, float iou_thresh, void* scratch, int* keep_out, int* count_out, void* stream);
 /* one-head attention of 256 channels, flash style (the memory attention of the video path, upstream MemoryAttentionLayer self / cross attention):
  * out = bf16(softmax(scale Q K^T) V + bias_v); Q [n_q][256], K, V [n_keys][256] bf16 row-major, n_q a multiple of 64; ws: scratch of at least
  * (n_q / 64) * 8 * 64 * 258 floats for the split over the keys, or NULL */

@@ -69,6 +69,7 @@ SIGNATURES = {
     "saber_amg_generate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(AmgParams), _vp, _i, C.POINTER(MaskMeta), C.POINTER(_i), _vp]),
     "saber_amg_last_syncs": (_i, [_vp]),
     "saber_engine_set_iou_pruning": (_i, [_vp, _i]),
+    "saber_engine_set_device_amg": (_i, [_vp, _i]),
     "saber_amg_last_pruning": (_i, [_vp, _vp, _vp]),
     "saber_engine_set_graphs": (_i, [_vp, _i]),
     "saber_engine_set_weight_format": (_i, [_vp, _i]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "saber_k_dwconv7_t": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_conv4x4s4": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "saber_k_resize_plane": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "saber_k_box_nms": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "saber_k_gemm_mx": (_i, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _vp]),
     "saber_k_quant_mx": (_i, [_vp, C.c_int64, _i, _vp, C.c_int64, _i, _vp, C.c_int64, C.c_int64, _vp]),
     "saber_k_ln_mx": (_i, [_vp, C.c_int64, _vp, _vp, _f, _i, _vp, C.c_int64, _i, _vp, C.c_int64, C.c_int64, _vp]),

@@ -75,6 +75,11 @@ static void gen_crop_boxes(int H, int W, int n_layers, float overlap_ratio, std:
 }
 
 extern "C" int saber_amg_last_syncs(const saber_engine* e) { return e ? e->amg_last_syncs : -1; }
+extern "C" int saber_engine_set_device_amg(saber_engine* e, int enable) {
+    if (!e) return SABER_ERR_INVALID;
+    e->amg_device = enable != 0;
+    return SABER_OK;
+}
 extern "C" int saber_amg_last_pruning(const saber_engine* e, int64_t* pruned, int64_t* m2m_candidates) {
     if (!e || !pruned || !m2m_candidates) return SABER_ERR_INVALID;
     *pruned = e->amg_last_pruned; *m2m_candidates = e->amg_last_m2m;
@@ -172,6 +177,30 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         e->amg_crop_words = need * mask_words;
         return SABER_OK;
     };
+    // ---- device-side post-processing (the default): everything after the decodes stays on the stream; the host path below is the fallback
+    // for generators with more candidates than the device NMS holds, and the reference the device path is tested against
+    size_t total_cand = 0;
+    int max_nm = 0;
+    for (int i = 0; i < (int)crops.size(); ++i) { const int nm_ = grid_n[layers[i]] * grid_n[layers[i]] * M; total_cand += (size_t)nm_; max_nm = std::max(max_nm, nm_); }
+    static const bool host_amg_env = getenv("SABER_AMD_HOST_AMG") != nullptr;
+    const bool use_dev = e->amg_device && !host_amg_env && total_cand <= 12288 && total_cand * mask_words * 4 <= ((size_t)6 << 30) && max_masks > 0;
+    size_t slot_base = 0;
+    if (use_dev) {
+        if (e->amg_dev_cap < total_cand) {
+            TRY(eng_regrow(e, &e->amg_pass, total_cand, s)); TRY(eng_regrow(e, &e->amg_tmp, total_cand, s)); TRY(eng_regrow(e, &e->amg_keep, total_cand, s));
+            TRY(eng_regrow(e, &e->amg_surv, total_cand, s)); TRY(eng_regrow(e, &e->amg_crops_dev, (size_t)256, s)); TRY(eng_regrow(e, &e->amg_counts, (size_t)256, s));
+            TRY(eng_regrow(e, &e->amg_crop_pts, total_cand * 2, s));
+            if (!e->amg_nsurv) { TRY(eng_alloc(e, &e->amg_nsurv, 1)); TRY(eng_alloc(e, &e->amg_count_dev, 1)); }
+            e->amg_dev_cap = total_cand;
+        }
+        if (e->amg_dev_masks_cap < (size_t)max_masks) {
+            TRY(eng_regrow(e, &e->amg_final_slots, (size_t)max_masks, s)); TRY(eng_regrow(e, &e->amg_meta_dev, (size_t)max_masks, s));
+            e->amg_dev_masks_cap = max_masks;
+        }
+        if (crops.size() > 256) return eng_fail(e, SABER_ERR_INVALID, "amg_generate: more than 256 crops");
+        TRY(crop_reserve(total_cand));                 // the K8 scratch holds EVERY candidate's slot: survivors are read from it at the end
+        ENG_HIP(e, hipMemsetAsync(e->amg_nsurv, 0, sizeof(int), s));
+    }
     std::vector<float> h_iou;
     std::vector<MaskStats> h_stats;
     std::vector<int> h_idx, h_plane, keep_src;
@@ -259,6 +288,29 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
                 for (int g = 0; g < G; ++g) e->slot_embb_valid[ci + g] = 1;       // (bookkeeping of the m2m decode, for replays)
                 gr.masks = low2; gr.ious = iou2; gr.plane_mode = 2;
             }
+        }
+        if (use_dev) {
+            // K9a: IoU filter + plane index per group; K8 for every crop (filtered candidates exit at once); K9b / K10: filters, NMS, compaction per crop
+            const float* iou_all = prm->use_m2m ? e->amg_iou2 : e->amg_iou1;
+            std::vector<DevCrop> dcs;
+            for (const Grp& gr : groups) {
+                ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_amg_plane(iou_all + gr.k0, gr.plane_mode == 2 ? e->amg_sel + gr.k0 : nullptr, gr.G * gr.nm, gr.plane_mode, prm->pred_iou_thresh,
+                                                                  e->amg_idx + gr.k0, e->amg_pass + gr.k0, s));
+                for (int g = 0; g < gr.G; ++g) {
+                    const auto& box = crops[c0 + gr.ci + g];
+                    DevCrop dc{{box[0], box[1], box[2], box[3]}, (int)(gr.k0 + (size_t)g * gr.nm), gr.nm, (int)(gr.pt0 + (size_t)g * gr.np), M};
+                    dcs.push_back(dc);
+                    ENG_KP(e, PC_MASK_POST, 0.0, (double)gr.nm * (65536.0 * 4 + (double)mask_words * 4),
+                           launch_mask_post(gr.masks, e->amg_idx + dc.kbase, gr.nm, box[0], box[1], box[2] - box[0], box[3] - box[1], H, W, prm->mask_threshold,
+                                            prm->stability_score_offset, e->amg_crop_bits + (slot_base + dc.kbase) * mask_words, e->amg_stats + dc.kbase, s, e->amg_pass + dc.kbase));
+                }
+            }
+            ENG_HIP(e, hipMemcpyAsync(e->amg_crops_dev, dcs.data(), sizeof(DevCrop) * dcs.size(), hipMemcpyHostToDevice, s));
+            ENG_HIP(e, hipMemcpyAsync(e->amg_crop_pts, crop_pts_all.data(), sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, s));
+            ENG_KP(e, PC_MASK_POST, 0.0, 0.0, launch_amg_crops(e->amg_crops_dev, (int)dcs.size(), max_nm, e->amg_stats, e->amg_pass, iou_all, e->amg_crop_pts, prm->stability_score_thresh,
+                                                            prm->box_nms_thresh, H, W, (int)slot_base, e->amg_tmp, e->amg_keep, e->amg_counts, e->amg_surv, e->amg_nsurv, (int)total_cand, s));
+            slot_base += n_cand;
+            continue;
         }
         // ---- phase 2: per-candidate scalars of the whole batch (sync 1)
         std::vector<float> h_iou_all(n_cand);
@@ -372,6 +424,25 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             acc_used += keep_src.size();
             keep_src.clear();
         }
+    }
+    if (use_dev) {
+        // cross-crop NMS, final order, records and the survivors' masks: one launch pair, then the slice's ONE synchronisation
+        ENG_KP(e, PC_MASK_POST, 0.0, 0.0, launch_amg_final(e->amg_surv, e->amg_nsurv, (int)total_cand, nc > 1 ? 1 : 0, prm->crop_nms_thresh, max_masks, e->amg_final_slots, e->amg_meta_dev,
+                                                        e->amg_count_dev, e->amg_crop_bits, out_bits_dev, (int64_t)mask_words, s));
+        int nf = 0;
+        unsigned long long h_pr[2] = {0, 0};
+        ENG_HIP(e, hipMemcpyAsync(&nf, e->amg_count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        ENG_HIP(e, hipMemcpyAsync(out_meta, e->amg_meta_dev, sizeof(saber_mask_meta) * max_masks, hipMemcpyDeviceToHost, s));
+        ENG_HIP(e, hipMemcpyAsync(h_pr, e->prune_counters, 16, hipMemcpyDeviceToHost, s));
+        { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
+        e->amg_last_pruned = (int64_t)h_pr[0]; e->amg_last_m2m = (int64_t)h_pr[1];
+        if (nf < 0) return eng_fail(e, SABER_ERR_HIP, "amg_generate: device post-processing overflow (internal)");
+        if (nf > max_masks) {
+            *out_count = nf;
+            return eng_fail(e, SABER_ERR_CAPACITY, "amg_generate: " + std::to_string(nf) + " masks exceed max_masks=" + std::to_string(max_masks));
+        }
+        *out_count = nf;
+        return SABER_OK;
     }
     std::vector<int> final_order(all.size());
     std::iota(final_order.begin(), final_order.end(), 0);

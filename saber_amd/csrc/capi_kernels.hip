@@ -24,6 +24,7 @@ extern "C" int saber_k_init(int device_id) {
     if (!m) m = hiera_attention_init_device();
     if (!m) m = image_ops_init_device();
     if (!m) m = decoder_fused_init_device();
+    if (!m) m = amg_device_init();
     (void)hipGetLastError();
     if (m) return kfail(m);
     return 0;
@@ -165,6 +166,9 @@ extern "C" int saber_k_quant_mx(const uint16_t* x, int64_t ldx, int C, uint8_t* 
 extern "C" int saber_k_ln_mx(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int C, uint8_t* out, int64_t ldo, int Kp, uint8_t* scales,
                              int64_t scale_rows, int64_t M, void* stream) {
     return kcheck(launch_ln_mx(x, ldx, gamma, beta, eps, C, out, ldo, Kp, scales, scale_rows, M, (hipStream_t)stream));
+}
+extern "C" int saber_k_box_nms(const float* boxes_xyxy, const float* scores, int n, float iou_thresh, void* scratch, int* keep_out, int* count_out, void* stream) {
+    return kcheck(launch_box_nms_probe(boxes_xyxy, scores, n, iou_thresh, scratch, keep_out, count_out, (hipStream_t)stream));
 }
 extern "C" int saber_k_flash256(const uint16_t* Q, const uint16_t* K, const uint16_t* V, int n_q, int n_keys, float scale, const float* bias_v, uint16_t* out, float* ws,
                                 int64_t ws_floats, void* stream) {

@@ -681,7 +681,8 @@ const char* launch_mask_select(const float* masks4, const float* iou4, int P, in
 template <bool PRE>
 __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ lowres, const int* __restrict__ idx, int crop_x0,
                                                         int crop_y0, int crop_w, int crop_h, int H, int W, float thr, float offset,
-                                                        uint32_t* __restrict__ bits, MaskStats* __restrict__ stats) {
+                                                        uint32_t* __restrict__ bits, MaskStats* __restrict__ stats, const uint8_t* __restrict__ pass) {
+    if (pass && !pass[blockIdx.y]) return;          // (device-side AMG: candidates the IoU filter dropped keep their initialised statistics)
     // per wave: the vertically blended source row (256 columns) lives in LDS, every output pixel is then two LDS reads
     __shared__ float vrow[4][256];
     __shared__ int red[4][8];
@@ -822,7 +823,8 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
 // Same arithmetic per pixel as mask_post_kernel: bit-identical masks and counts.
 __global__ __launch_bounds__(256) void mask_post_w1k_kernel(const float* __restrict__ lowres, const int* __restrict__ idx, int crop_x0,
                                                             int crop_y0, int crop_w, int crop_h, int H, int W, float thr, float offset,
-                                                            uint32_t* __restrict__ bits, MaskStats* __restrict__ stats) {
+                                                            uint32_t* __restrict__ bits, MaskStats* __restrict__ stats, const uint8_t* __restrict__ pass) {
+    if (pass && !pass[blockIdx.y]) return;
     __shared__ float vrow[4][260];
     __shared__ int red[4][8];
     const int mi = blockIdx.y;
@@ -945,14 +947,14 @@ __global__ void mask_stats_init_kernel(MaskStats* stats, int n) {
 
 extern int g_saber_debug_flags;
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
-                             int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s) {
+                             int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s, const uint8_t* pass) {
     if (n <= 0) return nullptr;
     if (crop_w <= 0 || crop_h <= 0) return "mask_post: empty crop";
     hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, n);
     const dim3 grid((H + MP_ROWS - 1) / MP_ROWS, n);
-    if (W <= 1024 && !(g_saber_debug_flags & 8)) hipLaunchKernelGGL(mask_post_w1k_kernel, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
-    else if (W <= 1024) hipLaunchKernelGGL(mask_post_kernel<true>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
-    else hipLaunchKernelGGL(mask_post_kernel<false>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats);
+    if (W <= 1024 && !(g_saber_debug_flags & 8)) hipLaunchKernelGGL(mask_post_w1k_kernel, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats, pass);
+    else if (W <= 1024) hipLaunchKernelGGL(mask_post_kernel<true>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats, pass);
+    else hipLaunchKernelGGL(mask_post_kernel<false>, grid, dim3(256), 0, s, lowres, idx, crop_x0, crop_y0, crop_w, crop_h, H, W, thr, offset, bits, stats, pass);
     return nullptr;
 }
 

@@ -78,6 +78,11 @@ struct saber_engine {
     // encoder workspace
     float *pix = nullptr, *xa = nullptr, *xb = nullptr, *lat3 = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    // device-side post-processing of the mask generator (amg_device.hip): filters, per-crop and cross-crop box NMS, compaction
+    bool amg_device = true;
+    uint8_t* amg_pass = nullptr; DevCand *amg_tmp = nullptr, *amg_keep = nullptr, *amg_surv = nullptr; DevCrop* amg_crops_dev = nullptr;
+    int *amg_counts = nullptr, *amg_nsurv = nullptr, *amg_final_slots = nullptr, *amg_count_dev = nullptr; float* amg_crop_pts = nullptr;
+    saber_mask_meta* amg_meta_dev = nullptr; size_t amg_dev_cap = 0, amg_dev_masks_cap = 0;
     bool iou_prune = true;          // AMG m2m pass: skip the mask upscaling of candidates whose predicted IoUs cannot pass pred_iou_thresh (identical results)
     uint8_t* live = nullptr;        // per-prompt flags of the decode chunk in progress
     unsigned long long* prune_counters = nullptr;   // device: [0] pruned, [1] seen (accumulated by iou_live_flags_kernel)

@@ -39,6 +39,9 @@ template int eng_alloc<uint32_t>(saber_engine*, uint32_t**, size_t);
 template int eng_alloc<MaskStats>(saber_engine*, MaskStats**, size_t);
 template int eng_alloc<double>(saber_engine*, double**, size_t);
 template int eng_alloc<uint8_t>(saber_engine*, uint8_t**, size_t);
+template int eng_alloc<DevCand>(saber_engine*, DevCand**, size_t);
+template int eng_alloc<DevCrop>(saber_engine*, DevCrop**, size_t);
+template int eng_alloc<saber_mask_meta>(saber_engine*, saber_mask_meta**, size_t);
 
 #define TRY(x) do { int _r = (x); if (_r != SABER_OK) return _r; } while (0)
 
@@ -186,6 +189,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     {
         const char* m = gemm_init_device();
         if (!m) m = gemm_rowln_init_device();
+        if (!m) m = amg_device_init();
         if (!m) m = gemm_w1_init_device();
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();

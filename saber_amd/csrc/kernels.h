@@ -197,7 +197,18 @@ const char* decoder_tokens_init_device();
 // K8: bilinear upsample of 256x256 logits to the crop, threshold / stability counts / bbox / bit-packing.
 struct MaskStats { int area; int inter; int uni; int x0; int y0; int x1; int y1; int pad; };
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
-                             int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s);
+                             int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s, const uint8_t* pass = nullptr);   // pass: optional per-mask flags, masks with 0 are skipped
+// ------------------------------------------------------------------ amg_device.hip: filters, box NMS and compaction of the mask generator on the device
+struct DevCand { float box[4]; float iou, stab; float pt[2]; int crop[4]; int area; int slot; float score; int pad; };   // slot: index of the bit mask in the K8 scratch
+struct DevCrop { int box[4]; int kbase; int nm; int pt0; int M; };   // one crop of a decoded batch: first candidate / candidates / first grid point (batch-relative), masks per point
+struct saber_mask_meta;
+const char* amg_device_init();
+const char* launch_box_nms_probe(const float* boxes, const float* scores, int n, float thr, void* tmp /* n x 64 bytes */, int* keep, int* count, hipStream_t s);
+const char* launch_amg_plane(const float* iou, const int* sel, int n, int plane_mode, float thr, int* plane, uint8_t* pass, hipStream_t s);
+const char* launch_amg_crops(const DevCrop* crops, int n_crops, int max_nm, const MaskStats* stats, const uint8_t* pass, const float* iou, const float* crop_pts, float stab_thr,
+                             float nms_thr, int H, int W, int slot_base, DevCand* tmp, DevCand* keep, int* counts, DevCand* surv, int* nsurv, int cap, hipStream_t s);
+const char* launch_amg_final(DevCand* surv, const int* nsurv, int cap, int multi_crop, float nms_thr, int max_masks, int* final_slots, saber_mask_meta* meta, int* out_count,
+                             const uint32_t* scratch, uint32_t* out_bits, int64_t words, hipStream_t s);
 // paint label planes: plane[y][x] = max over i (in order) ... later masks overwrite earlier ones (propagation.py:185-186)
 const char* launch_gather_masks(const uint32_t* src, const int* idx, uint32_t* dst, int n, int64_t words, hipStream_t s);
 const char* launch_label_plane(const uint32_t* bits, const int* order, int n, int H, int W, uint16_t* plane, hipStream_t s);

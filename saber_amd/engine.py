@@ -256,6 +256,10 @@ class Engine:
         self._check(self.lib.saber_engine_set_precision(self.h, 1 if precision == "exact" else 0))
         self.precision = precision
 
+    def set_device_amg(self, enable: bool):
+        """Filters / NMS / compaction of the mask generator on the device (default) or on the host (include/saber_amd.h: saber_engine_set_device_amg)."""
+        self._check(self.lib.saber_engine_set_device_amg(self.h, int(bool(enable))))
+
     def set_iou_pruning(self, enable: bool):
         """IoU pruning of the AMG m2m pass (include/saber_amd.h: saber_engine_set_iou_pruning); on by default, results identical."""
         self._check(self.lib.saber_engine_set_iou_pruning(self.h, int(bool(enable))))

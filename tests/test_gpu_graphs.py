@@ -105,3 +105,53 @@ def test_iou_pruning_of_the_m2m_pass_changes_nothing_but_the_time():
             print(f"pred_iou_thresh {thr:.4f} (quantile {q}): {len(m)} masks, {pruned} of {seen} m2m candidates pruned before the upscaling")
     finally:
         eng.close(); ref.close()
+
+
+def test_device_side_filters_and_nms_equal_the_host_restatement():
+    """saber_engine_set_device_amg: IoU / stability / crop-edge filters, the per-crop box NMS, the cross-crop NMS and the compaction as
+    kernels (amg_device.hip) against the host restatement they replace (amg.hip), which is itself pinned to the oracle's AMG driver by
+    tests/test_gpu_engine.py / test_gpu_parity_bf16.py: identical masks, order and records over filter / NMS settings that exercise every
+    branch (NMS on and off, one crop and three layers of crops, single-mask and multimask, with and without the m2m pass), ONE host
+    synchronisation per call instead of three."""
+    from oracle import saber_ref
+    from saber_amd.engine import Engine, make_amg_params
+    from saber_amd.model_config import get_config
+    from saber_amd.weights import seeded_weights
+    cfg = get_config("tiny")
+    w = seeded_weights(cfg, 0)
+    dev = Engine("tiny", weights=w, max_images=21, max_prompts=256)
+    host = Engine("tiny", weights=w, max_images=21, max_prompts=256)
+    host.set_device_amg(False)
+    try:
+        img = dev.prepare(torch.from_numpy(saber_ref.synthetic_slice(seed=6, size=512)).cuda())
+        _, meta = host.amg_generate(img, make_amg_params(dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.0, stability_score_thresh=0.0, box_nms_thresh=1.0, crop_nms_thresh=1.0)), max_masks=8192)
+        ious = np.sort(np.array([m.predicted_iou for m in meta]))
+        stabs = np.sort(np.array([m.stability_score for m in meta]))
+        q = lambda a, f: float(a[int(f * (len(a) - 1))])
+        # (the seeded model's masks are image-sized blobs: box NMS at the usual 0.7 leaves one mask, so the thresholds that exercise partial
+        # suppression sit close to 1)
+        cases = [dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.0, stability_score_thresh=0.0, box_nms_thresh=1.0, crop_nms_thresh=1.0),
+                 dict(npoints=8, crop_n_layers=1, pred_iou_thresh=q(ious, 0.3), stability_score_thresh=q(stabs, 0.3), box_nms_thresh=0.7, crop_nms_thresh=0.7),
+                 dict(npoints=8, crop_n_layers=1, pred_iou_thresh=q(ious, 0.2), stability_score_thresh=0.0, box_nms_thresh=0.97, crop_nms_thresh=0.9),
+                 dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.0, stability_score_thresh=q(stabs, 0.2), box_nms_thresh=0.99, crop_nms_thresh=0.98),
+                 dict(npoints=8, crop_n_layers=2, pred_iou_thresh=q(ious, 0.5), stability_score_thresh=0.0, box_nms_thresh=0.995, crop_nms_thresh=0.95),
+                 dict(npoints=16, crop_n_layers=0, pred_iou_thresh=q(ious, 0.2), stability_score_thresh=q(stabs, 0.5), box_nms_thresh=0.98, crop_nms_thresh=0.7),
+                 dict(npoints=8, crop_n_layers=1, pred_iou_thresh=q(ious, 0.4), stability_score_thresh=0.0, box_nms_thresh=0.99, crop_nms_thresh=0.97, multimask_output=False),
+                 dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.0, stability_score_thresh=q(stabs, 0.6), box_nms_thresh=0.985, crop_nms_thresh=0.99, use_m2m=False),
+                 dict(npoints=8, crop_n_layers=1, pred_iou_thresh=0.999, stability_score_thresh=0.0, box_nms_thresh=0.7, crop_nms_thresh=0.7)]      # nothing survives
+        for ci, c in enumerate(cases):
+            params = make_amg_params(c)
+            for rep in range(2):                                     # eager and captured / replayed decode sequences
+                b, m = _run(dev, img, params)
+                sd = dev.lib.saber_amg_last_syncs(dev.h)
+                b0, m0 = _run(host, img, params)
+                sh = host.lib.saber_amg_last_syncs(host.h)
+                assert m == m0, f"case {ci}: records differ ({len(m)} vs {len(m0)})"
+                assert np.array_equal(b[:len(m)], b0[:len(m0)]), f"case {ci}: masks differ"
+            print(f"AMG case {ci}: {len(m)} masks, host synchronisations {sd} (device path) vs {sh} (host path)")
+            assert sd == 1 and sh >= 2
+        # too small a capacity: the call reports the count it needs and Engine.amg_generate retries with it, as on the host path
+        bits, meta2 = dev.amg_generate(img, make_amg_params(cases[0]), max_masks=4)      # 4 < count: Engine retries with the reported capacity
+        assert len(meta2) == len(meta)
+    finally:
+        dev.close(); host.close()
