@@ -415,11 +415,23 @@ def main():
             g8 = prof["gemm_mxfp8"]
             ach8 = g8["flops"] / (g8["ms"] * 1e-3) / 1e12 if g8["ms"] > 0 else 0.0
             out["roofline_bf16_gemms"] = out["roofline"]
-            out["roofline"] = {"bound": "mfma", "achieved": ach8, "peak": 5000.0, "unit": "TFLOP/s", "frac": ach8 / 5000.0, "traffic": None,
+            tr8, busy8, src8 = None, None, None
+            try:       # HBM counters of the MXFP8 GEMM launches: separate FETCH_SIZE / WRITE_SIZE / MFMA-busy passes of `bench.py --dtype mxfp8` (tools/summarize_pmc.py)
+                import glob
+                f8 = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mxfp8_pmc.json")))[-1]
+                k8 = {n: v for n, v in json.load(open(f8))["kernels"].items() if "gemm_mx" in n}
+                tr8 = sum(v["hbm_bytes_total"] for v in k8.values()) / max(1, sum(v["launches"] for v in k8.values()))
+                bz, av = sum(v.get("mfma_busy_cycles_total", 0.0) for v in k8.values()), sum(v.get("simd_cycles_total", 0.0) for v in k8.values())
+                busy8, src8 = (bz / av if av > 0 else None), os.path.basename(f8)
+            except Exception:
+                pass
+            out["roofline"] = {"bound": "mfma", "achieved": ach8, "peak": 5000.0, "unit": "TFLOP/s", "frac": ach8 / 5000.0, "traffic": tr8, "traffic_source": src8,
+                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)", "algorithmic_bytes_per_launch": g8["bytes"] / max(1, g8["launches"]),
+                               "traffic_over_algorithmic": (tr8 / (g8["bytes"] / max(1, g8["launches"]))) if tr8 and g8["bytes"] else None, "mfma_busy_frac": busy8,
                                "kernel": "gemm_mx_kernel (csrc/gemm_fp8.hip: v_mfma_scale_f32_16x16x128_f8f6f4, persistent 256x192 tiles)", "launches_per_slice": g8["launches"],
                                "avg_launch_us": g8["ms"] * 1e3 / max(1, g8["launches"]), "algorithmic_gflop_per_launch": g8["flops"] / max(1, g8["launches"]) / 1e9,
                                "kernel_ms_per_slice": g8["ms"], "share_of_kernel_time": g8["ms"] / total_ms if total_ms else None,
-                               "note": "dense fp8 peak 5 PFLOP/s; HBM traffic counters are collected for the headline (bf16) configuration only"}
+                               "note": "dense fp8 peak 5 PFLOP/s"}
         out["kernel_classes_ms_per_slice"] = {k: round(v["ms"], 3) for k, v in prof.items()}
         out["kernel_classes_launches"] = {k: v["launches"] for k, v in prof.items()}
         mp = prof["mask_post"]
