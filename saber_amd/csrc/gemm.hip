@@ -39,8 +39,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const bool vec_ok = (p.N & 3) == 0;
     auto apply_act = [&](float (&v)[4]) {
         if (p.act == ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            { const f32x2 g0_ = gelu_erf2((f32x2){v[0], v[1]}), g1_ = gelu_erf2((f32x2){v[2], v[3]}); v[0] = g0_.x; v[1] = g0_.y; v[2] = g1_.x; v[3] = g1_.y; }
         } else if (p.act == ACT_RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -373,8 +372,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                         v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
                         if (p.act == ACT_GELU) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                            { const f32x2 g0_ = gelu_erf2((f32x2){v[0], v[1]}), g1_ = gelu_erf2((f32x2){v[2], v[3]}); v[0] = g0_.x; v[1] = g0_.y; v[2] = g1_.x; v[3] = g1_.y; }
                         } else if (p.act == ACT_RELU) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -542,8 +540,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < 4; ++j) {
                 float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
                 if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    { const f32x2 g0_ = gelu_erf2((f32x2){v[0], v[1]}), g1_ = gelu_erf2((f32x2){v[2], v[3]}); v[0] = g0_.x; v[1] = g0_.y; v[2] = g1_.x; v[3] = g1_.y; }
                 } else if (p.act == ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -799,9 +796,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
-                if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                if (p.act == ACT_GELU) {                       // packed form: the same arithmetic as gelu_erf, two values per VALU issue slot
+                    const f32x2 g0 = gelu_erf2((f32x2){v[0], v[1]}), g1 = gelu_erf2((f32x2){v[2], v[3]});
+                    v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                 }                                              // (only ACT_NONE / ACT_GELU are routed to this kernel)
                 const int chunk = j * 2 + (fg >> 1);
                 // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS loads in
@@ -1070,7 +1067,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256x_kernel(GemmParams p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-                        if (p.act == ACT_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                        if (p.act == ACT_GELU) { const f32x2 g0_ = gelu_erf2((f32x2){v0, v1}), g1_ = gelu_erf2((f32x2){v2, v3}); v0 = g0_.x; v1 = g0_.y; v2 = g1_.x; v3 = g1_.y; }
                         const uint64_t pk = ((uint64_t)pack_bf16(v2, v3) << 32) | pack_bf16(v0, v1);
                         const int chunk = 4 * j + g;              // 16-byte chunk of the 128-byte row; its 8-byte half is h
                         asm volatile("ds_write_b64 %0, %1" ::"v"(tb + r32 * 128 + ((chunk ^ (r32 & 7)) << 4) + h * 8), "v"(pk) : "memory");

@@ -75,7 +75,7 @@ __device__ __forceinline__ void mx_epilogue(const GemmMxParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 float v0 = acc[j][i][0] + bias4[j].x, v1 = acc[j][i][1] + bias4[j].y, v2 = acc[j][i][2] + bias4[j].z, v3 = acc[j][i][3] + bias4[j].w;
-                if (p.act == ACT_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                if (p.act == ACT_GELU) { const f32x2 g0_ = gelu_erf2((f32x2){v0, v1}), g1_ = gelu_erf2((f32x2){v2, v3}); v0 = g0_.x; v1 = g0_.y; v2 = g1_.x; v3 = g1_.y; }
                 const uint64_t pk = ((uint64_t)pack_bf16(v2, v3) << 32) | pack_bf16(v0, v1);
                 MX_DSW64(scr + fi * PITCH + (16 * j + 4 * fg) * 2, pk);
             }
