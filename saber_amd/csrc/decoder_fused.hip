@@ -871,7 +871,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
                                                           const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
                                                           const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups,
-                                                          const uint8_t* __restrict__ live) {
+                                                          const uint8_t* __restrict__ live, const float* __restrict__ iou4, int multimask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
     char* w2s = w1s + UP_W1S;
@@ -953,6 +953,21 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         {
             const int slot = (p + s_off) / s_div;     // block-uniform
             if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
+        }
+        // Planes anybody reads afterwards (iou4 given): a multimask decode returns masks 1-3; a single-mask decode returns mask 0 or, when
+        // that one is unstable, the best of 1-3 by predicted IoU (first maximum: mask_pick_kernel / mask_select_dynamic_kernel) - the other
+        // hypernetwork products and their 256-KB planes are skipped.  Block-uniform.
+        int need = 0xF;
+        if (iou4) {
+            if (multimask) need = 0xE;
+            else {
+                int best = 1;
+                float bv = iou4[p * 4 + 1];
+                if (iou4[p * 4 + 2] > bv) { bv = iou4[p * 4 + 2]; best = 2; }
+                if (iou4[p * 4 + 3] > bv) best = 3;
+                need = 1 | (1 << best);
+            }
+            need = __builtin_amdgcn_readfirstlane(need);
         }
 #if UP_MFMA_HYPER
         // The hypernetwork product masks[k] = hyper[k] . u2 on the matrix cores (instead of 128 FMAs + a 3-step lane transpose per lane and
@@ -1058,7 +1073,8 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                     const f32x2 ub = gelu_erf2((f32x2){c2[nl][2], c2[nl][3]});
                     const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
+                    for (int k = 0; k < 4; ++k)
+                        if ((need >> k) & 1) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
                 }
                 // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
                 // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
@@ -1070,18 +1086,18 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 if (pp == 0) px2.x = mine; else px2.y = mine;
 #endif
             }
-            *reinterpret_cast<float2*>(orow + hb * 256) = px2;
+            if ((need >> fg) & 1) *reinterpret_cast<float2*>(orow + hb * 256) = px2;
         }
     }
 }
 
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap sm, const float* hyper, float* masks4, int P,
-                               hipStream_t s, const uint8_t* live) {
+                               hipStream_t s, const uint8_t* live, const float* iou4, int multimask) {
     if (P <= 0) return nullptr;
     if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
     const int groups = P >= 2 ? 2 : 1;   // 128 tiles x 2 groups = one resident block per CU
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups, live);
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups, live, iou4, multimask);
     return nullptr;
 }
 

@@ -1332,7 +1332,8 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     // upscaling head fused with the hypernetwork product (dec_upscale_kernel)
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
            launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot0 * 16384 * 64,
-                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, raw4_out ? raw4_out : e->masks4, P, s, live));
+                              e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, raw4_out ? raw4_out : e->masks4, P, s, live,
+                              getenv("SABER_AMD_ALL_PLANES") ? nullptr : e->iou4, multimask));      // (development A/B: all four planes)
     float* oi = out_iou ? out_iou : e->dec_out_iou;
     if (raw4_out) {
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s, live));
