@@ -152,7 +152,6 @@ def test_mxfp8_engine_vs_oracle_quantising_at_the_same_points(large_weights):
     emul = E.encode_image_emul(Wq, cfg, pix, mx=True)
     with torch.no_grad():
         f0 = sam2_ref.encode_image(W0, cfg, pix)
-        fq = sam2_ref.encode_image(Wq, cfg, pix)
     eng = Engine("large", weights=W, max_images=1, max_prompts=8, weight_format="mxfp8")
     eng16 = Engine("large", weights=W, max_images=1, max_prompts=8)
     try:
@@ -163,9 +162,9 @@ def test_mxfp8_engine_vs_oracle_quantising_at_the_same_points(large_weights):
     finally:
         eng.close(); eng16.close()
     for k in ("image_embed", "feat_s1", "feat_s0"):
-        e_emul, e_fp32, b_fp32, w_fp32, bf_fp32 = rel_rms(g8[k], emul[k][0]), rel_rms(g8[k], f0[k][0]), rel_rms(emul[k][0], f0[k][0]), rel_rms(fq[k][0], f0[k][0]), rel_rms(g16[k], f0[k][0])
+        e_emul, e_fp32, b_fp32, bf_fp32 = rel_rms(g8[k], emul[k][0]), rel_rms(g8[k], f0[k][0]), rel_rms(emul[k][0], f0[k][0]), rel_rms(g16[k], f0[k][0])
         print(f"{k}: mxfp8 engine vs MX emulation {e_emul:.3e} (emulation's realisation spread {MX_SPREAD[k]:.1e}); vs fp32 oracle: mxfp8 engine {e_fp32:.3e}, "
-              f"MX emulation {b_fp32:.3e}, MX weights alone (fp32 arithmetic) {w_fp32:.3e}, bf16 engine {bf_fp32:.3e}")
+              f"MX emulation {b_fp32:.3e}, bf16 engine {bf_fp32:.3e}  (the MX WEIGHTS alone, in fp32 arithmetic, cost 4.8e-2 on image_embed: tools/mx_spread.py)")
         if k == "image_embed":                                        # (the two high-resolution features leave the trunk before stage 2: equality with the bf16 engine below)
             assert e_emul < 2 * MX_SPREAD[k]
         assert e_fp32 < 1.15 * b_fp32 + 1e-4                          # no further from fp32 than the emulation is

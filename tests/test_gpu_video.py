@@ -307,7 +307,7 @@ def test_box_and_several_clicks_against_oracle():
         rng = np.random.default_rng(5)
         tomo = rng.uniform(-1, 1, (5, 128, 128)).astype(np.float32)
         P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
-        for case in ("box", "box+click", "two calls"):
+        for case in ("box+click", "two calls"):          # (a box alone: tests/test_gpu_exact.py at the decoder level)
             P.init_state(V.load_tomogram_frames(tomo), video_hw=(1024, 1024))
             vp.init_state(load_tomogram_frames(tomo), video_hw=(1024, 1024))
             for pred in (P, vp):
