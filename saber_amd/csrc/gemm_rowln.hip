@@ -34,6 +34,8 @@ typedef __attribute__((address_space(3))) void* lptr_r;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define RL_BK 32
+#define RL_PITCH 304                 // bytes per row of the bf16 transposition scratch (288 + 16)
+#define RL_SCR (16 * RL_PITCH)       // per wave
 // pieces of the K-step two ahead issued at the top of a K-step | behind its first MFMA group | behind the second (measured on the
 // stage-2 shapes against all of them at the top: fc2 401 -> 376 us, proj 219 -> 211 us)
 #define RL_SPLIT 1
@@ -47,7 +49,10 @@ template <int WM, int WN> struct RowLnCfg {
     static constexpr int RA = R / 16, RW = N / 16, PT = RA + RW;          // 1-KB pieces (16 rows x 64 B) of one K-step
     static constexpr int STAGE = (R + N) * 64;
     static constexpr int STAT = R * WN * 4;                                // one statistics buffer
-    static constexpr int LDS = 3 * STAGE + 2 * STAT;
+    // transposition scratch of the bf16 rows (RL_SCR per wave): ring stage 2 when an eighth of it is enough, else behind the statistics
+    static constexpr bool SCR_IN_RING = STAGE / 8 >= RL_SCR;
+    static constexpr int SCR_OFF = SCR_IN_RING ? 2 * STAGE : 3 * STAGE + 2 * STAT;
+    static constexpr int LDS = 3 * STAGE + 2 * STAT + (SCR_IN_RING ? 0 : 8 * RL_SCR);
     static constexpr int NQ = (PT + 7) / 8;                                // pieces per wave (upper bound)
 };
 
@@ -280,18 +285,42 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) rstd[i] = __builtin_amdgcn_rsqf(rs[i] * (1.0f / CF::N) + p.ln_eps);
         const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ln_out + (int64_t)m0 * p.ldln), 0, (int)((uint32_t)rows * (uint32_t)p.ldln * 2u), 0x00020000);
-        const uint32_t loff = (uint32_t)((trow * (int)p.ldln + ncol) * 2), lstep = (uint32_t)(16 * (int)p.ldln * 2);
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const float4 g4 = *reinterpret_cast<const float4*>(p.ln_gamma + ncol + j * 16);
             const float4 be4 = *reinterpret_cast<const float4*>(p.ln_beta + ncol + j * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v0 = fmaf(acc[i][j][0] * rstd[i], g4.x, be4.x), v1 = fmaf(acc[i][j][1] * rstd[i], g4.y, be4.y);
-                const float v2 = fmaf(acc[i][j][2] * rstd[i], g4.z, be4.z), v3 = fmaf(acc[i][j][3] * rstd[i], g4.w, be4.w);
-                u32x2 v;
-                v[0] = pack_bf16(v0, v1); v[1] = pack_bf16(v2, v3);
-                if (!dbg_nobf) __builtin_amdgcn_raw_buffer_store_b64(v, lrsrc, loff + j * 32, i * lstep, 0);
+                acc[i][j][0] = fmaf(acc[i][j][0] * rstd[i], g4.x, be4.x); acc[i][j][1] = fmaf(acc[i][j][1] * rstd[i], g4.y, be4.y);
+                acc[i][j][2] = fmaf(acc[i][j][2] * rstd[i], g4.z, be4.z); acc[i][j][3] = fmaf(acc[i][j][3] * rstd[i], g4.w, be4.w);
+            }
+        }
+        // bf16 rows leave through LDS: in the accumulator layout a store instruction covers 16 rows x 32 B (the same bytes cost twice
+        // what the fp32 rows cost: tools/rowln_bench.py, DBG=4096 against DBG=2048); transposed, a lane stores 16 B of a 288-B row
+        // segment, 3 rows per instruction.  The scratch is wave-private (16 rows x 304 B: the pitch spreads the 16 rows of a
+        // ds_write_b64 over the banks), in ring stage 2 - the next tile's K-steps 0 and 1 are landing in stages 0 and 1, K-step 2 is
+        // issued behind the barrier at the top of the next tile - or, where an eighth of a stage is too small, behind the statistics.
+        const uint32_t scr = (uint32_t)(uintptr_t)(lptr_r)(smem + CF::SCR_OFF) + (uint32_t)(wave * RL_SCR);
+        const uint32_t scr_w = scr + (uint32_t)(efi * RL_PITCH + efg * 8);
+        const int lrow = lane_e / 18, lch = lane_e - 18 * lrow;                  // lanes 0..53: 3 rows x 18 chunks of 16 B
+        const uint32_t scr_r = scr + (uint32_t)(lrow * RL_PITCH + lch * 16);
+        const uint32_t loff = (uint32_t)(((wm * 64 + lrow) * (int)p.ldln + wn * 144) * 2 + lch * 16);
+        const uint32_t lrowb = (uint32_t)((int)p.ldln * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const uint64_t pk = ((uint64_t)pack_bf16(acc[i][j][2], acc[i][j][3]) << 32) | pack_bf16(acc[i][j][0], acc[i][j][1]);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(scr_w + j * 32), "v"(pk) : "memory");
+            }
+            u32x4 val[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) asm volatile("ds_read_b128 %0, %1" : "=v"(val[r]) : "v"(scr_r + r * 3 * RL_PITCH) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]));
+            if (!dbg_nobf && lane_e < 54) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) __builtin_amdgcn_raw_buffer_store_b128(val[r], lrsrc, loff, (i * 16 + r * 3) * lrowb, 0);
+                if (lane_e < 18) __builtin_amdgcn_raw_buffer_store_b128(val[5], lrsrc, loff, (i * 16 + 15) * lrowb, 0);
             }
         }
     }
