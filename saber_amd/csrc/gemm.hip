@@ -713,6 +713,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     };
     Li = next_tile(blockIdx.x, &tmi, &tni);
     if (Li >= padded) return;                      // block-uniform
+    if (p.dbg >> 21) {      // development (tools/gemm_bench.py DBGS; GEMM micro-benchmarks only: the decoder reads these bits too): late start of some workgroups, as in gemm_rowln_kernel
+        const int units = (p.dbg >> 21) & 127, mode = (p.dbg >> 28) & 3;
+        int cnt = 0, a_, b_;
+        for (int L = blockIdx.x; L < padded; L += gridDim.x) cnt += tile_map(L, tiles_m, tiles_n, &a_, &b_) ? 1 : 0;
+        const int cmax = (tiles_m * tiles_n + (int)gridDim.x - 1) / (int)gridDim.x;
+        const bool late = mode == 0 ? cnt < cmax : mode == 1 ? ((blockIdx.x >> 3) & 1) : (cnt < cmax || ((blockIdx.x >> 3) & 1));
+        if (late) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)units * 4096ull) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     set_issue_tile();
     int Lc = Li, tmc = tmi, tnc = tni, ktc = 0, sc = 0;
 

@@ -112,6 +112,20 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
     int tl = blockIdx.x;                                   // position in this workgroup's walk; t = the tile (reversed walk: p.rev)
     if (tl >= tiles) return;
     auto tile_of = [&](int l) { return p.rev ? tiles - 1 - l : l; };
+    // Workgroups whose walk is one tile shorter than the longest (tiles is rarely a multiple of the grid: 2.6 / 5.25 / 10.5 tiles per
+    // workgroup on the 21-crop pass) start ~0.4 tile times late.  Every workgroup spends a tile time the same way - K loop (no HBM
+    // traffic to speak of), then an epilogue that moves 737 KB - and all start together, so the epilogues of all 256 CUs meet in HBM
+    // (5.7 TB/s while they last, nothing in between).  The late ones have a whole tile time of slack; their epilogues now fall into the
+    // others' K loops and the others' into theirs: proj 183 -> 177 us, fc2 341 -> 316 us, stage 2 311 -> 297 / 468 -> 444 us,
+    // stage 1 556 -> 535 / 807 -> 776 us (tools/rowln_bench.py; delaying workgroups WITH a full walk loses, as it must).
+    {
+        const int my_tiles = (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1, max_tiles = (tiles - 1) / (int)gridDim.x + 1;
+        if (my_tiles < max_tiles && !(p.dbg & 32768)) {
+            const unsigned long long late = 1080ull * (unsigned)nk + 40000ull;          // shader cycles: 0.4 x (2 700 per K-step + ~100 000 of epilogue)
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < late) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     issue(wrsrc, tile_of(tl), 0);
     if (nk > 1) issue(wrsrc, tile_of(tl), 1);
     for (; tl < tiles; tl += gridDim.x) {

@@ -11,17 +11,23 @@ if os.environ.get('DBG'): lib.saber_k_set_debug(int(os.environ['DBG'], 0))
 M0 = int(os.environ.get("M0", "8"))
 shapes = [(4096 * M0, 1728, 576), (4096 * M0, 576, 576), (4096 * M0, 2304, 576), (4096 * M0, 576, 2304), (16384 * M0, 864, 288), (16384 * M0, 1152, 288), (16384 * M0, 288, 1152),
           (65536 * M0, 432, 144), (65536 * M0, 576, 144), (65536 * M0, 144, 576), (1024 * M0, 3456, 1152), (1024 * M0, 4608, 1152), (1024 * M0, 1152, 4608), (8192, 256, 256), (4096, 4096, 4096), (8192, 8192, 8192)]
+dbgs = [int(v, 0) for v in os.environ['DBGS'].split(',')] if os.environ.get('DBGS') else [None]     # sweep of development flags in one process
+if os.environ.get('SHAPES'): shapes = [shapes[int(i)] for i in os.environ['SHAPES'].split(',')]
 for M, N, K in shapes:
     Kp = (K + 63) // 64 * 64   # weights as the engine uploads them: rows zero-padded to a multiple of 64
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); W = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
     W[:, :K] = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     outf = torch.empty(M, N, device="cuda") if RES else None; res = torch.randn(M, N, device="cuda") if RES else None
-    for _ in range(3): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, None)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"M={M:7d} N={N:5d} K={K:5d}  {ms*1e3:9.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s", flush=True)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def run(): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, st)
+    for d in dbgs:
+        if d is not None: lib.saber_k_set_debug(d)
+        for _ in range(3): run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f"M={M:7d} N={N:5d} K={K:5d}  {'' if d is None else f'DBG={d:#x}  '}{ms*1e3:9.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s", flush=True)

@@ -17,6 +17,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+dbgs = [int(v, 0) for v in os.environ['DBGS'].split(',')] if os.environ.get('DBGS') else [None]
 for M, N, K in shapes:
     Kp = (K + 63) // 64 * 64
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); W = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
@@ -24,6 +25,13 @@ for M, N, K in shapes:
     bias, g, b = torch.randn(N, device="cuda"), torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
     x = torch.randn(M, N, device="cuda"); xn = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if dbgs != [None]:          # sweep of development flags in one process (DBGS=a,b,c): fused kernel only
+        for d in dbgs:
+            lib.saber_k_set_debug(d)
+            t = timeit(lambda: lib.saber_k_gemm_rowln(ptr(A), K, ptr(W), Kp, ptr(bias), ptr(x), ptr(x), None, ptr(g), ptr(b), 1e-6, ptr(xn), M, N, K, s))
+            print(f"M={M:8d} N={N:4d} K={K:5d}  DBG={d:#x}  fused {t:8.1f} us", flush=True)
+        lib.saber_k_set_debug(0)
+        continue
     t_f = timeit(lambda: lib.saber_k_gemm_rowln(ptr(A), K, ptr(W), Kp, ptr(bias), ptr(x), ptr(x), None, ptr(g), ptr(b), 1e-6, ptr(xn), M, N, K, s))
     t_g = timeit(lambda: lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(x), ptr(x), None, M, N, K, 0, s))
     t_l = timeit(lambda: lib.saber_k_layernorm(ptr(x), ptr(g), ptr(b), 1e-6, None, ptr(xn), M, N, 0, s))
