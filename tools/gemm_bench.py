@@ -13,6 +13,7 @@ shapes = [(4096 * M0, 1728, 576), (4096 * M0, 576, 576), (4096 * M0, 2304, 576),
           (65536 * M0, 432, 144), (65536 * M0, 576, 144), (65536 * M0, 144, 576), (1024 * M0, 3456, 1152), (1024 * M0, 4608, 1152), (1024 * M0, 1152, 4608), (8192, 256, 256), (4096, 4096, 4096), (8192, 8192, 8192)]
 dbgs = [int(v, 0) for v in os.environ['DBGS'].split(',')] if os.environ.get('DBGS') else [None]     # sweep of development flags in one process
 if os.environ.get('SHAPES'): shapes = [shapes[int(i)] for i in os.environ['SHAPES'].split(',')]
+if os.environ.get('SHAPE_LIST'): shapes = [tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPE_LIST'].split(';')]     # "M,N,K;M,N,K"
 for M, N, K in shapes:
     Kp = (K + 63) // 64 * 64   # weights as the engine uploads them: rows zero-padded to a multiple of 64
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); W = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
