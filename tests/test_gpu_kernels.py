@@ -430,7 +430,8 @@ def test_hand_synchronised_kernels_are_run_to_run_identical(gpu_lib):
 
 
 @pytest.mark.parametrize("M,N,K,with_res,with_bf", [(4096, 576, 576, True, False), (4096 + 70, 576, 2304, True, True), (16384, 288, 1152, True, False),
-                                                    (2048 + 300, 288, 288, False, True), (65536, 144, 144, True, False), (4096 + 33, 144, 576, True, True)])
+                                                    (2048 + 300, 288, 288, False, True), (65536, 144, 144, True, False), (4096 + 33, 144, 576, True, True),
+                                                    (128 * 356 + 17, 576, 576, True, False)])      # 357 tiles on 256 workgroups: uneven walks, the short ones start late
 def test_gemm_rowln(gpu_lib, M, N, K, with_res, with_bf):
     """residual GEMM + the LayerNorm that follows it in one kernel (gemm_rowln.hip): y against fp64 on the same bf16 operands,
     the normalised bf16 rows against LayerNorm of the kernel's own y (<= 1 bf16 ulp, almost all exact) and of the fp64 y"""
@@ -465,3 +466,27 @@ def test_gemm_rowln(gpu_lib, M, N, K, with_res, with_bf):
     assert (d > 0).float().mean().item() < 2e-3         # rounding flips only
     ln_ref = torch.nn.functional.layer_norm(ref, (N,), gamma.double(), beta.double(), 1e-6)
     assert (got.double() - ln_ref).abs().max().item() < 0.05
+
+
+def test_gemm_rowln_late_start_changes_nothing(gpu_lib):
+    """gemm_rowln_kernel starts the workgroups with the shorter tile walk late (timing only): same bits with the late start switched off
+    (saber_k_set_debug(32768)), on a problem whose tile count (357) is not a multiple of the grid (256)"""
+    M, N, K = 128 * 356 + 17, 576, 2304
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16).view(torch.uint16).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).view(torch.uint16).cuda()
+    bias, gamma, beta = torch.randn(N, generator=g).cuda(), (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    res = (torch.randn(M, N, generator=g) * 2).cuda()
+    outs = []
+    for flag in (0, 32768, 0):
+        gpu_lib.saber_k_set_debug(flag)
+        try:
+            y = res.clone()
+            ln = torch.zeros(M, N, dtype=torch.uint16, device="cuda")
+            kcall(gpu_lib, gpu_lib.saber_k_gemm_rowln(ptr(A), K, ptr(W), K, ptr(bias), ptr(y), ptr(y), None, ptr(gamma), ptr(beta), 1e-6, ptr(ln), M, N, K, None))
+            torch.cuda.synchronize()
+        finally:
+            gpu_lib.saber_k_set_debug(0)
+        outs.append((y, ln))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
