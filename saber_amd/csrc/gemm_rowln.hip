@@ -26,6 +26,7 @@
 //   * epilogue: bias into the accumulators, residual rows added, fp32 rows stored, two-pass LayerNorm statistics (row sums
 //     reduced over the lanes of a row with permlane swaps, over the WN waves of a row through 2 x 2 KB of LDS), normalised
 //     rows stored as bf16.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -41,6 +42,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define RL_SPLIT 1
 #define RL_Q1 1
 #define RL_Q2 3
+#ifndef RL_ANTIPHASE
+#define RL_ANTIPHASE 1               // the two waves of a SIMD issue their transfers at different points of the K-step (0: the lockstep loop of round 2)
+#endif
 __device__ __forceinline__ int rl_perm(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0, 2, 3, 1}: gemm.hip g2perm
 __device__ __forceinline__ int rl_swz(int row, int chunk) { return row * 64 + ((chunk ^ rl_perm(row)) << 4); }
 
@@ -139,6 +143,48 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         // K-steps 0 (and 1) of this tile were issued before the previous tile's epilogue: everything has landed after vmcnt(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#if RL_ANTIPHASE
+        // The two waves of a SIMD (w and w + 4) take their transfer issues at different points of the K-step: waves 0-3 issue ahead of
+        // each MFMA group, waves 4-7 behind the first and second.  An LDS-DMA issue holds its wave for as long as the L2 -> LDS path is
+        // backed up (60-185 cycles); in lockstep both waves of the SIMD sat in their issues at the same time and the matrix core idled.
+        // Same-box A/B against the lockstep loop (tools/rowln_bench.py, two builds interleaved): fc2 of stage 2 358 -> 340 us, of stage 1
+        // 453 -> 439, stage 0 531 -> 484 / 764 -> 719 us; the K = 576 / K = 288 proj shapes level.  (Waves 0-3 issuing 3 + 3 pieces ahead
+        // of the first two groups instead of 2 + 2 + 2: no difference.)
+        // Two straight-line K loops (one per half) with the same barrier sequence: a branch inside one loop makes hipcc spill.
+        auto kstep = [&](auto ph_tag, int kt) {
+            constexpr bool PH = decltype(ph_tag)::value;
+            const bool more = kt + 2 < nk;
+            const char* sa = smem + (kt % 3) * STAGE;
+            const char* sw = sa + RA * 1024;
+            if (!PH && more) issue(wrsrc, t, kt + 2, 0, 2);
+            bf16x8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
+#pragma unroll
+            for (int jg = 0; jg < 3; ++jg) {
+                bf16x8 wf[3];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const bf16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj)
+                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (!PH) { if (jg == 0) issue(wrsrc, t, kt + 2, 2, 4); else if (jg == 1) issue(wrsrc, t, kt + 2, 4, NQ); }
+                    else { if (jg == 0) issue(wrsrc, t, kt + 2, 0, 3); else if (jg == 1) issue(wrsrc, t, kt + 2, 3, NQ); }
+                }
+            }
+            if (more) { if (NQ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        if (wave < 4) { for (int kt = 0; kt < nk; ++kt) kstep(std::false_type{}, kt); }
+        else { for (int kt = 0; kt < nk; ++kt) kstep(std::true_type{}, kt); }
+#else
         for (int kt = 0; kt < nk; ++kt) {
 #if RL_SPLIT
             if (kt + 2 < nk) issue(wrsrc, t, kt + 2, 0, RL_Q1);
@@ -172,6 +218,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+#endif
         // ---------------- epilogue: lane owns rows m0 + wm*64 + i*16 + fi, columns wn*144 + j*16 + fg*4 .. +3
         // (opaque lane copy: keeps the epilogue's address arithmetic from being hoisted above the main loop, where every live register
         // costs a spill).  Residual, fp32 rows and bf16 rows go through buffer descriptors over this tile's rows: one 32-bit offset per
