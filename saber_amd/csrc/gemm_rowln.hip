@@ -125,7 +125,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
     {
         const int my_tiles = (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1, max_tiles = (tiles - 1) / (int)gridDim.x + 1;
         if (my_tiles < max_tiles && !(p.dbg & 32768)) {
-            const unsigned long long late = 1080ull * (unsigned)nk + 40000ull;          // shader cycles: 0.4 x (2 700 per K-step + ~100 000 of epilogue)
+            unsigned long long late = 1080ull * (unsigned)nk + 40000ull;                // shader cycles: 0.4 x (2 700 per K-step + ~100 000 of epilogue)
+            if ((p.dbg >> 21) & 127) late = (unsigned long long)((p.dbg >> 21) & 127) * 4096ull;      // development: tools/rowln_bench.py DBGS sweep (micro-benchmark only: the decoder reads these bits too)
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while (__builtin_amdgcn_s_memtime() - t0 < late) __builtin_amdgcn_s_sleep(32);
         }
