@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--max-prompts", type=int, default=1024, help="prompts decoded per batched pass")
     ap.add_argument("--workers", type=int, default=2, help="engine handles per GPU, each on its own thread and HIP stream, slices dealt round-robin "
                     "(the reference's GPUPool runs one thread per GPU; kernels of two slices in flight fill each other's idle issue slots)")
-    ap.add_argument("--dtype", choices=("bf16", "fp8", "mxfp8"), default="bf16", help="fp8: e4m3 weights (per-row power-of-two scales) for the stage-2/3 block GEMMs, "
-                    "bf16 activations and MFMA operands, fp32 accumulate (BASELINE configs[4]); a SEPARATE line, never the headline")
+    ap.add_argument("--dtype", choices=("bf16", "fp16", "fp8", "mxfp8"), default="bf16", help="fp16: the same kernels compiled for IEEE half operands (10 mantissa bits = the TF32 "
+                    "arithmetic the reference enables, 1e-3 from the fp32 oracle); fp8: e4m3 weights (per-row power-of-two scales) for the stage-2/3 block GEMMs, "
+                    "bf16 activations and MFMA operands, fp32 accumulate (BASELINE configs[4]); SEPARATE lines, never the headline (BASELINE configs[1] says bf16)")
+    ap.add_argument("--no-alt-dtypes", action="store_true", help="skip the extra keys `alt_dtypes` (the fp16 and mxfp8 lines measured after the headline on fresh handles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-encoder-only", action="store_true", help="skip the extra encoder-only timing (profiling runs: keeps the kernel population of the trace = whole slices)")
@@ -172,10 +174,10 @@ def tail_mode(eng, pool, a, segment_slice_to_plane, make_amg_params):
                                  "what": "saber_engine_set_iou_pruning(1), the engine's default: candidates that cannot pass pred_iou_thresh skip the mask upscaling; same masks"}}
 
 
-def precision_check(weights, img):
-    """One encode + 64 grid prompts (+ their m2m refinement) on a handle that carries both precisions: relative RMS difference of the bf16
-    production arithmetic from the exact fp32 mode (saber_engine_set_precision; tests/test_gpu_exact.py pins that mode to the fp32 CPU
-    oracle at ~1e-6), and the time the exact mode takes."""
+def precision_check(weights, img, operands="bf16"):
+    """One encode + 64 grid prompts (+ their m2m refinement) on a handle that carries both precisions: relative RMS difference of the 16-bit
+    production arithmetic (`operands`: bf16 or fp16) from the exact fp32 mode (saber_engine_set_precision; tests/test_gpu_exact.py pins that
+    mode to the fp32 CPU oracle at ~1e-6), and the time the exact mode takes."""
     import numpy as np
     import torch
     from saber_amd.engine import Engine
@@ -183,12 +185,12 @@ def precision_check(weights, img):
     def rel(a, b):
         a, b = a.double().flatten(), b.double().flatten()
         return float(((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item())
-    e = Engine("large", device=0, weights=weights, max_images=1, max_prompts=64, precision="exact")
+    e = Engine("large", device=0, weights=weights, max_images=1, max_prompts=64, precision="exact", operands=operands)
     try:
         g = np.linspace(1 / 16, 1 - 1 / 16, 8, dtype=np.float32) * 1024
         pts = torch.from_numpy(np.stack(np.meshgrid(g, g), -1).reshape(-1, 2).copy()).cuda()
         res = {}
-        for mode in ("exact", "bf16"):
+        for mode in ("exact", operands):
             e.set_precision(mode)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -199,12 +201,12 @@ def precision_check(weights, img):
             low2, iou2, _ = e.decode_points(pts, slot=0, multimask=False, mask_input=mi)
             torch.cuda.synchronize()
             res[mode] = (f, low, iou, low2, iou2, time.perf_counter() - t0)
-        x, b = res["exact"], res["bf16"]
-        return {"what": "bf16 production arithmetic vs the engine's exact (fp32-operand) mode, same handle, same slice: 1 encoder pass + 64 grid prompts (3 masks) + their m2m refinement",
+        x, b = res["exact"], res[operands]
+        return {"what": f"{operands} production arithmetic vs the engine's exact (fp32-operand) mode, same handle, same slice: 1 encoder pass + 64 grid prompts (3 masks) + their m2m refinement",
                 "rel_rms": {"image_embed": rel(b[0]["image_embed"], x[0]["image_embed"]), "feat_s1": rel(b[0]["feat_s1"], x[0]["feat_s1"]),
                             "feat_s0": rel(b[0]["feat_s0"], x[0]["feat_s0"]), "low_res_logits": rel(b[1], x[1]), "m2m_low_res_logits": rel(b[3], x[3])},
                 "pred_iou_max_abs": float((b[2] - x[2]).abs().max().item()), "mask_sign_agreement": float(((b[1] > 0) == (x[1] > 0)).float().mean().item()),
-                "seconds": {"exact": x[5], "bf16": b[5]}}
+                "seconds": {"exact": x[5], operands: b[5]}}
     finally:
         e.close()
 
@@ -240,7 +242,11 @@ def main():
 
     cfg = get_config("large")
     weights = seeded_weights(cfg, 0)
-    eng = Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, weight_format=a.dtype)
+    def mk_engine(dtype):
+        if dtype == "fp16":
+            return Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, precision="fp16")
+        return Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, weight_format=dtype)
+    eng = mk_engine(a.dtype)
     amg = dict(npoints=a.npoints, crop_n_layers=a.crop_n_layers)
     params = make_amg_params(amg)
 
@@ -253,11 +259,11 @@ def main():
             planes[i] = plane
         return n_masks
 
-    engines = [eng] + [Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, weight_format=a.dtype) for _ in range(a.workers - 1)]
+    engines = [eng] + [mk_engine(a.dtype) for _ in range(a.workers - 1)]
     streams = [torch.cuda.Stream() for _ in engines]
-    # The headline runs with the m2m IoU pruning OFF (every one of the 9 216 refined candidates is upscaled, as in rounds 1-2): with the seeded
-    # synthetic weights nearly every candidate falls below cfgAMG's pred_iou_thresh, so the production default (pruning on, identical results)
-    # would skip almost all of that work - a property of the random IoU head, not of EM data.  The pruned time is reported beside it (`iou_pruning`).
+    # The headline runs with the m2m IoU pruning OFF (every one of the 9 216 refined candidates is upscaled, as in rounds 1-2): how much work the
+    # production default (pruning on, identical results) skips depends on the IoU head - a property of the weights, not of the kernels - so the
+    # metric does not lean on it.  The time with pruning on and the fraction it pruned are reported beside it (`iou_pruning`).
     for e_ in engines:
         e_.set_iou_pruning(False)
 
@@ -284,6 +290,7 @@ def main():
             t.join()
         return sum(totals)
 
+    img01_cpu = eng.prepare(pool[0]).cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None      # (input of the CPU baseline leg)
     run_steps(0, max(a.warmup, len(engines) if a.warmup else 0))
     planes = torch.zeros((a.steps, 1024, 1024), dtype=torch.uint16, device="cuda")
     gathered = torch.zeros((world * a.steps, 1024, 1024), dtype=torch.uint16, device="cuda") if world > 1 else None
@@ -326,12 +333,13 @@ def main():
         out = {
             "metric": "EM slices/sec (1024^2, Hiera-L)", "value": world * a.steps / dt, "unit": "slices/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp8": "bf16 operands, e4m3 weights (stage-2/3 block GEMMs)",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16 (IEEE half MFMA operands, fp32 accumulation: v_mfma_f32_16x16x32_f16)", "fp8": "bf16 operands, e4m3 weights (stage-2/3 block GEMMs)",
                                          "mxfp8": "mxfp8 operands on the fp8 MFMA (qkv / fc1 / fc2 of stages 2-3), bf16 elsewhere"}[a.dtype], "data": "synthetic",
             "config": {"workload": f"1024x1024 uint16 EM slice -> prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults: npoints={a.npoints}, "
                                    f"crop_n_layers={a.crop_n_layers} -> {n_crops} crops, {n_first} grid prompts + {3 * n_first} m2m refinements, multimask) "
                                    f"-> dedup/sort -> uint16 label plane; BASELINE configs[1]",
-                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)" + {"bf16": "", "fp8": "; qkv / proj / fc1 / fc2 of stages 2-3 quantised to OCP e4m3fn with "
+                       "weights": "seeded synthetic Hiera-L (no checkpoint offline)" + {"bf16": "", "fp16": "; weights, stored activations and every MFMA operand in IEEE half (SABER_PRECISION_FP16): "
+                                  "the bf16 kernels compiled for the other 16-bit type, same MFMA rate; NOT the headline precision (BASELINE configs[1] states bf16)", "fp8": "; qkv / proj / fc1 / fc2 of stages 2-3 quantised to OCP e4m3fn with "
                                   "per-row power-of-two scales at load, expanded to bf16 MFMA operands (storage format: the roofline stays the bf16 one)",
                                   "mxfp8": "; qkv (blocks that keep their width) / fc1 / fc2 of stages 2-3 in OCP MXFP8 (e4m3 + e8m0 per 32 K-elements), activations quantised to the same "
                                   "format where produced, products on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE configs[4]); NOT the headline precision"}[a.dtype], "slices_per_rank": a.steps, "engine_handles_per_gpu": a.workers,
@@ -384,8 +392,8 @@ def main():
         dtp = (time.perf_counter() - t0) / 6
         pruned, seen = eng.last_pruning()
         out["iou_pruning"] = {"what": "same step with saber_engine_set_iou_pruning on (the engine's default): m2m candidates whose four IoU predictions are all <= pred_iou_thresh skip "
-                                      "the mask upscaling; identical masks.  The fraction pruned is a property of the weights: the seeded IoU head puts nearly every candidate below cfgAMG's "
-                                      "threshold, a trained one does not - this is why the headline runs with pruning off",
+                                      "the mask upscaling; identical masks.  The fraction pruned (`pruned` of `m2m_candidates`, measured here) is a property of the weights' IoU head, "
+                                      "which is why the headline runs with pruning off",
                               "ms_per_slice": dtp * 1e3, "slices_per_s": 1.0 / dtp, "m2m_candidates": seen, "pruned": pruned, "pruned_fraction": (pruned / seen) if seen else None}
         for e_ in engines:
             e_.set_iou_pruning(False)
@@ -463,14 +471,55 @@ def main():
             out["propagation"] = video_bench.run("large", 32)
         except Exception as ex:
             out["propagation"] = {"error": str(ex)[:300]}
-    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail and a.dtype == "bf16":
-        try:        # what the bf16 operands of the headline cost against the engine's exact (fp32) mode on this slice; never part of `value`
-            out["precision"] = precision_check(weights, eng.prepare(pool[0]))
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail and a.dtype in ("bf16", "fp16"):
+        try:        # what the 16-bit operands of the headline cost against the engine's exact (fp32) mode on this slice; never part of `value`
+            out["precision"] = precision_check(weights, eng.prepare(pool[0]), a.dtype)
         except Exception as ex:
             out["precision"] = {"error": str(ex)[:300]}
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail and not a.no_alt_dtypes and a.dtype == "bf16":
+        # The other arithmetic modes as extra keys of the default line, each on fresh handles after the headline's were closed
+        # (a Hiera-L handle with its AMG scratch is ~58 GB): the same step, the same slices, `--workers` handles; never part of `value`.
+        img_prec = eng.prepare(pool[0]).clone()
+        for e_ in engines:
+            e_.close()
+        engines.clear()
+        out["alt_dtypes"] = {}
+        for dt_name in ("fp16", "mxfp8"):
+            try:
+                alt = [mk_engine(dt_name) for _ in range(a.workers)]
+                for e_ in alt:
+                    e_.set_iou_pruning(False)
+                engines.extend(alt)
+                eng = engines[0]
+                run_steps(0, 2 * len(engines))
+                torch.cuda.synchronize()
+                n_alt = max(8, a.steps // 2)
+                t0 = time.perf_counter()
+                run_steps(0, n_alt)
+                torch.cuda.synchronize()
+                dta = (time.perf_counter() - t0) / n_alt
+                rec = {"slices_per_s": 1.0 / dta, "ms_per_slice": dta * 1e3, "slices": n_alt, "engine_handles": len(engines),
+                       "vs_headline": (dt / a.steps) / dta}
+                eng.profile_begin()
+                step(0)
+                pr = eng.profile_end()
+                rec["kernel_classes_ms_per_slice"] = {k: round(v["ms"], 3) for k, v in pr.items()}
+                g = pr["gemm_bf16"]
+                if g["ms"] > 0 and dt_name == "fp16":
+                    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                    rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "kernel": "the gemm class of the headline, compiled for fp16 operands (namespace op_f16)",
+                                       "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]), "launches_per_slice": g["launches"]}
+                if dt_name == "fp16":
+                    rec["precision"] = precision_check(weights, img_prec, "fp16")
+                out["alt_dtypes"][dt_name] = rec
+            except Exception as ex:
+                out["alt_dtypes"][dt_name] = {"error": str(ex)[:300]}
+            for e_ in engines:
+                e_.close()
+            engines.clear()
+        eng = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        img01 = eng.prepare(pool[0]).cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(cfg, weights, img01, a.crop_n_layers)
+        out["cpu_baseline"] = cpu_baseline(cfg, weights, img01_cpu, a.crop_n_layers)
     if rank == 0:
         print(json.dumps(out))
     for e_ in engines:

@@ -177,10 +177,19 @@ int saber_engine_set_weight_format(saber_engine* e, int format);
  * SABER_PRECISION_EXACT: every operand, stored activation and statistic in fp32 (GEMMs on the fp32-input MFMA, exact-erf GELU, the mask
  *   decoder as the unfolded composition upstream executes): the reference's own precision (saber/utils/io.py:127-132 runs fp32, autocast
  *   commented out), ~1e-5 from the fp32 CPU oracle; tens of times slower - a verification mode, never the default.
+ * SABER_PRECISION_FP16 (round 4): the production kernels compiled for IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 forms' rate)
+ *   - 10 mantissa bits on every GEMM / attention operand with fp32 accumulation, i.e. the operand width of the TF32 arithmetic the
+ *   reference enables on its GPUs (saber/utils/io.py:127-130).  Same kernels, schedules, token order, workspaces and C-ABI as bf16; weights
+ *   and stored activations are fp16.  What fp16 gives up is RANGE (largest finite value 65 504): saber_engine_finalize fails loudly when a
+ *   weight, or a LayerNorm output bound |gamma| sqrt(C) + |beta|, cannot be represented.  The choice is made ONCE, before
+ *   saber_engine_finalize (the weights are converted there); a handle finalized in one 16-bit type cannot be switched to the other.
+ *   Not available together with the fp8 weight formats.
  * Call it with EXACT once BEFORE saber_engine_finalize (the fp32 weight copies are kept only then: +0.9 GB for Hiera-L); afterwards the
- * mode can be switched back and forth between calls on the same handle.  hipGraph replay is bypassed in exact mode. */
+ * mode can be switched back and forth between EXACT and the handle's 16-bit type between calls on the same handle (EXACT then FP16 before
+ * finalize makes a handle with both).  hipGraph replay is bypassed in exact mode. */
 #define SABER_PRECISION_BF16 0
 #define SABER_PRECISION_EXACT 1
+#define SABER_PRECISION_FP16 2
 int saber_engine_set_precision(saber_engine* e, int precision);
 
 /* hipGraph replay of saber_amg_generate's launch sequences (BASELINE configs[4]: "hipGraph-captured per-slice encode+decode"): the batched

@@ -139,6 +139,13 @@ int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* p
 int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pek, const uint16_t* Qt, const float* tq, float qscale, float* part_ws,
                     float* ml_ws, int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream);
 
+/* 16-bit operand type of every kernel-level entry point called from THIS thread (thread-local): 0 = bf16 (default), 1 = IEEE fp16.  The
+ * uint16_t operands and outputs of saber_k_gemm*, saber_k_layernorm, saber_k_hiera_attention*, saber_k_dec_*, saber_k_flash256, ... are
+ * then fp16 bit patterns; same kernels, compiled for v_mfma_f32_16x16x32_f16.  Returns the previous setting. */
+int saber_k_set_operand_type(int f16);
+/* the host-side fp32 -> IEEE half (round to nearest even) conversion saber_engine_finalize applies to the weights in SABER_PRECISION_FP16
+ * (host pointers; no device needed) */
+void saber_k_host_f32_to_f16(const float* in, uint16_t* out, int64_t n);
 /* development hook: bit flags read by experimental kernel variants (0 in production) */
 void saber_k_set_debug(int flags);
 /* development: device buffer (uint64 per block, wave and phase) that instrumented kernels fill with s_memtime sums; NULL = off */

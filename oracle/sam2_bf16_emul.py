@@ -34,9 +34,30 @@ from saber_amd.model_config import HieraConfig, DEC_HEADS, DYN_MULTIMASK_DELTA, 
 LOG2E = 1.4426950408889634
 
 
+# The 16-bit type every rounding point below rounds to: bf16 (the engine's default arithmetic) or IEEE half (SABER_PRECISION_FP16, round 4:
+# the same kernels compiled for fp16 operands - same rounding POINTS, 10 mantissa bits instead of 7).  `with operand_type("fp16"):` switches
+# it for the emulation calls inside the block.
+_OPERAND_DTYPE = torch.bfloat16
+
+
+class operand_type:
+    def __init__(self, name: str):
+        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[name]
+
+    def __enter__(self):
+        global _OPERAND_DTYPE
+        self.prev, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_DTYPE
+        _OPERAND_DTYPE = self.prev
+        return False
+
+
 def bf(x: torch.Tensor) -> torch.Tensor:
-    """round to nearest-even bf16, keep the value in fp32"""
-    return x.to(torch.bfloat16).to(torch.float32)
+    """round to nearest-even to the 16-bit operand type (bf16 unless inside operand_type("fp16")), keep the value in fp32"""
+    return x.to(_OPERAND_DTYPE).to(torch.float32)
 
 
 def lin(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

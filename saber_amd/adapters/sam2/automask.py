@@ -25,9 +25,15 @@ def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_imag
         raise RuntimeError(f"the MI355X engine needs a ROCm device, got '{dev}' (there is no CPU fallback)")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     src = pretrained_weights.resolve_weights(sam2_cfg, checkpoint)
-    key = (idx, sam2_cfg, tuple(sorted(src.items())), replica)
+    # SABER_AMD_PRECISION=fp16: the production kernels on IEEE half operands (10 mantissa bits = the TF32 arithmetic the reference enables on
+    # its GPUs, saber/utils/io.py:127-130; include/saber_amd.h: SABER_PRECISION_FP16).  Default: bf16, the arithmetic of BASELINE configs[1].
+    import os
+    precision = os.environ.get("SABER_AMD_PRECISION", "bf16")
+    if precision not in ("bf16", "fp16"):
+        raise ValueError(f"SABER_AMD_PRECISION must be 'bf16' or 'fp16', got '{precision}'")
+    key = (idx, sam2_cfg, tuple(sorted(src.items())), replica, precision)
     if key not in _ENGINES:
-        eng = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, **src)
+        eng = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, precision=precision, **src)
         eng._build = (sam2_cfg, checkpoint)       # what get_replica() needs to build an identical handle
         _ENGINES[key] = eng
     return _ENGINES[key]

@@ -39,6 +39,37 @@ def _bf16_bits(a: np.ndarray) -> np.ndarray:
     return r.astype(np.uint16)
 
 
+def _f16_bits(a: np.ndarray) -> np.ndarray:
+    """fp32 -> IEEE half bit patterns, round to nearest even (the engine's weight conversion in SABER_PRECISION_FP16)"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if np.abs(a).max(initial=0.0) > 65504.0:
+        raise ValueError("a memory-model weight exceeds the fp16 range (65504): run this checkpoint with bf16 operands")
+    return a.astype(np.float16).view(np.uint16)
+
+
+class _OperandLib:
+    """The kernel-level C-ABI (saber_k_*) with the calling thread's 16-bit operand type set to fp16 around every call
+    (include/saber_amd_kernels.h: saber_k_set_operand_type is thread-local; the engine-level entry points set it from the handle)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("saber_k_") or name in ("saber_k_last_error", "saber_k_set_operand_type"):
+            return fn
+        lib = self._lib
+
+        def call(*args):
+            prev = lib.saber_k_set_operand_type(1)
+            try:
+                return fn(*args)
+            finally:
+                lib.saber_k_set_operand_type(prev)
+        setattr(self, name, call)
+        return call
+
+
 def _sine_pe_2d(side: int, num_pos_feats: int) -> np.ndarray:
     """upstream PositionEmbeddingSine(normalize=True, scale 2 pi, temperature 1e4): (side*side, 2*num_pos_feats), y half first"""
     eps, scale = 1e-6, 2 * math.pi
@@ -133,6 +164,11 @@ class VideoPredictor:
         if num_maskmem > 7:
             raise ValueError("num_maskmem must be at most 7")
         self.eng, self.lib, self.dev = engine, engine.lib, engine.device
+        # 16-bit operand type of the engine handle: every uint16 buffer of this class (GEMM weights, stored memories, attention operands)
+        # holds that type's bit patterns
+        self.f16 = getattr(engine, "operands", "bf16") == "fp16"
+        if self.f16:
+            self.lib = _OperandLib(engine.lib)
         if self.lib.saber_k_init(engine.device_index) != 0:
             raise RuntimeError(self.lib.saber_k_last_error().decode())
         self.num_maskmem = num_maskmem
@@ -154,7 +190,7 @@ class VideoPredictor:
             is_gemm_w = k.endswith(".weight") and a.ndim >= 2 and "dwconv" not in k and not k.startswith("mask_downsample.") and \
                 ("mask_downsampler.encoder" not in k or k.endswith("encoder.12.weight"))
             if is_gemm_w:       # operands of the bf16 MFMA GEMM: [N][K] row-major, bf16 (RNE) like the engine's own weights
-                self.bf[k] = torch.from_numpy(_bf16_bits(a.reshape(a.shape[0], -1))).to(self.dev)
+                self.bf[k] = torch.from_numpy((_f16_bits if self.f16 else _bf16_bits)(a.reshape(a.shape[0], -1))).to(self.dev)
         self.tpos = np.asarray(W["maskmem_tpos_enc"], dtype=np.float32)[:num_maskmem].reshape(num_maskmem, -1)      # predictor.py:31-32
         self.no_obj_ptr = np.asarray(W["no_obj_ptr"], dtype=np.float32).reshape(1, 256)
         self.no_obj_spatial = np.asarray(W["no_obj_embed_spatial"], dtype=np.float32).reshape(-1)

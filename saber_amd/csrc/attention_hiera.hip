@@ -34,35 +34,32 @@ template <int HD_> struct HdTraits {
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+__device__ __forceinline__ op16x4 tr_read(const char* p) {
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-    return __builtin_bit_cast(bf16x4, v);
+    return __builtin_bit_cast(op16x4, v);
 }
-__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+__device__ __forceinline__ op16x8 cat4(op16x4 a, op16x4 b) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
-    uint4 u = make_uint4(pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(b0, b1), pack_bf16(b2, b3));
-    return __builtin_bit_cast(bf16x8, u);
+__device__ __forceinline__ op16x8 pack8(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+    uint4 u = make_uint4(pack_op16(a0, a1), pack_op16(a2, a3), pack_op16(b0, b1), pack_op16(b2, b3));
+    return __builtin_bit_cast(op16x8, u);
 }
 __device__ __forceinline__ uint4 bf16max4(uint4 a, uint4 b) {
-    // elementwise max of 8 packed bf16 (exact: compare as floats)
+    // elementwise max of 8 packed 16-bit operands (exact: compare as floats)
     uint32_t* pa = reinterpret_cast<uint32_t*>(&a);
     const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float alo = __uint_as_float(pa[i] << 16), ahi = __uint_as_float(pa[i] & 0xffff0000u);
-        const float blo = __uint_as_float(pb[i] << 16), bhi = __uint_as_float(pb[i] & 0xffff0000u);
-        const uint32_t lo = __float_as_uint(fmaxf(alo, blo)) >> 16;
-        const uint32_t hi = __float_as_uint(fmaxf(ahi, bhi)) & 0xffff0000u;
-        pa[i] = hi | lo;
+        // (the maximum of two representable values is representable: the re-pack is exact in either operand type)
+        pa[i] = pack_op16(fmaxf(op16_lo(pa[i]), op16_lo(pb[i])), fmaxf(op16_hi(pa[i]), op16_hi(pb[i])));
     }
     return a;
 }
 
 // q fragment for 16 rows starting at pooled/unpooled row index `row` (already validated by caller)
 template <int HD>
-__device__ __forceinline__ bf16x8 load_q_frag(const bf16_t* qkv, int64_t rs, int64_t tok0, int row, bool valid, int hdoff,
+__device__ __forceinline__ op16x8 load_q_frag(const bf16_t* qkv, int64_t rs, int64_t tok0, int row, bool valid, int hdoff,
                                               int hoff, int q_pool) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (valid && hdoff < HD) {
@@ -76,7 +73,7 @@ __device__ __forceinline__ bf16x8 load_q_frag(const bf16_t* qkv, int64_t rs, int
             v = *reinterpret_cast<const uint4*>(qkv + (tok0 + row) * rs + hoff + hdoff);
         }
     }
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(op16x8, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -109,7 +106,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
         *reinterpret_cast<uint4*>(vs + row * VSTRIDE + ch * 16) = val;
     }
     // K fragments straight from global
-    bf16x8 kf[KT][CK];
+    op16x8 kf[KT][CK];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
             const int key = kt * 16 + fi, hdoff = 32 * c + 8 * fg;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (key < nk && hdoff < HD) v = *reinterpret_cast<const uint4*>(qkv + (tok0 + key) * rs + os + h * HD + hdoff);
-            kf[kt][c] = __builtin_bit_cast(bf16x8, v);
+            kf[kt][c] = __builtin_bit_cast(op16x8, v);
         }
     __builtin_amdgcn_wave_barrier();
 
@@ -127,7 +124,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
     for (int qt = 0; qt * 16 < nq; ++qt) {
         const int row = qt * 16 + fi;
         const bool rvalid = row < nq;
-        bf16x8 qf[CK];
+        op16x8 qf[CK];
 #pragma unroll
         for (int c = 0; c < CK; ++c) qf[c] = load_q_frag<HD>(qkv, rs, tok0, row, rvalid, 32 * c + 8 * fg, h * HD, q_pool);
         f32x4 s[KT];
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
         for (int kt = 0; kt < KT; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < CK; ++c) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kt], 0, 0, 0);
+            for (int c = 0; c < CK; ++c) s[kt] = MFMA_16x16x32(kf[kt][c], qf[c], s[kt], 0, 0, 0);
         }
         // softmax in the exp2 domain with the scale folded into the exponent's fma: exp2(s * sc - max * sc), raw v_exp_f32
         // (exp2f() adds a denormal-range fix-up of 4 more VALU instructions per element; results below 2^-126 flush to 0 either way)
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
             }
         sum = xor32_sum(xor16_sum(sum));
         const float inv = __builtin_amdgcn_rcpf(sum);
-        bf16x8 pf[KS];
+        op16x8 pf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             pf[ks] = pack8(s[2 * ks][0], s[2 * ks][1], s[2 * ks][2], s[2 * ks][3], s[2 * ks + 1][0], s[2 * ks + 1][1],
@@ -172,13 +169,13 @@ __global__ __launch_bounds__(256) void hiera_attn_small_kernel(const bf16_t* __r
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const char* base = vs + (32 * ks + 4 * fg + (fi >> 2)) * VSTRIDE + (16 * dt + 4 * (fi & 3)) * 2;
-                const bf16x8 vf = cat4(tr_read(base), tr_read(base + 16 * VSTRIDE));
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks], o, 0, 0, 0);
+                const op16x8 vf = cat4(tr_read(base), tr_read(base + 16 * VSTRIDE));
+                o = MFMA_16x16x32(vf, pf[ks], o, 0, 0, 0);
             }
             const int d = 16 * dt + 4 * fg;
             if (rvalid && d < HD)
                 *reinterpret_cast<uint2*>(out + (orow0 + row) * os + h * HD + d) =
-                    make_uint2(pack_bf16(o[0] * inv, o[1] * inv), pack_bf16(o[2] * inv, o[3] * inv));
+                    make_uint2(pack_op16(o[0] * inv, o[1] * inv), pack_op16(o[2] * inv, o[3] * inv));
         }
     }
 }
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
     // zero the whole K/V region once: pad chunks are never overwritten afterwards
     for (int i = tid; i < (K_LDS_BYTES + V_LDS_BYTES) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    bf16x8 qf[QT][CK];
+    op16x8 qf[QT][CK];
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -276,17 +273,17 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
         f32x4 s[QT][8];
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            bf16x8 kf[CK];
+            op16x8 kf[CK];
 #pragma unroll
             for (int c = 0; c < CK; ++c) {
                 const int row = 16 * kt + fi;
-                kf[c] = *reinterpret_cast<const bf16x8*>(ks_ + row * 256 + (((4 * c + fg) ^ (row & 15)) << 4));
+                kf[c] = *reinterpret_cast<const op16x8*>(ks_ + row * 256 + (((4 * c + fg) ^ (row & 15)) << 4));
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qf[t][c], s[t][kt], 0, 0, 0);
+                for (int c = 0; c < CK; ++c) s[t][kt] = MFMA_16x16x32(kf[c], qf[t][c], s[t][kt], 0, 0, 0);
             }
         }
         uint32_t mbits = 0xffffffffu;                      // bit 4*kt + r: key kb*128 + 16*kt + 4*fg + r takes part
@@ -302,7 +299,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
                     if (key + r < nk && ((mv >> (8 * r)) & 0xffu)) mbits |= 1u << (4 * kt + r);
             }
         }
-        bf16x8 pf[QT][4];
+        op16x8 pf[QT][4];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             // online softmax in the exp2 domain; the scale rides in the exponent's fma and v_exp_f32 is used raw (see the small kernel)
@@ -344,9 +341,9 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const char* base = vs + (32 * ks + 4 * fg + (fi >> 2)) * VSTRIDE + (16 * dt + 4 * (fi & 3)) * 2;
-                const bf16x8 vf = cat4(tr_read(base), tr_read(base + 16 * VSTRIDE));
+                const op16x8 vf = cat4(tr_read(base), tr_read(base + 16 * VSTRIDE));
 #pragma unroll
-                for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
+                for (int t = 0; t < QT; ++t) o[t][dt] = MFMA_16x16x32(vf, pf[t][ks], o[t][dt], 0, 0, 0);
             }
     }
 #pragma unroll
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(256) void hiera_attn_large_kernel(const bf16_t* __r
             const int d = 16 * dt + 4 * fg;
             if (d < HD)
                 *reinterpret_cast<uint2*>(out + (orow0 + row) * os + h * HD + d) =
-                    make_uint2(pack_bf16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_bf16(o[t][dt][2] * inv, o[t][dt][3] * inv));
+                    make_uint2(pack_op16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_op16(o[t][dt][2] * inv, o[t][dt][3] * inv));
         }
     }
 }
@@ -449,13 +446,13 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
         // (raw s_barrier: __syncthreads() would also drain the output stores still in flight with vmcnt(0))
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        bf16x8 qc[2][CK];
+        op16x8 qc[2][CK];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int c = 0; c < CK; ++c) {
                 const u32x4 z4 = {0u, 0u, 0u, 0u};
-                qc[t][c] = __builtin_bit_cast(bf16x8, (32 * c + 8 * fg) < HD ? qraw[t][c] : z4);
+                qc[t][c] = __builtin_bit_cast(op16x8, (32 * c + 8 * fg) < HD ? qraw[t][c] : z4);
             }
         const int64_t tok_c = tok0;
         const int h_c = h;
@@ -481,20 +478,20 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
             f32x4 s[2][8];
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) {
-                bf16x8 kf[CK];
+                op16x8 kf[CK];
 #pragma unroll
-                for (int c = 0; c < CK; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(kbase + (16 * kt + fi) * ROWB + (4 * c + fg) * 16);
+                for (int c = 0; c < CK; ++c) kf[c] = *reinterpret_cast<const op16x8*>(kbase + (16 * kt + fi) * ROWB + (4 * c + fg) * 16);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
+                    for (int c = 0; c < CK; ++c) s[t][kt] = MFMA_16x16x32(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
                 }
             }
             constexpr int NJ = (NINST + 7) / 8;
             // (placement measured on the stage-2 shape: 125 us per launch against 140 with all pairs at the task's start; pairs 1 | 1 | 2 | rest)
             if (more) { if (kb == 0) issue(tok0, h, nbuf, 0, 1); else issue(tok0, h, nbuf, 2, NJ > 4 ? 4 : NJ); }
-            bf16x8 pf[2][4];
+            op16x8 pf[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float mx = -3.0e38f;
@@ -542,9 +539,9 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 vf = cat4(__builtin_bit_cast(bf16x4, lo[ks]), __builtin_bit_cast(bf16x4, hi[ks]));
+                    const op16x8 vf = cat4(__builtin_bit_cast(op16x4, lo[ks]), __builtin_bit_cast(op16x4, hi[ks]));
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
+                    for (int t = 0; t < 2; ++t) o[t][dt] = MFMA_16x16x32(vf, pf[t][ks], o[t][dt], 0, 0, 0);
                 }
             }
         }
@@ -557,7 +554,7 @@ __global__ __launch_bounds__(512) void hiera_attn_win256_kernel(const bf16_t* __
                 const int d = 16 * dt + 4 * fg;
                 if (d < HD)
                     *reinterpret_cast<uint2*>(out + (tok_c + row) * os + h_c * HD + d) =
-                        make_uint2(pack_bf16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_bf16(o[t][dt][2] * inv, o[t][dt][3] * inv));
+                        make_uint2(pack_op16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_op16(o[t][dt][2] * inv, o[t][dt][3] * inv));
             }
         }
         // the next task's loads were issued before this task's 2 * DT output stores: all but the youngest 2 * DT operations done
@@ -664,7 +661,7 @@ __global__ __launch_bounds__(512) void hiera_attn_stream_kernel(const bf16_t* __
     (void)issue_next();                               // item 0 (with the first task's Q)
     n1 = issue_next();                                // item 1
     wait_younger(n1);
-    bf16x8 qc[2][CK];
+    op16x8 qc[2][CK];
     float m[2], l[2];
     f32x4 o[2][DT];
     const float sc = TR::SCALE;
@@ -679,7 +676,7 @@ __global__ __launch_bounds__(512) void hiera_attn_stream_kernel(const bf16_t* __
 #pragma unroll
                 for (int c = 0; c < CK; ++c) {
                     const u32x4 z4 = {0u, 0u, 0u, 0u};
-                    qc[t][c] = __builtin_bit_cast(bf16x8, (32 * c + 8 * fg) < HD ? qraw[t][c] : z4);
+                    qc[t][c] = __builtin_bit_cast(op16x8, (32 * c + 8 * fg) < HD ? qraw[t][c] : z4);
                 }
                 m[t] = -3.0e38f;
                 l[t] = 0.f;
@@ -694,17 +691,17 @@ __global__ __launch_bounds__(512) void hiera_attn_stream_kernel(const bf16_t* __
             f32x4 s[2][8];
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) {
-                bf16x8 kf[CK];
+                op16x8 kf[CK];
 #pragma unroll
-                for (int c = 0; c < CK; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(kbase + (16 * kt + fi) * ROWB + (4 * c + fg) * 16);
+                for (int c = 0; c < CK; ++c) kf[c] = *reinterpret_cast<const op16x8*>(kbase + (16 * kt + fi) * ROWB + (4 * c + fg) * 16);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < CK; ++c) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
+                    for (int c = 0; c < CK; ++c) s[t][kt] = MFMA_16x16x32(kf[c], qc[t][c], s[t][kt], 0, 0, 0);
                 }
             }
-            bf16x8 pf[2][4];
+            op16x8 pf[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float mx = -3.0e38f;
@@ -749,9 +746,9 @@ __global__ __launch_bounds__(512) void hiera_attn_stream_kernel(const bf16_t* __
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 vf = cat4(__builtin_bit_cast(bf16x4, lo[ks]), __builtin_bit_cast(bf16x4, hi2[ks]));
+                    const op16x8 vf = cat4(__builtin_bit_cast(op16x4, lo[ks]), __builtin_bit_cast(op16x4, hi2[ks]));
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
+                    for (int t = 0; t < 2; ++t) o[t][dt] = MFMA_16x16x32(vf, pf[t][ks], o[t][dt], 0, 0, 0);
                 }
             }
         }
@@ -770,7 +767,7 @@ __global__ __launch_bounds__(512) void hiera_attn_stream_kernel(const bf16_t* __
                     const int d = 16 * dt + 4 * fg;
                     if (d < HD)
                         *reinterpret_cast<uint2*>(out + (tokc + row) * os + hc * HD + d) =
-                            make_uint2(pack_bf16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_bf16(o[t][dt][2] * inv, o[t][dt][3] * inv));
+                            make_uint2(pack_op16(o[t][dt][0] * inv, o[t][dt][1] * inv), pack_op16(o[t][dt][2] * inv, o[t][dt][3] * inv));
                 }
             }
             kbc = 0;
@@ -814,7 +811,6 @@ static const char* launch_hd(const bf16_t* qkv, bf16_t* out, int n_windows, int 
     }
     if (q_pool && (nk & 3)) return "hiera_attention: q_pool needs nk % 4 == 0";
     const int nq = q_pool ? nk / 4 : nk;
-    extern int g_saber_debug_flags;
     if constexpr (WIN256_LDS(HD) <= 160 * 1024) if (nk == 256 && !q_pool && !kmask && !(g_saber_debug_flags & (32 | 2))) {
         const int tasks_per_xcd = ((n_windows + 7) / 8) * heads;       // persistent: one workgroup per CU, fewer when there is less work
         hipLaunchKernelGGL((hiera_attn_win256_kernel<HD>), dim3(8 * (tasks_per_xcd < 32 ? tasks_per_xcd : 32)), dim3(512), WIN256_LDS(HD), s, qkv, out, n_windows, heads);

@@ -20,7 +20,6 @@ extern "C" int saber_k_init(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return kfail("hipSetDevice failed");
     const char* m = gemm_init_device();
     if (!m) m = gemm_rowln_init_device();
-    if (!m) m = gemm_w1_init_device();
     if (!m) m = hiera_attention_init_device();
     if (!m) m = image_ops_init_device();
     if (!m) m = decoder_fused_init_device();
@@ -118,6 +117,13 @@ int g_saber_debug_flags = 0;
 unsigned long long* g_saber_stamp_buf = nullptr;   // development: device buffer for in-kernel cycle stamps (nullptr in production)
 extern "C" void saber_k_set_stamp_buffer(void* dev) { g_saber_stamp_buf = (unsigned long long*)dev; }
 extern "C" void saber_k_set_debug(int flags) { g_saber_debug_flags = flags; }
+// 16-bit operand type of the kernel-level entry points called from THIS thread: 0 = bf16 (default), 1 = fp16 (common.h "OPERAND TYPE").
+// The engine-level C-ABI sets it per call from the handle's precision mode and restores it on return (DeviceGuard, engine.h).
+thread_local int g_saber_op_f16 = 0;
+bf16_t saber_host_f2h(float f);          // engine.hip
+// host-side fp32 -> IEEE half conversion the engine converts its weights with (exposed for the CPU test against numpy.float16)
+extern "C" void saber_k_host_f32_to_f16(const float* in, uint16_t* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = saber_host_f2h(in[i]); }
+extern "C" int saber_k_set_operand_type(int f16) { const int prev = g_saber_op_f16; g_saber_op_f16 = f16 ? 1 : 0; return prev; }
 
 // ------------------------------------------------------------------------------------------------ video (memory) path kernels
 extern "C" int saber_k_rope(const float* x, int64_t rows, int n_rot, int C, int side, float theta, float* out_f32, uint16_t* out_bf16, void* stream) {

@@ -43,6 +43,7 @@ struct saber_classifier {
 
 int eng_rm_tables(saber_engine* e);    // engine.hip
 
+bf16_t saber_host_f2h(float f);          // engine.hip: fp32 -> IEEE half bits (RNE)
 static inline bf16_t cls_f2bf(float f) {
     uint32_t u; memcpy(&u, &f, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(256) void cls_crop_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && ball) atomicAdd(&areas[b], __popcll(ball));
 }
 // A0[b][r = y*64+x][0..255] = emb * m, [256..511] = emb * (1 - m); m = mask crop sampled at (5y, 5x) (nearest 320 -> 64)
+// (F16: the engine handle's 16-bit operand type - this file is compiled once, so the two element-wise kernels that write GEMM operands pick
+// the conversion at compile time through a template flag; the GEMMs themselves dispatch through kernels.h)
+template <bool F16> __device__ __forceinline__ uint32_t cls_pack(float lo, float hi) { return F16 ? pack_f16_rn(lo, hi) : pack_bf16_rn(lo, hi); }
+template <bool F16>
 __global__ __launch_bounds__(64) void cls_roi_kernel(const float* __restrict__ emb, const int* __restrict__ rm_to_eng, const uint8_t* __restrict__ cmask,
                                                      const int* __restrict__ sel, bf16_t* __restrict__ A0) {
     const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(64) void cls_roi_kernel(const float* __restrict__ e
     const int t = rm_to_eng[r];
     const bool m = cmask[(int64_t)sel[b] * CROP_PIX + (5 * y) * CROP + 5 * x] != 0;
     const float4 f = *reinterpret_cast<const float4*>(emb + ((int64_t)b * 4096 + t) * 256 + 4 * lane);
-    const uint2 v = make_uint2(pack_bf16(f.x, f.y), pack_bf16(f.z, f.w)), z = make_uint2(0u, 0u);
+    const uint2 v = make_uint2(cls_pack<F16>(f.x, f.y), cls_pack<F16>(f.z, f.w)), z = make_uint2(0u, 0u);
     bf16_t* row = A0 + ((int64_t)b * 4096 + r) * 512 + 4 * lane;
     *reinterpret_cast<uint2*>(row) = m ? v : z;
     *reinterpret_cast<uint2*>(row + 256) = m ? z : v;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(64) void cls_roi_kernel(const float* __restrict__ e
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.f ? v : a * v; }
 // A[b][y*S+x][(ky*3+kx)*C + c] = act(G)[b][y+ky-1][x+kx-1][c] (zero outside); act = PReLU, followed by a 2x2 max-pool of the 2S x 2S grid
 // when POOL.  One block per output pixel.
-template <bool POOL>
+template <bool POOL, bool F16>
 __global__ __launch_bounds__(256) void cls_im2col_kernel(const float* __restrict__ G, float alpha, int S, int C, bf16_t* __restrict__ A) {
     const int r = blockIdx.x, b = blockIdx.y;
     const int y = r / S, x = r - y * S;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void cls_im2col_kernel(const float* __restrict
                 v = *reinterpret_cast<const float4*>(Gb + ((int64_t)yy * S + xx) * C + c);
                 v.x = prelu(v.x, alpha); v.y = prelu(v.y, alpha); v.z = prelu(v.z, alpha); v.w = prelu(v.w, alpha);
             }
-            o = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            o = make_uint2(cls_pack<F16>(v.x, v.y), cls_pack<F16>(v.z, v.w));
         }
         *reinterpret_cast<uint2*>(row + (int64_t)k * C + c) = o;
     }
@@ -220,12 +225,16 @@ __global__ __launch_bounds__(128) void cls_tail_kernel(const float* __restrict__
 }
 
 static const char* launch_cls_roi(const float* emb, const int* rm, const uint8_t* cmask, const int* sel, bf16_t* A0, int k, hipStream_t s) {
-    hipLaunchKernelGGL(cls_roi_kernel, dim3(4096, k), dim3(64), 0, s, emb, rm, cmask, sel, A0);
+    if (saber_op_is_f16()) hipLaunchKernelGGL(cls_roi_kernel<true>, dim3(4096, k), dim3(64), 0, s, emb, rm, cmask, sel, A0);
+    else hipLaunchKernelGGL(cls_roi_kernel<false>, dim3(4096, k), dim3(64), 0, s, emb, rm, cmask, sel, A0);
     return nullptr;
 }
 static const char* launch_cls_im2col(bool pool, const float* G, float alpha, int S, int C, bf16_t* A, int k, hipStream_t s) {
-    if (pool) hipLaunchKernelGGL(cls_im2col_kernel<true>, dim3(S * S, k), dim3(256), 0, s, G, alpha, S, C, A);
-    else hipLaunchKernelGGL(cls_im2col_kernel<false>, dim3(S * S, k), dim3(256), 0, s, G, alpha, S, C, A);
+    const bool f16 = saber_op_is_f16();
+    if (pool && f16) hipLaunchKernelGGL((cls_im2col_kernel<true, true>), dim3(S * S, k), dim3(256), 0, s, G, alpha, S, C, A);
+    else if (pool) hipLaunchKernelGGL((cls_im2col_kernel<true, false>), dim3(S * S, k), dim3(256), 0, s, G, alpha, S, C, A);
+    else if (f16) hipLaunchKernelGGL((cls_im2col_kernel<false, true>), dim3(S * S, k), dim3(256), 0, s, G, alpha, S, C, A);
+    else hipLaunchKernelGGL((cls_im2col_kernel<false, false>), dim3(S * S, k), dim3(256), 0, s, G, alpha, S, C, A);
     return nullptr;
 }
 
@@ -272,7 +281,7 @@ struct ClsFinal {
     bf16_t* up_bf16(const std::vector<float>& v) {
         if (st != SABER_OK) return nullptr;
         std::vector<bf16_t> h(v.size());
-        for (size_t i = 0; i < v.size(); ++i) h[i] = cls_f2bf(v[i]);
+        for (size_t i = 0; i < v.size(); ++i) h[i] = c->e->op_f16 ? saber_host_f2h(v[i]) : cls_f2bf(v[i]);      // the engine handle's 16-bit operand type
         bf16_t* d = nullptr;
         st = eng_alloc(c->e, &d, h.size());
         if (st == SABER_OK && hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) st = eng_fail(c->e, SABER_ERR_HIP, "classifier: weight upload failed");

@@ -1,27 +1,62 @@
-// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 bf16).
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 on 16-bit operands).
+//
+// OPERAND TYPE.  Every MFMA kernel of the engine takes 16-bit operands and accumulates in fp32.  Which 16-bit type is a build-time
+// parameter of the kernel sources: each of them is compiled twice (csrc/Makefile, op_wrap.hip), once with bf16 operands (namespace
+// op_bf16: 8 exponent / 7 mantissa bits, the headline arithmetic of BASELINE configs[1]) and once with SABER_OP_F16 (namespace op_f16:
+// IEEE half, 5 / 10 bits - the mantissa width of the TF32 arithmetic the reference enables on its GPUs, saber/utils/io.py:127-130; same
+// MFMA rate: v_mfma_f32_16x16x32_f16).  Kernels only ever name the type through op16x8 / pack_op16 / f2op / op2f / op16_lo / op16_hi /
+// MFMA_16x16x32 below; storage is uint16_t (`bf16_t`, the name predates the second type) in either build.  kernels.h dispatches every
+// launcher on the calling thread's operand type (saber_op_is_f16()), which the engine sets from its precision mode.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // staging registers: a first-class vector (HIP's uint4 is a struct and can end up in scratch)
-typedef uint16_t bf16_t;  // storage type for bf16 in global memory
+typedef uint16_t bf16_t;  // storage type of a 16-bit operand in global memory (bf16 or fp16 bits, see above)
 
 #define WAVE 64
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
-// round-to-nearest-even f32 -> bf16 pair (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+// both conversion sets exist in every build (the classifier's two element-wise kernels pick one at run time)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_bits_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float f16_bits_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// round-to-nearest-even f32 -> 16-bit pair (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pack_bf16_rn(float lo, float hi) {
     __hip_bfloat162 v = __float22bfloat162_rn(make_float2(lo, hi));
     return *reinterpret_cast<uint32_t*>(&v);
 }
-__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)(pack_bf16(x, 0.f) & 0xffffu); }
+__device__ __forceinline__ uint32_t pack_f16_rn(float lo, float hi) {
+    const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+#ifdef SABER_OP_F16
+typedef _Float16 op16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 op16x4 __attribute__((ext_vector_type(4)));
+#define MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SABER_OP_NAME "f16"
+__device__ __forceinline__ float op2f(bf16_t v) { return f16_bits_to_f32(v); }
+__device__ __forceinline__ uint32_t pack_op16(float lo, float hi) { return pack_f16_rn(lo, hi); }
+// the two halves of a packed pair as fp32 (v_cvt_f32_f16, the upper one with an SDWA word select)
+__device__ __forceinline__ float op16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
+__device__ __forceinline__ float op16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
+#else
+typedef __bf16 op16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 op16x4 __attribute__((ext_vector_type(4)));
+#define MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SABER_OP_NAME "bf16"
+__device__ __forceinline__ float op2f(bf16_t v) { return bf16_bits_to_f32(v); }
+__device__ __forceinline__ uint32_t pack_op16(float lo, float hi) { return pack_bf16_rn(lo, hi); }
+__device__ __forceinline__ float op16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float op16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
+__device__ __forceinline__ bf16_t f2op(float x) { return (bf16_t)(pack_op16(x, 0.f) & 0xffffu); }
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, ~12 VALU ops instead of libm's ~60): the exact-erf GELU of
 // SAM2 is evaluated ~5e10 times per slice, so libm erff alone would cost tens of ms of pure VALU time.

@@ -32,23 +32,23 @@
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 typedef unsigned int u32x2_d __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16x4 tr_read_d(const char* p) {
+__device__ __forceinline__ op16x4 tr_read_d(const char* p) {
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-    return __builtin_bit_cast(bf16x4, v);
+    return __builtin_bit_cast(op16x4, v);
 }
-__device__ __forceinline__ bf16x8 cat4_d(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-__device__ __forceinline__ bf16x8 pack8_d(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
-    uint4 u = make_uint4(pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(b0, b1), pack_bf16(b2, b3));
-    return __builtin_bit_cast(bf16x8, u);
+__device__ __forceinline__ op16x8 cat4_d(op16x4 a, op16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ op16x8 pack8_d(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+    uint4 u = make_uint4(pack_op16(a0, a1), pack_op16(a2, a3), pack_op16(b0, b1), pack_op16(b2, b3));
+    return __builtin_bit_cast(op16x8, u);
 }
 // 8 packed bf16 + 8 packed bf16 -> 8 packed bf16 (fp32 add, RNE)
 __device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b) {
     u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
-        const float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
-        r[i] = pack_bf16(lo, hi);
+        const float lo = op16_lo(a[i]) + op16_lo(b[i]);
+        const float hi = op16_hi(a[i]) + op16_hi(b[i]);
+        r[i] = pack_op16(lo, hi);
     }
     return r;
 }
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__
                 const uint4 u = *reinterpret_cast<const uint4*>(W + (16 * h + 4 * j4 + jj) * 256 + c0);
                 const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { w[jj][2 * k] = __uint_as_float(uu[k] << 16); w[jj][2 * k + 1] = __uint_as_float(uu[k] & 0xffff0000u); }
+                for (int k = 0; k < 4; ++k) { w[jj][2 * k] = op16_lo(uu[k]); w[jj][2 * k + 1] = op16_hi(uu[k]); }
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             *reinterpret_cast<uint4*>(out + ((int64_t)p * 64 + 8 * h + t) * 256 + c0) =
-                make_uint4(pack_bf16(acc[t][0] * scale, acc[t][1] * scale), pack_bf16(acc[t][2] * scale, acc[t][3] * scale),
-                           pack_bf16(acc[t][4] * scale, acc[t][5] * scale), pack_bf16(acc[t][6] * scale, acc[t][7] * scale));
+                make_uint4(pack_op16(acc[t][0] * scale, acc[t][1] * scale), pack_op16(acc[t][2] * scale, acc[t][3] * scale),
+                           pack_op16(acc[t][4] * scale, acc[t][5] * scale), pack_op16(acc[t][6] * scale, acc[t][7] * scale));
     } else {
         for (int h = 0; h < 8; ++h) {
             float w[16];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__
                 const uint4 w0 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h), w1 = *reinterpret_cast<const uint4*>(W + d * 128 + 16 * h + 8);
                 const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { w[2 * j] = __uint_as_float(ww[j] << 16); w[2 * j + 1] = __uint_as_float(ww[j] & 0xffff0000u); }
+                for (int j = 0; j < 8; ++j) { w[2 * j] = op16_lo(ww[j]); w[2 * j + 1] = op16_hi(ww[j]); }
             }
             float r[8];
 #pragma unroll
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void dec_fold_kernel(const float* __restrict__
             }
             // Vt^T: rows = channel d, 64 folded columns -> the 8 tokens of head h are 16 contiguous bytes of row d
             *reinterpret_cast<uint4*>(out + ((int64_t)p * 256 + d) * 64 + 8 * h) =
-                make_uint4(pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]), pack_bf16(r[4], r[5]), pack_bf16(r[6], r[7]));
+                make_uint4(pack_op16(r[0], r[1]), pack_op16(r[2], r[3]), pack_op16(r[4], r[5]), pack_op16(r[6], r[7]));
         }
     }
     if (cb && d < 64) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
     // instruction of a wave reads one contiguous KB.  This wave: channel tiles 2 wave, 2 wave + 1 of the block's four row tiles.
     const float* Ep = BUILD ? embb + (int64_t)((p + x_off) / x_div) * x_bs + ((int64_t)(key0 / 16) * 16 + 2 * wave) * 256 + lane * 4 : nullptr;
     const bf16_t* Hp = BUILD ? h2 + ((int64_t)p * 4096 + key0 + fi) * 16 + 8 * (fg & 1) : nullptr;
-    bf16x8 w3f[2];
+    op16x8 w3f[2];
     if (BUILD) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -231,20 +231,20 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
                      "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]) :: "memory");
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const bf16x8 hf = __builtin_bit_cast(bf16x8, fg < 2 ? hb[tt] : (u32x4){0u, 0u, 0u, 0u});
+            const op16x8 hf = __builtin_bit_cast(op16x8, fg < 2 ? hb[tt] : (u32x4){0u, 0u, 0u, 0u});
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ct], hf, eb[ct][tt], 0, 0, 0);     // a[r] = X0[key 16 tt + fi][channel 32 wave + 16 ct + 4 fg + r]
-                lds_write_b64(sx + (16 * tt + fi) * ROW_B + (((4 * wave + 2 * ct + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8, pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+                const f32x4 a = MFMA_16x16x32(w3f[ct], hf, eb[ct][tt], 0, 0, 0);     // a[r] = X0[key 16 tt + fi][channel 32 wave + 16 ct + 4 fg + r]
+                lds_write_b64(sx + (16 * tt + fi) * ROW_B + (((4 * wave + 2 * ct + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8, pack_op16(a[0], a[1]), pack_op16(a[2], a[3]));
             }
         }
     };
 
-    bf16x8 qf[8], pq;
+    op16x8 qf[8], pq;
     {
         const bf16_t* qrow = Qt + ((int64_t)p * 64 + qt * 16 + fi) * DC;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
         // block-diagonal projected query: row fi = token (fi & 7) of head 2 qt + (fi >> 3); k = 8 fg .. 8 fg + 7 of [head A 16 | head B 16]
         const int hsel = fg >> 1;
         const float* qp = tq + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qt + hsel) + 8 * (fg & 1);
@@ -312,12 +312,12 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
         f32x4 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            const bf16x8 kp = *reinterpret_cast<const bf16x8*>(ps + (kt * 16 + fi) * T2I_PEK_ROWB + (((4 * qt + fg) ^ fi) << 4));
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kp, pq, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const op16x8 kp = *reinterpret_cast<const op16x8*>(ps + (kt * 16 + fi) * T2I_PEK_ROWB + (((4 * qt + fg) ^ fi) << 4));
+            s[kt] = MFMA_16x16x32(kp, pq, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kx = *reinterpret_cast<const bf16x8*>(xs + kt * 16 * ROW_B + koff[ks]);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kx, qf[ks], s[kt], 0, 0, 0);
+                const op16x8 kx = *reinterpret_cast<const op16x8*>(xs + kt * 16 * ROW_B + koff[ks]);
+                s[kt] = MFMA_16x16x32(kx, qf[ks], s[kt], 0, 0, 0);
             }
         }
         T2I_STAMP(1);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
             }
         sum = xor32_sum(xor16_sum(sum));
         l += sum;
-        const bf16x8 pf = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
+        const op16x8 pf = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
         T2I_STAMP(2);
         // V^T fragments through inline asm, four output tiles per wait: a compiler-visible ds_read_b64_tr_b16 is ordered behind the
         // direct-to-LDS loads of the NEXT key block with s_waitcnt vmcnt(0) (the prefetch then ended between the softmax and
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bf16x8 vf = cat4_d(__builtin_bit_cast(bf16x4, lo[j]), __builtin_bit_cast(bf16x4, hi[j]));
-                    o[d4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d4 + j], 0, 0, 0);
+                    const op16x8 vf = cat4_d(__builtin_bit_cast(op16x4, lo[j]), __builtin_bit_cast(op16x4, hi[j]));
+                    o[d4 + j] = MFMA_16x16x32(vf, pf, o[d4 + j], 0, 0, 0);
                 }
             }
         }
@@ -431,17 +431,17 @@ __global__ __launch_bounds__(64 * NW) void dec_t2i_kernel(const bf16_t* __restri
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const float4 z0 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg), z1 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg + 4);
-                const bf16x8 zf = pack8_d(z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w);
-                const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + fi) * DC + 32 * ks + 8 * fg));
-                const bf16x8 w1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + 16 + fi) * DC + 32 * ks + 8 * fg));
-                r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, zf, r0, 0, 0, 0);
-                r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, zf, r1, 0, 0, 0);
+                const op16x8 zf = pack8_d(z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w);
+                const op16x8 w0 = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + fi) * DC + 32 * ks + 8 * fg));
+                const op16x8 w1 = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + 16 + fi) * DC + 32 * ks + 8 * fg));
+                r0 = MFMA_16x16x32(w0, zf, r0, 0, 0, 0);
+                r1 = MFMA_16x16x32(w1, zf, r1, 0, 0, 0);
             }
             const int hsel = fi >> 3, hh = 2 * qt + hsel, t = fi & 7;      // lane: row q = fi -> head hh, token t; outputs 16 hh + 4 fg + r
             const float4 b4 = *reinterpret_cast<const float4*>(bv + 16 * hh + 4 * fg);
             const f32x4 r = hsel ? r1 : r0;
             *reinterpret_cast<uint2*>(out + (int64_t)p * 1024 + t * 128 + 16 * hh + 4 * fg) =
-                make_uint2(pack_bf16(r[0] + b4.x, r[1] + b4.y), pack_bf16(r[2] + b4.z, r[3] + b4.w));
+                make_uint2(pack_op16(r[0] + b4.x, r[1] + b4.y), pack_op16(r[2] + b4.z, r[3] + b4.w));
         }
     }
 }
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256) void dec_t2i_finish_kernel(const float* __rest
         const int t = tid >> 4, oo = 16 * h + (tid & 15);
         const bf16_t* w = Wv + oo * 256;
         float acc = bv[oo];
-        for (int d = 0; d < DC; ++d) acc += bf2f(w[d]) * z[t][d];
-        out[(int64_t)p * 1024 + t * 128 + oo] = f2bf(acc);
+        for (int d = 0; d < DC; ++d) acc += op2f(w[d]) * z[t][d];
+        out[(int64_t)p * 1024 + t * 128 + oo] = f2op(acc);
     }
 }
 
@@ -489,8 +489,6 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
     if (P <= 0) return nullptr;
     if (split != 1 && split != 2 && split != 4 && split != 8) return "dec_t2i: split must be 1, 2, 4 or 8";
     if (xm.div <= 0) return "dec_t2i: XMap.div must be positive";
-    extern unsigned long long* g_saber_stamp_buf;
-    extern int g_saber_debug_flags;
     const float* nf = nullptr; const bf16_t* nb = nullptr;
     if (build) {
         if (!build->embb || !build->h2 || !build->w3 || build->map.div <= 0) return "dec_t2i: incomplete XBuild";
@@ -575,8 +573,8 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
         const int ch = tid;        // 256 threads: one W3 row each
         const float* wr = w3 + ch * 16;
         const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4), c = *reinterpret_cast<const float4*>(wr + 8), d = *reinterpret_cast<const float4*>(wr + 12);
-        *reinterpret_cast<uint4*>(smem + CF::LDS + ch * 32) = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
-        *reinterpret_cast<uint4*>(smem + CF::LDS + ch * 32 + 16) = make_uint4(pack_bf16(c.x, c.y), pack_bf16(c.z, c.w), pack_bf16(d.x, d.y), pack_bf16(d.z, d.w));
+        *reinterpret_cast<uint4*>(smem + CF::LDS + ch * 32) = make_uint4(pack_op16(a.x, a.y), pack_op16(a.z, a.w), pack_op16(b.x, b.y), pack_op16(b.z, b.w));
+        *reinterpret_cast<uint4*>(smem + CF::LDS + ch * 32 + 16) = make_uint4(pack_op16(c.x, c.y), pack_op16(c.z, c.w), pack_op16(d.x, d.y), pack_op16(d.z, d.w));
         __syncthreads();
     }
     f32x4 eb[4];
@@ -592,16 +590,16 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
     bf16_t* Xo = Xout + ((int64_t)p * 4096 + row0) * DC;
 
     // folded operands of this prompt, straight into registers
-    bf16x8 kf[8], vf[4][2];
+    op16x8 kf[8], vf[4][2];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
-        kf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Kt + ((int64_t)p * 64 + 16 * qr + fi) * DC + 32 * ks + 8 * fg));
+        kf[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(Kt + ((int64_t)p * 64 + 16 * qr + fi) * DC + 32 * ks + 8 * fg));
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            vf[t][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(VtT + ((int64_t)p * 256 + 64 * qr + 16 * t + fi) * 64 + 32 * ks + 8 * fg));
-    bf16x8 kq;   // block-diagonal projected keys: row fi = token (fi & 7) of head 2 qr + (fi >> 3); k = 8 fg .. + 7 of [head A 16 | head B 16]
+            vf[t][ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(VtT + ((int64_t)p * 256 + 64 * qr + 16 * t + fi) * 64 + 32 * ks + 8 * fg));
+    op16x8 kq;   // block-diagonal projected keys: row fi = token (fi & 7) of head 2 qr + (fi >> 3); k = 8 fg .. + 7 of [head A 16 | head B 16]
     {
         const int hsel = fg >> 1;
         const float* kp = tk + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qr + hsel) + 8 * (fg & 1);
@@ -673,7 +671,7 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
         for (int tt = 0; tt < 4; ++tt) {
             const f32x2 v0 = ((y2[2 * tt] - mean2) * rstd2) * g2[2 * tt] + be2[2 * tt];
             const f32x2 v1 = ((y2[2 * tt + 1] - mean2) * rstd2) * g2[2 * tt + 1] + be2[2 * tt + 1];
-            lds_write_b64(tb + (((2 * tt + (fg >> 1)) ^ (fi & 7)) << 4), pack_bf16(v0.x, v0.y), pack_bf16(v1.x, v1.y));
+            lds_write_b64(tb + (((2 * tt + (fg >> 1)) ^ (fi & 7)) << 4), pack_op16(v0.x, v0.y), pack_op16(v1.x, v1.y));
         }
         u32x4 o0, o1;
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
@@ -690,14 +688,14 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
         // `younger` = this wave's vector-memory operations issued after the tile's loads that may stay in flight
 #define I2T_WAITR(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(eb[0]), "+v"(eb[1]), "+v"(eb[2]), "+v"(eb[3]), "+v"(hb) :: "memory")
         if (younger >= 3) I2T_WAITR(3); else if (younger == 2) I2T_WAITR(2); else if (younger == 1) I2T_WAITR(1); else I2T_WAITR(0);
-        const bf16x8 hf = __builtin_bit_cast(bf16x8, fg < 2 ? hb : (u32x4){0u, 0u, 0u, 0u});
-        bf16x8 w3f[4];
+        const op16x8 hf = __builtin_bit_cast(op16x8, fg < 2 ? hb : (u32x4){0u, 0u, 0u, 0u});
+        op16x8 w3f[4];
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(w3f[0]), "=&v"(w3f[1]), "=&v"(w3f[2]), "=&v"(w3f[3]) : "v"(w3_a) : "memory");
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ct], hf, eb[ct], 0, 0, 0);
-            lds_write_b64(sx + roff[ct], pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+            const f32x4 a = MFMA_16x16x32(w3f[ct], hf, eb[ct], 0, 0, 0);
+            lds_write_b64(sx + roff[ct], pack_op16(a[0], a[1]), pack_op16(a[2], a[3]));
         }
     };
     issue(0); issue(1); issue(2);
@@ -716,15 +714,15 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
         // GEMM1 (swapped): S^T[c][m] = Kt[c].x[m] + Kt[c].pe[m] + cb[c] for this wave's 16 columns c
         f32x4 s = (f32x4){cb4.x, cb4.y, cb4.z, cb4.w}, s1;
         {
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(ps + poff);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq, pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const op16x8 pf = *reinterpret_cast<const op16x8*>(ps + poff);
+            s1 = MFMA_16x16x32(kq, pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < 8; ks += 2) {       // two accumulation chains
-            const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(xs + xoff[ks]);
-            const bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(xs + xoff[ks + 1]);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], xf0, s, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks + 1], xf1, s1, 0, 0, 0);
+            const op16x8 xf0 = *reinterpret_cast<const op16x8*>(xs + xoff[ks]);
+            const op16x8 xf1 = *reinterpret_cast<const op16x8*>(xs + xoff[ks + 1]);
+            s = MFMA_16x16x32(kf[ks], xf0, s, 0, 0, 0);
+            s1 = MFMA_16x16x32(kf[ks + 1], xf1, s1, 0, 0, 0);
         }
         s += s1;
         // softmax over the 8 tokens of a head: this lane's 4 values + lane ^ 16
@@ -737,7 +735,7 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
             sum = xor16_sum(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);
             // LDS stores go through inline asm: a compiler-visible ds_write makes it wait vmcnt(0) for the direct-to-LDS loads in flight
-            lds_write_b64(prow_a + (t & 1) * I2T_PBUF_B + (16 * qr + 4 * fg) * 2, pack_bf16(s[0] * inv, s[1] * inv), pack_bf16(s[2] * inv, s[3] * inv));
+            lds_write_b64(prow_a + (t & 1) * I2T_PBUF_B + (16 * qr + 4 * fg) * 2, pack_op16(s[0] * inv, s[1] * inv), pack_op16(s[2] * inv, s[3] * inv));
         }
         // tile t+1 (issued two iterations ago) must have landed before the barrier makes it visible to everyone; the younger
         // loads and the bf16 stores stay in flight.  Queue behind L(t+1): [S(t-3)] L(t+2) [S(t-2)]; a load group is 3 ops, a store group 2.
@@ -768,13 +766,13 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
         // GEMM2: Y^T[d][m] for this wave's 64 channels
         f32x4 y[4];
         {
-            bf16x8 p0, p1;
+            op16x8 p0, p1;
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(p0), "=&v"(p1) : "v"(prow_a + (t & 1) * I2T_PBUF_B + 16 * fg) : "memory");
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                y[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt][0], p0, y[tt], 0, 0, 0);
-                y[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt][1], p1, y[tt], 0, 0, 0);
+                y[tt] = MFMA_16x16x32(vf[tt][0], p0, y[tt], 0, 0, 0);
+                y[tt] = MFMA_16x16x32(vf[tt][1], p1, y[tt], 0, 0, 0);
             }
         }
         // residual + bias, partial LayerNorm statistics over this wave's 64 channels of row m.  The residual reads of the
@@ -792,8 +790,8 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const uint32_t xlo = (uint32_t)xrs[tt], xhi = (uint32_t)(xrs[tt] >> 32);
-            const f32x2 r0 = (f32x2){__uint_as_float(xlo << 16), __uint_as_float(xlo & 0xffff0000u)};
-            const f32x2 r1 = (f32x2){__uint_as_float(xhi << 16), __uint_as_float(xhi & 0xffff0000u)};
+            const f32x2 r0 = (f32x2){op16_lo(xlo), op16_hi(xlo)};
+            const f32x2 r1 = (f32x2){op16_lo(xhi), op16_hi(xhi)};
             y2[2 * tt] = ((f32x2){y[tt][0], y[tt][1]} + bo2[2 * tt]) + r0;
             y2[2 * tt + 1] = ((f32x2){y[tt][2], y[tt][3]} + bo2[2 * tt + 1]) + r1;
             sum2 += y2[2 * tt]; sum2 += y2[2 * tt + 1];
@@ -827,10 +825,8 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
     }
     int nsplit = 1;
     while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's tiles over several blocks
-    extern int g_saber_debug_flags;
     if (g_saber_debug_flags >> 20) nsplit = g_saber_debug_flags >> 20;      // (bits 8-19 belong to the GEMM kernels)
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
-    extern unsigned long long* g_saber_stamp_buf;
     if (g_saber_debug_flags & 1)
         hipLaunchKernelGGL((dec_i2t_kernel<2, false, false>), dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
     else
@@ -930,11 +926,11 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
 
     // B-operand fragments of the wave's 16 tokens: lane (fi, fg) holds X[tok][32 ks + 8 fg .. +7], ks = 0..7
     const int64_t xrow = ((int64_t)tile * UP_TOK + tl) * DC + 8 * fg;
-    bf16x8 xf[8];
-    auto xload = [&](int p, bf16x8 (&dst)[8]) {
+    op16x8 xf[8];
+    auto xload = [&](int p, op16x8 (&dst)[8]) {
         const bf16_t* Xt = X + (int64_t)p * 4096 * DC + xrow;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) dst[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Xt + 32 * ks));
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const u32x4*>(Xt + 32 * ks));
     };
     // output pixels of this lane: token (gy, gx) on the 64x64 grid, ConvT1 position (dy1, dx1); mask k = fg
     const int gy = ty0 + ty, gx = tx0 + tx;
@@ -976,14 +972,14 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         // phase B leaves its GELU outputs in, so they are packed into the B operand as they stand.  Every row 4 fg + r of the result is
         // mask fg of token fi: the lane reads its own mask from register 0, no lane movement.  hyper enters as a bf16 hi + lo pair (two
         // MFMAs, exact to 2^-17); u2 is rounded to bf16 (2^-9 per element, averaged over the 32-term sum).
-        bf16x8 hy_hi, hy_lo;
+        op16x8 hy_hi, hy_lo;
         {
             const float* hp = hyper + (int64_t)p * 128 + (fi >> 2) * 32 + 4 * fg;
             const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 16);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             float l[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) l[j] = v[j] - bf2f(f2bf(v[j]));
+            for (int j = 0; j < 8; ++j) l[j] = v[j] - op2f(f2op(v[j]));
             hy_hi = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
             hy_lo = pack8_d(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]);
         }
@@ -1002,14 +998,14 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1s + kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg));
-                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[ks], acc[ni], 0, 0, 0);
+                const op16x8 wf = *reinterpret_cast<const op16x8*>(w1s + kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg));
+                acc[ni] = MFMA_16x16x32(wf, xf[ks], acc[ni], 0, 0, 0);
             }
         }
         // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
         if (pn < P) xload(pn, xf);
         // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
-        bf16x8 uf[2];
+        op16x8 uf[2];
         {
             float v[4][4], sum = 0.f;
 #pragma unroll
@@ -1049,8 +1045,8 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int nl = 0; nl < 4; ++nl) {
-                    const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
-                    c2[nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, uf[ks], c2[nl], 0, 0, 0);
+                    const op16x8 w2f = *reinterpret_cast<const op16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
+                    c2[nl] = MFMA_16x16x32(w2f, uf[ks], c2[nl], 0, 0, 0);
                 }
             float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
 #pragma unroll
@@ -1058,9 +1054,9 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
 #if UP_MFMA_HYPER
                 const f32x2 ua0 = gelu_erf2((f32x2){c2[2 * pp][0], c2[2 * pp][1]}), ub0 = gelu_erf2((f32x2){c2[2 * pp][2], c2[2 * pp][3]});
                 const f32x2 ua1 = gelu_erf2((f32x2){c2[2 * pp + 1][0], c2[2 * pp + 1][1]}), ub1 = gelu_erf2((f32x2){c2[2 * pp + 1][2], c2[2 * pp + 1][3]});
-                const bf16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
-                f32x4 dm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hy_hi, uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hy_lo, uop, dm, 0, 0, 0);
+                const op16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
+                f32x4 dm = MFMA_16x16x32(hy_hi, uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dm = MFMA_16x16x32(hy_lo, uop, dm, 0, 0, 0);
                 if (pp == 0) px2.x = dm[0]; else px2.y = dm[0];
                 continue;
 #else

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
         // this kernel VALU-bound at half the HBM write rate).  Wave w owns tokens 16 w .. 16 w + 15; W3 (bf16) and image_embed + b3
         // stay in registers across the prompts; the tile leaves through LDS as full 512-B token rows (dwordx4).
         const int lane = tid & 63, wv = tid >> 6, fi = lane & 15, fg = lane >> 4;
-        bf16x8 w3f[16];
+        op16x8 w3f[16];
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
                 const float4 a = *reinterpret_cast<const float4*>(w.w3 + (16 * nt + fi) * 16 + 8 * fg), b = *reinterpret_cast<const float4*>(w.w3 + (16 * nt + fi) * 16 + 8 * fg + 4);
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
             }
-            const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-            w3f[nt] = __builtin_bit_cast(bf16x8, u);
+            const uint4 u = make_uint4(pack_op16(v[0], v[1]), pack_op16(v[2], v[3]), pack_op16(v[4], v[5]), pack_op16(v[6], v[7]));
+            w3f[nt] = __builtin_bit_cast(op16x8, u);
         }
         const int tok = tok0 + 16 * wv + fi;
         float4 eb[16];
@@ -192,13 +192,13 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
                 const float4 a = *reinterpret_cast<const float4*>(&h2s[pi][16 * wv + fi][8 * fg]), b = *reinterpret_cast<const float4*>(&h2s[pi][16 * wv + fi][8 * fg + 4]);
                 hv[0] = a.x; hv[1] = a.y; hv[2] = a.z; hv[3] = a.w; hv[4] = b.x; hv[5] = b.y; hv[6] = b.z; hv[7] = b.w;
             }
-            const uint4 hu = make_uint4(pack_bf16(hv[0], hv[1]), pack_bf16(hv[2], hv[3]), pack_bf16(hv[4], hv[5]), pack_bf16(hv[6], hv[7]));
-            const bf16x8 hf = __builtin_bit_cast(bf16x8, hu);
+            const uint4 hu = make_uint4(pack_op16(hv[0], hv[1]), pack_op16(hv[2], hv[3]), pack_op16(hv[4], hv[5]), pack_op16(hv[6], hv[7]));
+            const op16x8 hf = __builtin_bit_cast(op16x8, hu);
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) {
                 const f32x4 z = {eb[nt].x, eb[nt].y, eb[nt].z, eb[nt].w};
-                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[nt], hf, z, 0, 0, 0);    // a[r] = src[token fi][channel 16 nt + 4 fg + r]
-                *reinterpret_cast<uint2*>(my + fi * 512 + (((2 * nt + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+                const f32x4 a = MFMA_16x16x32(w3f[nt], hf, z, 0, 0, 0);    // a[r] = src[token fi][channel 16 nt + 4 fg + r]
+                *reinterpret_cast<uint2*>(my + fi * 512 + (((2 * nt + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8) = make_uint2(pack_op16(a[0], a[1]), pack_op16(a[2], a[3]));
             }
             __builtin_amdgcn_wave_barrier();
             bf16_t* dst = src_bf + ((int64_t)p * 4096 + tok0 + 16 * wv) * DEC_C;
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void mask_embed_src_kernel(const float* __rest
                 }
                 const int64_t off = ((int64_t)p * 4096 + tok) * DEC_C + c0;
                 if (src_f) *reinterpret_cast<float4*>(src_f + off) = make_float4(a[0], a[1], a[2], a[3]);
-                *reinterpret_cast<uint2*>(src_bf + off) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
-                if (srcpos_bf) *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_bf16(a[0] + pp.x, a[1] + pp.y), pack_bf16(a[2] + pp.z, a[3] + pp.w));
+                *reinterpret_cast<uint2*>(src_bf + off) = make_uint2(pack_op16(a[0], a[1]), pack_op16(a[2], a[3]));
+                if (srcpos_bf) *reinterpret_cast<uint2*>(srcpos_bf + off) = make_uint2(pack_op16(a[0] + pp.x, a[1] + pp.y), pack_op16(a[2] + pp.z, a[3] + pp.w));
             }
         }
     }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void mask_hidden_kernel(const float* __restric
     const float o1 = gelu_erf((h2[1] - mu) * rstd * w.g2[4 * q + 1] + w.be2[4 * q + 1]);
     const float o2 = gelu_erf((h2[2] - mu) * rstd * w.g2[4 * q + 2] + w.be2[4 * q + 2]);
     const float o3 = gelu_erf((h2[3] - mu) * rstd * w.g2[4 * q + 3] + w.be2[4 * q + 3]);
-    *reinterpret_cast<uint2*>(h2out + ((int64_t)p * 4096 + tok0 + tl) * 16 + 4 * q) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+    *reinterpret_cast<uint2*>(h2out + ((int64_t)p * 4096 + tok0 + tl) * 16 + 4 * q) = make_uint2(pack_op16(o0, o1), pack_op16(o2, o3));
 }
 const char* launch_mask_hidden(const float* mask_in, int P, MaskEmbedWeights w, bf16_t* h2, float clamp_abs, hipStream_t s, int raw4_q0) {
     if (P <= 0) return nullptr;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void dec_attn_fewkeys_kernel(const float* __re
         }
         bf16_t* op = out + b * o_bs + (int64_t)qi * C + h * HDIM;
 #pragma unroll
-        for (int d = 0; d < HDIM; d += 4) *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf16(o[d], o[d + 1]), pack_bf16(o[d + 2], o[d + 3]));
+        for (int d = 0; d < HDIM; d += 4) *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_op16(o[d], o[d + 1]), pack_op16(o[d + 2], o[d + 3]));
     }
 }
 
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void dec_attn_fewq_kernel(const float* __restr
             L += red[w][t][HDIM + 1] * f;
             A += red[w][t][d] * f;
         }
-        out[b * o_bs + (int64_t)t * C + h * HDIM + d] = f2bf(A / L);
+        out[b * o_bs + (int64_t)t * C + h * HDIM + d] = f2op(A / L);
     }
 }
 
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void mask_dot_kernel(const bf16_t* __restrict_
         const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(wds[j] << 16), hi = __uint_as_float(wds[j] & 0xffff0000u);
+            const float lo = op16_lo(wds[j]), hi = op16_hi(wds[j]);
             const int c = q * 8 + j * 2;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc[kk] += hs[kk][c] * lo + hs[kk][c + 1] * hi;
@@ -945,7 +945,6 @@ __global__ void mask_stats_init_kernel(MaskStats* stats, int n) {
     if (i < n) { MaskStats s; s.area = 0; s.inter = 0; s.uni = 0; s.x0 = 1 << 30; s.y0 = 1 << 30; s.x1 = -1; s.y1 = -1; s.pad = 0; stats[i] = s; }
 }
 
-extern int g_saber_debug_flags;
 const char* launch_mask_post(const float* lowres, const int* idx, int n, int crop_x0, int crop_y0, int crop_w, int crop_h, int H,
                              int W, float thr, float offset, uint32_t* bits, MaskStats* stats, hipStream_t s, const uint8_t* pass) {
     if (n <= 0) return nullptr;
@@ -1147,7 +1146,6 @@ __global__ __launch_bounds__(256) void pair_inter_tiled_kernel(const uint32_t* _
 const char* launch_pair_intersections(const uint32_t* bits, int n, int64_t words, int* inter, hipStream_t s) {
     if (n <= 0) return nullptr;
     if ((uintptr_t)bits & 15) return "pair_intersections: masks must be 16-byte aligned";
-    extern int g_saber_debug_flags;
     if ((words & 3) == 0 && n > PT && !(g_saber_debug_flags & 65536)) {
         const int nt = (n + PT - 1) / PT;
         hipLaunchKernelGGL(pair_inter_tiled_kernel, dim3(nt, nt), dim3(256), 0, s, bits, n, words, inter);

@@ -33,14 +33,14 @@ __device__ __forceinline__ void wgemm(const TokCtx& c, const char* A, int K, con
     for (int i = 0; i < NTW; ++i) wr[i] = W + (int64_t)min(n0 + 16 * (c.wave * NTW + i) + c.fi, nrows - 1) * ldw + 8 * c.fg;
 #pragma unroll 8
     for (int ks = 0; ks < K / 32; ++ks) {
-        bf16x8 b[MT];
+        op16x8 b[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) b[m] = *reinterpret_cast<const bf16x8*>(A + (16 * m + c.fi) * TK_AS + (32 * ks + 8 * c.fg) * 2);
+        for (int m = 0; m < MT; ++m) b[m] = *reinterpret_cast<const op16x8*>(A + (16 * m + c.fi) * TK_AS + (32 * ks + 8 * c.fg) * 2);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wr[i] + 32 * ks));
+            const op16x8 a = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(wr[i] + 32 * ks));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[m], acc[i][m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[i][m] = MFMA_16x16x32(a, b[m], acc[i][m], 0, 0, 0);
         }
     }
 }
@@ -54,7 +54,7 @@ __device__ __forceinline__ void to_operand(const TokCtx& c, char* B, const float
             const float4 p = *reinterpret_cast<const float4*>(pe_rows + r * 256 + c4);
             v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         }
-        *reinterpret_cast<uint2*>(B + r * TK_AS + c4 * 2) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+        *reinterpret_cast<uint2*>(B + r * TK_AS + c4 * 2) = make_uint2(pack_op16(v.x, v.y), pack_op16(v.z, v.w));
     }
 }
 // Q[row] = LN(Q[row]) for the workgroup's 32 rows (wave w: rows 4 w .. 4 w + 3; a lane holds 4 channels)
@@ -100,12 +100,12 @@ __device__ __forceinline__ void proj_to_f(const TokCtx& c, const char* A, int K,
                 make_float4(acc[i][m][0] + b.x, acc[i][m][1] + b.y, acc[i][m][2] + b.z, acc[i][m][3] + b.w);
     }
 }
-__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
-    const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-    return __builtin_bit_cast(bf16x8, u);
+__device__ __forceinline__ op16x8 pack8(const float (&v)[8]) {
+    const uint4 u = make_uint4(pack_op16(v[0], v[1]), pack_op16(v[2], v[3]), pack_op16(v[4], v[5]), pack_op16(v[6], v[7]));
+    return __builtin_bit_cast(op16x8, u);
 }
 // block-diagonal bf16 hi / lo operand of a fold: row (hsel, t) = fi, k = 8 fg .. + 7 of [head 2 hp | head 2 hp + 1]
-__device__ __forceinline__ void fold_operand(const TokCtx& c, const char* F, int pi, int hp, float scale, bf16x8* hi, bf16x8* lo) {
+__device__ __forceinline__ void fold_operand(const TokCtx& c, const char* F, int pi, int hp, float scale, op16x8* hi, op16x8* lo) {
     const int hsel = c.fi >> 3, t = c.fi & 7, hk = c.fg >> 1;
     const float* a = reinterpret_cast<const float*>(F) + (8 * pi + t) * TK_FS + 16 * (2 * hp + hsel) + 8 * (c.fg & 1);
     const float z = hk == hsel ? scale : 0.f;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void fold_operand(const TokCtx& c, const char* F, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         v[j] = a[j] * z;
-        l[j] = v[j] - bf2f(f2bf(v[j]));
+        l[j] = v[j] - op2f(f2op(v[j]));
     }
     *hi = pack8(v); *lo = pack8(l);
 }
@@ -121,52 +121,52 @@ __device__ __forceinline__ void fold_operand(const TokCtx& c, const char* F, int
 // (the wave's 8 weight fragments - 4 head pairs x 2 channel tiles - are loaded once, ahead of the loop over the prompts: fetched inside it
 // they cost one L2 round trip per (prompt, head pair), 16 in a row)
 __device__ __forceinline__ void fold_rows(const TokCtx& c, const char* F, const bf16_t* WT, float scale, bf16_t* out, int p0, int P) {
-    bf16x8 w[4][2];
+    op16x8 w[4][2];
 #pragma unroll
     for (int hp = 0; hp < 4; ++hp)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            w[hp][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(WT + (16 * (c.wave * 2 + i) + c.fi) * 128 + 32 * hp + 8 * c.fg));
+            w[hp][i] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(WT + (16 * (c.wave * 2 + i) + c.fi) * 128 + 32 * hp + 8 * c.fg));
     for (int pi = 0; pi < TK_G; ++pi) {
         if (p0 + pi >= P) break;
 #pragma unroll
         for (int hp = 0; hp < 4; ++hp) {
-            bf16x8 hi, lo;
+            op16x8 hi, lo;
             fold_operand(c, F, pi, hp, scale, &hi, &lo);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int dt = c.wave * 2 + i;
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[hp][i], hi, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[hp][i], lo, acc, 0, 0, 0);
+                f32x4 acc = MFMA_16x16x32(w[hp][i], hi, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc = MFMA_16x16x32(w[hp][i], lo, acc, 0, 0, 0);
                 // D[d = 16 dt + 4 fg + r][(hsel, t) = fi]
                 bf16_t* o = out + ((int64_t)(p0 + pi) * 64 + 8 * (2 * hp + (c.fi >> 3)) + (c.fi & 7)) * 256 + 16 * dt + 4 * c.fg;
-                *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]));
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_op16(acc[0], acc[1]), pack_op16(acc[2], acc[3]));
             }
         }
     }
 }
 // out[p][d][8 h + t] = sum_j a[t][16 h + j] W[d][16 h + j], W bf16 [256][128]  (dec_fold_kernel mode 1: transposed output)
 __device__ __forceinline__ void fold_cols(const TokCtx& c, const char* F, const bf16_t* W, int ldw, bf16_t* out, int p0, int P) {
-    bf16x8 w[4][2];
+    op16x8 w[4][2];
 #pragma unroll
     for (int hp = 0; hp < 4; ++hp)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            w[hp][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(W + (int64_t)(16 * (c.wave * 2 + i) + c.fi) * ldw + 32 * hp + 8 * c.fg));
+            w[hp][i] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(W + (int64_t)(16 * (c.wave * 2 + i) + c.fi) * ldw + 32 * hp + 8 * c.fg));
     for (int pi = 0; pi < TK_G; ++pi) {
         if (p0 + pi >= P) break;
 #pragma unroll
         for (int hp = 0; hp < 4; ++hp) {
-            bf16x8 hi, lo;
+            op16x8 hi, lo;
             fold_operand(c, F, pi, hp, 1.0f, &hi, &lo);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int dt = c.wave * 2 + i;
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, w[hp][i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, w[hp][i], acc, 0, 0, 0);
+                f32x4 acc = MFMA_16x16x32(hi, w[hp][i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc = MFMA_16x16x32(lo, w[hp][i], acc, 0, 0, 0);
                 // D[(hsel, t) = 4 fg + r][d = 16 dt + fi]  ->  columns 16 hp + 4 fg + r of row d
                 bf16_t* o = out + ((int64_t)(p0 + pi) * 256 + 16 * dt + c.fi) * 64 + 16 * hp + 4 * c.fg;
-                *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]));
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_op16(acc[0], acc[1]), pack_op16(acc[2], acc[3]));
             }
         }
     }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
                     *reinterpret_cast<uint2*>(c.H + (16 * m + c.fi) * TK_AS + n * 2) =
-                        make_uint2(pack_bf16(fmaxf(acc[i][m][0] + b.x, 0.f), fmaxf(acc[i][m][1] + b.y, 0.f)), pack_bf16(fmaxf(acc[i][m][2] + b.z, 0.f), fmaxf(acc[i][m][3] + b.w, 0.f)));
+                        make_uint2(pack_op16(fmaxf(acc[i][m][0] + b.x, 0.f), fmaxf(acc[i][m][1] + b.y, 0.f)), pack_op16(fmaxf(acc[i][m][2] + b.z, 0.f), fmaxf(acc[i][m][3] + b.w, 0.f)));
             }
             __syncthreads();
             f32x4 part[2][2];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
                 }
                 char* op = c.H + (8 * pi + qi) * TK_AS + (128 * hc + 32 * hh) * 2;
 #pragma unroll
-                for (int d = 0; d < 32; d += 4) *reinterpret_cast<uint2*>(op + d * 2) = make_uint2(pack_bf16(o[d], o[d + 1]), pack_bf16(o[d + 2], o[d + 3]));
+                for (int d = 0; d < 32; d += 4) *reinterpret_cast<uint2*>(op + d * 2) = make_uint2(pack_op16(o[d], o[d + 1]), pack_op16(o[d + 2], o[d + 3]));
             }
             __syncthreads();
         }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
                 const int r = idx >> 6, c4 = (idx & 63) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < np) v = *reinterpret_cast<const float4*>(c.Q + ((8 * r + token) * 256 + c4) * 4);
-                *reinterpret_cast<uint2*>(c.B0 + r * TK_AS + c4 * 2) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+                *reinterpret_cast<uint2*>(c.B0 + r * TK_AS + c4 * 2) = make_uint2(pack_op16(v.x, v.y), pack_op16(v.z, v.w));
             }
             __syncthreads();
             for (int l = 0; l < 2; ++l) {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
                     const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
                     const float4 b = *reinterpret_cast<const float4*>(L[l].b + b_off0 + n);
                     *reinterpret_cast<uint2*>(outb + c.fi * TK_AS + n * 2) =
-                        make_uint2(pack_bf16(fmaxf(acc[i][0][0] + b.x, 0.f), fmaxf(acc[i][0][1] + b.y, 0.f)), pack_bf16(fmaxf(acc[i][0][2] + b.z, 0.f), fmaxf(acc[i][0][3] + b.w, 0.f)));
+                        make_uint2(pack_op16(fmaxf(acc[i][0][0] + b.x, 0.f), fmaxf(acc[i][0][1] + b.y, 0.f)), pack_op16(fmaxf(acc[i][0][2] + b.z, 0.f), fmaxf(acc[i][0][3] + b.w, 0.f)));
                 }
                 __syncthreads();
             }

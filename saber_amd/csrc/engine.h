@@ -34,6 +34,7 @@ struct saber_engine {
     bool finalized = false;
     int weight_format = 0;          // SABER_WEIGHTS_*
     int precision = 0;              // SABER_PRECISION_*: the mode compute calls run in
+    bool op_f16 = false;            // 16-bit operand type of this handle's weights / workspaces (fixed at finalize): false = bf16, true = IEEE fp16
     bool keep_f32 = false;          // fp32 weight copies were requested before finalize (exact mode available)
     void* exact_ws = nullptr;       // exact.hip's workspaces (allocated on first use)
 
@@ -161,17 +162,20 @@ void prof_end(saber_engine* e, hipStream_t s);
 int eng_fail(saber_engine* e, int code, const std::string& msg);
 // Binds the calling thread to the engine's device for the duration of one C-ABI call and restores the caller's current device on
 // return (a caller whose torch current device is M must not find it switched to the engine's device N afterwards).
+// It also selects the kernels' 16-bit operand type for the call (kernels.h: the launchers dispatch on the calling thread's setting).
 struct DeviceGuard {
     int prev = -1;
+    int prev_op = 0;
     hipError_t st = hipSuccess;
-    explicit DeviceGuard(int dev) {
+    explicit DeviceGuard(int dev, bool op_f16) {
+        prev_op = g_saber_op_f16; g_saber_op_f16 = op_f16 ? 1 : 0;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) st = hipSetDevice(dev); else prev = -1;
     }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    ~DeviceGuard() { g_saber_op_f16 = prev_op; if (prev >= 0) (void)hipSetDevice(prev); }
 };
 #define ENG_DEVICE(e)                                                                                  \
-    DeviceGuard _dev_guard((e)->device);                                                               \
+    DeviceGuard _dev_guard((e)->device, (e)->op_f16);                                                               \
     if (_dev_guard.st != hipSuccess) return eng_fail((e), SABER_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.st))
 #define ENG_HIP(e, call)                                                                              \
     do {                                                                                              \

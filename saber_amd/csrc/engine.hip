@@ -97,7 +97,7 @@ static const char* hiera_spec(saber_engine* e, const TrunkSpec& t) {
 // size baked into its launches.  First sight: eager (lazy one-time setup inside launchers happens here); second: captured + launched;
 // afterwards: one hipGraphLaunch.  Anything that goes wrong while capturing marks the key bad and the sequence stays eager.
 int eng_graphed(saber_engine* e, const std::string& key, hipStream_t s, const std::function<int()>& body) {
-    if (!e->graphs_on || e->prof_on || s == nullptr || e->precision != SABER_PRECISION_BF16 || e->graph_bad.count(key)) return body();
+    if (!e->graphs_on || e->prof_on || s == nullptr || e->precision == SABER_PRECISION_EXACT || e->graph_bad.count(key)) return body();
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) {
         ENG_HIP(e, hipGraphLaunch(it->second, s));
@@ -140,10 +140,18 @@ extern "C" int saber_engine_set_weight_format(saber_engine* e, int format) {
 }
 extern "C" int saber_engine_set_precision(saber_engine* e, int precision) {
     if (!e) return SABER_ERR_INVALID;
-    if (precision != SABER_PRECISION_BF16 && precision != SABER_PRECISION_EXACT) return eng_fail(e, SABER_ERR_INVALID, "set_precision: unknown precision");
-    if (!e->finalized) { if (precision == SABER_PRECISION_EXACT) e->keep_f32 = true; }
-    else if (precision == SABER_PRECISION_EXACT && !e->keep_f32)
-        return eng_fail(e, SABER_ERR_STATE, "set_precision: the exact mode needs the fp32 weight copies; request it once before saber_engine_finalize");
+    if (precision != SABER_PRECISION_BF16 && precision != SABER_PRECISION_EXACT && precision != SABER_PRECISION_FP16) return eng_fail(e, SABER_ERR_INVALID, "set_precision: unknown precision");
+    if (!e->finalized) {
+        if (precision == SABER_PRECISION_EXACT) e->keep_f32 = true;
+        else e->op_f16 = precision == SABER_PRECISION_FP16;      // the 16-bit type the weights will be converted to
+    } else {
+        if (precision == SABER_PRECISION_EXACT && !e->keep_f32)
+            return eng_fail(e, SABER_ERR_STATE, "set_precision: the exact mode needs the fp32 weight copies; request it once before saber_engine_finalize");
+        if (precision == SABER_PRECISION_FP16 && !e->op_f16)
+            return eng_fail(e, SABER_ERR_STATE, "set_precision: this handle was finalized with bf16 weights; choose SABER_PRECISION_FP16 before saber_engine_finalize");
+        if (precision == SABER_PRECISION_BF16 && e->op_f16)
+            return eng_fail(e, SABER_ERR_STATE, "set_precision: this handle was finalized with fp16 weights; it runs in SABER_PRECISION_FP16 (or EXACT)");
+    }
     e->precision = precision;
     return SABER_OK;
 }
@@ -190,7 +198,6 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
         const char* m = gemm_init_device();
         if (!m) m = gemm_rowln_init_device();
         if (!m) m = amg_device_init();
-        if (!m) m = gemm_w1_init_device();
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();
         if (!m) m = decoder_fused_init_device();
@@ -235,6 +242,27 @@ static inline bf16_t host_f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// fp32 -> IEEE half bits, round to nearest even (subnormals included; overflow -> infinity, which the finalize range check rejects first)
+bf16_t saber_host_f2h(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (bf16_t)(sign | 0x7e00u);                     // NaN
+    if (a >= 0x477ff000u) return (bf16_t)(sign | 0x7c00u);                    // >= 65520 rounds to infinity
+    if (a < 0x33000001u) return (bf16_t)sign;                                 // <= 2^-25 rounds to zero
+    const int ex = (int)(a >> 23) - 127;
+    uint32_t man = (a & 0x7fffffu) | 0x800000u;                               // 24-bit significand
+    int shift = 13;                                                           // normal: keep 10 fraction bits
+    uint32_t hexp = (uint32_t)(ex + 15);
+    if (ex < -14) { shift = 13 + (-14 - ex); hexp = 0; }                      // subnormal half
+    const uint32_t half_ulp = 1u << (shift - 1), mask = (1u << shift) - 1u;
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & mask;
+    if (rem > half_ulp || (rem == half_ulp && (q & 1u))) ++q;
+    // q carries the implicit bit for normals (bit 10): adding it to (hexp - 1) << 10 handles the mantissa overflow into the exponent
+    const uint32_t h = hexp ? ((hexp - 1) << 10) + q : q;
+    return (bf16_t)(sign | h);
+}
+static inline bf16_t host_f2op(float f, bool f16) { return f16 ? saber_host_f2h(f) : host_f2bf(f); }
 
 struct Finalizer {
     saber_engine* e;
@@ -263,7 +291,11 @@ struct Finalizer {
     const bf16_t* up_bf16(const std::vector<float>& v) {
         if (status != SABER_OK) return nullptr;
         std::vector<bf16_t> h(v.size());
-        for (size_t i = 0; i < v.size(); ++i) h[i] = host_f2bf(v[i]);
+        if (e->op_f16) {      // fp16 operands: the type's range is the one thing it gives up against bf16 - fail loudly, never produce infinities
+            for (size_t i = 0; i < v.size(); ++i)
+                if (!(std::fabs(v[i]) <= 65504.0f)) { status = eng_fail(e, SABER_ERR_INVALID, "SABER_PRECISION_FP16: a weight of magnitude " + std::to_string(std::fabs(v[i])) + " exceeds the fp16 range (65504); use SABER_PRECISION_BF16 for this checkpoint"); return nullptr; }
+        }
+        for (size_t i = 0; i < v.size(); ++i) h[i] = host_f2op(v[i], e->op_f16);
         bf16_t* d = nullptr;
         status = eng_alloc(e, &d, h.size());
         if (status != SABER_OK) return nullptr;
@@ -369,6 +401,12 @@ struct Finalizer {
         const HostTensor* g = get(prefix + ".weight", {c});
         const HostTensor* b = get(prefix + ".bias", {c});
         if (!g || !b) return l;
+        if (e->op_f16) {      // a normalised row has |x^| <= sqrt(C - 1): bound of the LayerNorm output that becomes an fp16 operand
+            float mg = 0.f, mb = 0.f;
+            for (float x : g->data) mg = std::max(mg, std::fabs(x));
+            for (float x : b->data) mb = std::max(mb, std::fabs(x));
+            if (!(mg * std::sqrt((float)c) + mb <= 65504.0f)) { status = eng_fail(e, SABER_ERR_INVALID, "SABER_PRECISION_FP16: LayerNorm '" + prefix + "' can produce values beyond the fp16 range (max |gamma| sqrt(C) + max |beta| > 65504); use SABER_PRECISION_BF16 for this checkpoint"); return l; }
+        }
         l.g = up_f32(g->data); l.b = up_f32(b->data);
         return l;
     }
@@ -422,6 +460,7 @@ static double bicubic_sample(const float* plane, int h, int w, int oy, int ox, i
 extern "C" int saber_engine_finalize(saber_engine* e) {
     if (!e) return SABER_ERR_INVALID;
     if (e->finalized) return eng_fail(e, SABER_ERR_STATE, "finalize called twice");
+    if (e->op_f16 && e->weight_format != SABER_WEIGHTS_BF16) return eng_fail(e, SABER_ERR_INVALID, "SABER_PRECISION_FP16 runs with the default weight format only (the fp8 formats are defined on bf16 operands)");
     ENG_DEVICE(e);
     Finalizer F{e};
     const int C0 = e->embed_dim;
@@ -897,7 +936,6 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
     const size_t nblocks = e->blocks.size();
     // window-padding rows (padded layout): the reference pads the normalised tokens with zeros before qkv
     ENG_KP(e, PC_LAYERNORM, 0.0, 0.0, ln_run(x, e->bw[0].n1, 1e-6f, n * tokens, e->blocks[0].din, nullptr, e->xn, ACT_NONE, s, nullptr, nullptr, 0, e->valid[0], tokens));
-    extern int g_saber_debug_flags;
     // Consumers walk the M tiles AGAINST their producers: a kernel that starts on the rows its predecessor wrote last finds them in the
     // 256-MB Infinity Cache (walking the same way, every row has been evicted by the time it is read: LRU streaming).  Measured where
     // the tensor in between is larger than the cache: qkv (297 MB in stage 3) -> window attention 10.73 -> 10.23 ms per slice; neutral

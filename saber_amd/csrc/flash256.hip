@@ -15,10 +15,10 @@ typedef s16x4 __attribute__((address_space(3))) * f2_lds_s16x4_ptr;
 typedef unsigned int f2_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void* f2_gptr;
 typedef __attribute__((address_space(3))) void* f2_lptr;
-__device__ __forceinline__ bf16x8 f2_cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-__device__ __forceinline__ bf16x8 f2_pack8(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
-    uint4 u = make_uint4(pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(b0, b1), pack_bf16(b2, b3));
-    return __builtin_bit_cast(bf16x8, u);
+__device__ __forceinline__ op16x8 f2_cat4(op16x4 a, op16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ op16x8 f2_pack8(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+    uint4 u = make_uint4(pack_op16(a0, a1), pack_op16(a2, a3), pack_op16(b0, b1), pack_op16(b2, b3));
+    return __builtin_bit_cast(op16x8, u);
 }
 #define F2_ROWB 512
 #define F2_KB 64
@@ -40,11 +40,11 @@ __global__ __launch_bounds__(512) void flash256_kernel(const bf16_t* __restrict_
     const int kb0 = sp * per, nkb = max(0, min(per, nkb_all - kb0));
     const int q0 = qb * 64;
 
-    bf16x8 qf[8];
+    op16x8 qf[8];
     {
         const bf16_t* qrow = Q + (int64_t)(q0 + qt * 16 + fi) * 256;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
     }
     float m = -3.0e38f, l = 0.f;
     f32x4 o[16];
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(512) void flash256_kernel(const bf16_t* __restrict_
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kx = *reinterpret_cast<const bf16x8*>(ks_ + kt * 16 * F2_ROWB + koff[ks]);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kx, qf[ks], s[kt], 0, 0, 0);
+                const op16x8 kx = *reinterpret_cast<const op16x8*>(ks_ + kt * 16 * F2_ROWB + koff[ks]);
+                s[kt] = MFMA_16x16x32(kx, qf[ks], s[kt], 0, 0, 0);
             }
         }
         // scale into the exp2 domain; keys beyond n_keys take no part
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512) void flash256_kernel(const bf16_t* __restrict_
             }
         sum = xor32_sum(xor16_sum(sum));
         l += sum;
-        const bf16x8 pf = f2_pack8(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
+        const op16x8 pf = f2_pack8(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
         {
             const uint32_t va = (uint32_t)(uintptr_t)(f2_lptr)(vs_ + vrow * F2_ROWB + vlow);
 #pragma unroll
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(512) void flash256_kernel(const bf16_t* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bf16x8 vf = f2_cat4(__builtin_bit_cast(bf16x4, lo[j]), __builtin_bit_cast(bf16x4, hi[j]));
-                    o[d4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d4 + j], 0, 0, 0);
+                    const op16x8 vf = f2_cat4(__builtin_bit_cast(op16x4, lo[j]), __builtin_bit_cast(op16x4, hi[j]));
+                    o[d4 + j] = MFMA_16x16x32(vf, pf, o[d4 + j], 0, 0, 0);
                 }
             }
         }
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(512) void flash256_kernel(const bf16_t* __restrict_
                 const float4 t = *reinterpret_cast<const float4*>(mo + fi * 260 + 16 * dt + 4 * fg);
                 const float4 b = *reinterpret_cast<const float4*>(bias_v + 16 * dt + 4 * fg);
                 *reinterpret_cast<uint2*>(out + (int64_t)q * 256 + 16 * dt + 4 * fg) =
-                    make_uint2(pack_bf16((o[dt][0] * a1 + t.x * a2) * inv + b.x, (o[dt][1] * a1 + t.y * a2) * inv + b.y),
-                               pack_bf16((o[dt][2] * a1 + t.z * a2) * inv + b.z, (o[dt][3] * a1 + t.w * a2) * inv + b.w));
+                    make_uint2(pack_op16((o[dt][0] * a1 + t.x * a2) * inv + b.x, (o[dt][1] * a1 + t.y * a2) * inv + b.y),
+                               pack_op16((o[dt][2] * a1 + t.z * a2) * inv + b.z, (o[dt][3] * a1 + t.w * a2) * inv + b.w));
             }
         }
     }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void flash256_combine_kernel(const float* __re
     }
     const float inv = 1.0f / L;
     const float4 b = *reinterpret_cast<const float4*>(bias_v + 4 * lane);
-    *reinterpret_cast<uint2*>(out + (int64_t)q * 256 + 4 * lane) = make_uint2(pack_bf16(acc.x * inv + b.x, acc.y * inv + b.y), pack_bf16(acc.z * inv + b.z, acc.w * inv + b.w));
+    *reinterpret_cast<uint2*>(out + (int64_t)q * 256 + 4 * lane) = make_uint2(pack_op16(acc.x * inv + b.x, acc.y * inv + b.y), pack_op16(acc.z * inv + b.z, acc.w * inv + b.w));
 }
 
 const char* launch_flash256(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int n_q, int n_keys, float scale, const float* bias_v, bf16_t* out, float* ws,

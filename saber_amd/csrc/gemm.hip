@@ -103,10 +103,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
             if (Cb) {
                 bf16_t* cp = Cb + (int64_t)mo * p.ldcb + n;
-                if (nvec) *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                if (nvec) *reinterpret_cast<uint2*>(cp) = make_uint2(pack_op16(v[0], v[1]), pack_op16(v[2], v[3]));
                 else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = f2bf(v[r]);
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = f2op(v[r]);
                 }
             }
         }
@@ -185,17 +185,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         const char* sw = sa + TBYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[T], wf[T];
+            op16x8 af[T], wf[T];
 #pragma unroll
             for (int i = 0; i < T; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * (16 * T) + i * 16 + fi, ks * 4 + fg));
-                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * (16 * T) + i * 16 + fi, ks * 4 + fg));
+                af[i] = *reinterpret_cast<const op16x8*>(sa + swz(wm * (16 * T) + i * 16 + fi, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const op16x8*>(sw + swz(wn * (16 * T) + i * 16 + fi, ks * 4 + fg));
             }
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
                 for (int j = 0; j < T; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA_16x16x32(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore((kt + 1) & 1);
         __syncthreads();
@@ -337,17 +337,17 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
         const char* sw = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
+            op16x8 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
-                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
+                af[i] = *reinterpret_cast<const op16x8*>(sa + swz(wm * 64 + i * 16 + fi, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const op16x8*>(sw + swz(wn * 64 + i * 16 + fi, ks * 4 + fg));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA_16x16x32(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         --ahead;
         // the K-tile computed next must have landed (this wave's part) before the barrier; the youngest one may stay in flight.
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_glds_kernel(GemmParams p) 
                         const int chunk = j * 2 + (fg >> 1);
                         // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS
                         // loads in flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous 16 rows.
-                        const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                        const uint64_t pk = ((uint64_t)pack_op16(v[2], v[3]) << 32) | pack_op16(v[0], v[1]);
                         asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
                     }
                     u32x4 val0, val1;
@@ -494,17 +494,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const char* sa = smem + (kt % 3) * G2_STAGE;
         const char* sw = sa + A_BYTES;
         if (cols_live) {
-            bf16x8 af[4], wf[4];
+            op16x8 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 64 + i * 16 + fi, fg));
-                wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + i * 16 + fi, fg));
+                af[i] = *reinterpret_cast<const op16x8*>(sa + swz2(wm * 64 + i * 16 + fi, fg));
+                wf[i] = *reinterpret_cast<const op16x8*>(sw + swz2(wn * 64 + i * 16 + fi, fg));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA_16x16x32(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         // the K-tile two ahead is issued BEHIND this one's MFMAs (an LDS-DMA issue stalls the issuing wave 60-185 cycles; at the top of
         // the K-tile, right behind the barrier, nothing of this wave is in flight to hide it): -0.3 ms per slice
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
                 }
                 const int chunk = j * 2 + (fg >> 1);
-                const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                const uint64_t pk = ((uint64_t)pack_op16(v[2], v[3]) << 32) | pack_op16(v[0], v[1]);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
             }
             u32x4 val0, val1;
@@ -768,14 +768,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
     else if (issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    bf16x8 af[8], wf[4];
+    op16x8 af[8], wf[4];
     auto read_frags = [&](int stage) {
         const char* sa = smem + stage * P2_STAGE;
         const char* sw = sa + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sw + swz2(wn * 64 + j * 16 + fi, fg));
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const op16x8*>(sw + swz2(wn * 64 + j * 16 + fi, fg));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + swz2(wm * 128 + i * 16 + fi, fg));
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + swz2(wm * 128 + i * 16 + fi, fg));
     };
     // The MFMA cluster must stay inside its half-step: MFMAs touch no memory, so hipcc is free to move them across the raw barriers and
     // the inline-asm waits (it did, depending on unrelated edits: 305 us <-> 335 us on the fc1 shape).  s_setprio around the cluster
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = MFMA_16x16x32(wf[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256s_kernel(GemmParams p) {
                 const int chunk = j * 2 + (fg >> 1);
                 // LDS traffic of the epilogue is inline asm: hipcc orders every VISIBLE ds access behind the direct-to-LDS loads in
                 // flight with s_waitcnt vmcnt(0), which would also drain the stores of the previous rows
-                const uint64_t pk = ((uint64_t)pack_bf16(v[2], v[3]) << 32) | pack_bf16(v[0], v[1]);
+                const uint64_t pk = ((uint64_t)pack_op16(v[2], v[3]) << 32) | pack_op16(v[0], v[1]);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(tb_a + fi * 128 + ((chunk ^ (fi & 7)) << 4) + (fg & 1) * 8), "v"(pk) : "memory");
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256x_kernel(GemmParams p) {
     }
     u32x4 fa[2][4], fw[2][2];                      // two fragment sets
 #define PX_RD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
-#define PX_MFMA(set, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[set][j]), __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0)
+#define PX_MFMA(set, i, j) acc[i][j] = MFMA_32x32x16(__builtin_bit_cast(op16x8, fw[set][j]), __builtin_bit_cast(op16x8, fa[set][i]), acc[i][j], 0, 0, 0)
 #define PX_FENCE() __builtin_amdgcn_sched_barrier(0)
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
 
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256x_kernel(GemmParams p) {
                     for (int g = 0; g < 4; ++g) {
                         float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
                         if (p.act == ACT_GELU) { const f32x2 g0_ = gelu_erf2((f32x2){v0, v1}), g1_ = gelu_erf2((f32x2){v2, v3}); v0 = g0_.x; v1 = g0_.y; v2 = g1_.x; v3 = g1_.y; }
-                        const uint64_t pk = ((uint64_t)pack_bf16(v2, v3) << 32) | pack_bf16(v0, v1);
+                        const uint64_t pk = ((uint64_t)pack_op16(v2, v3) << 32) | pack_op16(v0, v1);
                         const int chunk = 4 * j + g;              // 16-byte chunk of the 128-byte row; its 8-byte half is h
                         asm volatile("ds_write_b64 %0, %1" ::"v"(tb + r32 * 128 + ((chunk ^ (r32 & 7)) << 4) + h * 8), "v"(pk) : "memory");
                     }
@@ -1126,11 +1126,9 @@ const char* gemm_init_device() {
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }
 
-extern int g_saber_debug_flags;
 const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.dbg = g_saber_debug_flags;
-    extern unsigned long long* g_saber_stamp_buf;
     p.stamps = g_saber_stamp_buf;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
     if ((p.K & 7) || (p.lda & 7) || (p.ldw & 7)) return "gemm: K, lda, ldw must be multiples of 8";
@@ -1149,9 +1147,7 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
     const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1 && (p.act == ACT_NONE || p.act == ACT_GELU);
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    // opt-in (development flag 131072; + 262144: also for problems of fewer than 256 tiles): the one-wave-per-SIMD kernel of gemm_w1.hip.
-    // Parity-green, level with the kernels below on the fc2-like shapes and 4-12 % behind on qkv / fc1: not the default.
-    if ((p.dbg & 131072) && bf16_only && (tiles_p2 >= 256 || (p.dbg & 262144)) && gemm_w1_supported(p)) return launch_gemm_w1(p, stream);
+    // (the one-wave-per-SIMD experiment of round 3, DESIGN.md section 4, is parked in tools/experiments/gemm_w1.hip: it lost its A/B)
     if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);

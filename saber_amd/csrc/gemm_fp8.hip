@@ -76,7 +76,7 @@ __device__ __forceinline__ void mx_epilogue(const GemmMxParams& p, f32x4 (&acc)[
             for (int j = 0; j < 6; ++j) {
                 float v0 = acc[j][i][0] + bias4[j].x, v1 = acc[j][i][1] + bias4[j].y, v2 = acc[j][i][2] + bias4[j].z, v3 = acc[j][i][3] + bias4[j].w;
                 if (p.act == ACT_GELU) { const f32x2 g0_ = gelu_erf2((f32x2){v0, v1}), g1_ = gelu_erf2((f32x2){v2, v3}); v0 = g0_.x; v1 = g0_.y; v2 = g1_.x; v3 = g1_.y; }
-                const uint64_t pk = ((uint64_t)pack_bf16(v2, v3) << 32) | pack_bf16(v0, v1);
+                const uint64_t pk = ((uint64_t)pack_op16(v2, v3) << 32) | pack_op16(v0, v1);
                 MX_DSW64(scr + fi * PITCH + (16 * j + 4 * fg) * 2, pk);
             }
             u32x4 val[3];
@@ -126,7 +126,7 @@ __device__ __forceinline__ void mx_epilogue(const GemmMxParams& p, f32x4 (&acc)[
                                                  __uint_as_float(val[t][3]) + r[t].w);
                     if (m < p.M && n < p.N) {
                         *reinterpret_cast<float4*>(p.Cf + m * p.ldcf + n) = o;
-                        if (p.Cb) *reinterpret_cast<uint2*>(p.Cb + m * p.ldcb + n) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                        if (p.Cb) *reinterpret_cast<uint2*>(p.Cb + m * p.ldcb + n) = make_uint2(pack_op16(o.x, o.y), pack_op16(o.z, o.w));
                     }
                 }
             }
@@ -556,7 +556,6 @@ const char* launch_gemm_mx(const GemmMxParams& p, hipStream_t s) {
     const int padded = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const int cap = ver == 4 ? 512 : 256;                  // persistent: as many workgroups as fit the chip at once (a multiple of 8)
     const int grid = padded < cap ? padded : cap;
-    extern unsigned long long* g_saber_stamp_buf;          // development: per-phase cycle stamps (tools/gemm_fp8_stamps.py)
     unsigned long long* sb = g_saber_stamp_buf;
 #define MX_LAUNCH(K, LDS, ST, NT)                                                                                               \
     do {                                                                                                                        \

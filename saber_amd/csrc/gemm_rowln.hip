@@ -158,20 +158,20 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             const char* sa = smem + (kt % 3) * STAGE;
             const char* sw = sa + RA * 1024;
             if (!PH && more) issue(wrsrc, t, kt + 2, 0, 2);
-            bf16x8 af[4];
+            op16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
 #pragma unroll
             for (int jg = 0; jg < 3; ++jg) {
-                bf16x8 wf[3];
+                op16x8 wf[3];
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const bf16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
+                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const op16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj)
-                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = MFMA_16x16x32(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     if (!PH) { if (jg == 0) issue(wrsrc, t, kt + 2, 2, 4); else if (jg == 1) issue(wrsrc, t, kt + 2, 4, NQ); }
@@ -196,19 +196,19 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             const char* sw = sa + RA * 1024;
             // fragments in three column groups of 3 tiles: 16 + 12 live operand registers instead of 52 (the kernel lives on 256 VGPRs
             // with 144 of them accumulators)
-            bf16x8 af[4];
+            op16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
 #pragma unroll
             for (int jg = 0; jg < 3; ++jg) {
-                bf16x8 wf[3];
+                op16x8 wf[3];
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const bf16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
+                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const op16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj)
-                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = MFMA_16x16x32(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
 #if RL_SPLIT
                 if (kt + 2 < nk) { if (jg == 0) issue(wrsrc, t, kt + 2, RL_Q1, RL_Q2); else if (jg == 1) issue(wrsrc, t, kt + 2, RL_Q2, NQ); }
 #endif
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
                     u32x2 v;
-                    v[0] = pack_bf16(acc[i][j][0], acc[i][j][1]); v[1] = pack_bf16(acc[i][j][2], acc[i][j][3]);
+                    v[0] = pack_op16(acc[i][j][0], acc[i][j][1]); v[1] = pack_op16(acc[i][j][2], acc[i][j][3]);
                     __builtin_amdgcn_raw_buffer_store_b64(v, brsrc, boff + j * 32, i * bstep, 0);
                 }
         }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                const uint64_t pk = ((uint64_t)pack_bf16(acc[i][j][2], acc[i][j][3]) << 32) | pack_bf16(acc[i][j][0], acc[i][j][1]);
+                const uint64_t pk = ((uint64_t)pack_op16(acc[i][j][2], acc[i][j][3]) << 32) | pack_op16(acc[i][j][0], acc[i][j][1]);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(scr_w + j * 32), "v"(pk) : "memory");
             }
             u32x4 val[6];
@@ -422,7 +422,6 @@ bool gemm_rowln_supported(const GemmParams& p) {
            p.act == ACT_NONE && p.res_shift == 0 && p.res_mod == 0;
 }
 
-extern int g_saber_debug_flags;
 const char* launch_gemm_rowln(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.dbg = g_saber_debug_flags;

@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormParams p) {
                 if (zero_row) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
                 if (p.out_f) *reinterpret_cast<float4*>(p.out_f + row * p.ldo + 4 * c) = make_float4(y0, y1, y2, y3);
                 if (p.out_bf)
-                    *reinterpret_cast<uint2*>(p.out_bf + row * p.ldo + 4 * c) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+                    *reinterpret_cast<uint2*>(p.out_bf + row * p.ldo + 4 * c) = make_uint2(pack_op16(y0, y1), pack_op16(y2, y3));
                 if (p.out_bf_add) {
                     const float4 a = *reinterpret_cast<const float4*>(addv + 4 * c);
                     *reinterpret_cast<uint2*>(p.out_bf_add + row * p.ldo + 4 * c) =
-                        make_uint2(pack_bf16(y0 + a.x, y1 + a.y), pack_bf16(y2 + a.z, y3 + a.w));
+                        make_uint2(pack_op16(y0 + a.x, y1 + a.y), pack_op16(y2 + a.z, y3 + a.w));
                 }
             }
         }
@@ -142,11 +142,11 @@ __global__ __launch_bounds__(256) void layernorm_rows4_kernel(LayerNormParams p)
                     if (zero_row) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
                     if (p.out_f) *reinterpret_cast<float4*>(p.out_f + row * p.ldo + 4 * c) = make_float4(y0, y1, y2, y3);
                     if (p.out_bf)
-                        *reinterpret_cast<uint2*>(p.out_bf + row * p.ldo + 4 * c) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+                        *reinterpret_cast<uint2*>(p.out_bf + row * p.ldo + 4 * c) = make_uint2(pack_op16(y0, y1), pack_op16(y2, y3));
                     if (p.out_bf_add) {
                         const float4 a = *reinterpret_cast<const float4*>(addv + 4 * c);
                         *reinterpret_cast<uint2*>(p.out_bf_add + row * p.ldo + 4 * c) =
-                            make_uint2(pack_bf16(y0 + a.x, y1 + a.y), pack_bf16(y2 + a.z, y3 + a.w));
+                            make_uint2(pack_op16(y0 + a.x, y1 + a.y), pack_op16(y2 + a.z, y3 + a.w));
                     }
                 }
             }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void add_to_bf16_kernel(const float* __restric
             const float4 b = *reinterpret_cast<const float4*>(y + (r % ymod) * C + 4 * c);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        if (out_bf) *reinterpret_cast<uint2*>(out_bf + r * C + 4 * c) = make_uint2(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w));
+        if (out_bf) *reinterpret_cast<uint2*>(out_bf + r * C + 4 * c) = make_uint2(pack_op16(a.x, a.y), pack_op16(a.z, a.w));
         if (out_f) *reinterpret_cast<float4*>(out_f + r * C + 4 * c) = a;
     }
 }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, 
             a = ra; b = rb;
         }
         if (out_f) { out_f[row * C + 2 * i] = a; out_f[row * C + 2 * i + 1] = b; }
-        if (out_bf) *reinterpret_cast<uint32_t*>(out_bf + row * C + 2 * i) = pack_bf16(a, b);
+        if (out_bf) *reinterpret_cast<uint32_t*>(out_bf + row * C + 2 * i) = pack_op16(a, b);
     }
 }
 const char* launch_rope(const float* x, int64_t rows, int n_rot, int C, int side, float theta, float* out_f, bf16_t* out_bf, hipStream_t s) {
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     __syncthreads();
     const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
     bf16_t* p = P + row * ldp;
-    for (int c = tid; c < ldp; c += 256) p[c] = c < n ? f2bf(__expf((s[c] - mx) * scale) * inv) : (bf16_t)0;
+    for (int c = tid; c < ldp; c += 256) p[c] = c < n ? f2op(__expf((s[c] - mx) * scale) * inv) : (bf16_t)0;
 }
 const char* launch_softmax_rows(const float* S, int64_t lds_, int64_t rows, int n, float scale, bf16_t* P, int64_t ldp, hipStream_t s) {
     if (rows <= 0 || n <= 0) return nullptr;
@@ -290,7 +290,7 @@ const char* launch_axpy(const float* x, const float* y, const float* g, float al
 }
 
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, int64_t n, float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = bf2f(x[i]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = op2f(x[i]);
 }
 const char* launch_bf16_to_f32(const bf16_t* x, int64_t n, float* out, hipStream_t s) {
     if (n <= 0) return nullptr;

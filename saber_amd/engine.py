@@ -30,7 +30,8 @@ class Engine:
     """One engine handle bound to one device (reference threading contract: one caller per device)."""
 
     def __init__(self, trunk: str = "large", device: int = 0, weights: Optional[Dict[str, np.ndarray]] = None,
-                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64, weight_format: str = "bf16", precision: str = "bf16"):
+                 checkpoint: Optional[str] = None, seed: int = 0, max_images: int = 1, max_prompts: int = 64, weight_format: str = "bf16", precision: str = "bf16",
+                 operands: Optional[str] = None):
         self.lib = _lib.load()
         self.cfg = get_config(trunk)  # ValueError for unknown names, like the reference
         if not torch.cuda.is_available():
@@ -49,10 +50,20 @@ class Engine:
         self.weight_format = weight_format
         if weight_format != "bf16":      # fp8: e4m3 storage of the stage-2/3 block weights; mxfp8: MX operands on the fp8 MFMA (include/saber_amd.h: saber_engine_set_weight_format)
             self._check(self.lib.saber_engine_set_weight_format(self.h, {"fp8": 1, "mxfp8": 2}[weight_format]))
-        if precision not in ("bf16", "exact"):
-            raise ValueError(f"precision must be 'bf16' or 'exact', got '{precision}'")
+        if precision not in ("bf16", "fp16", "exact"):
+            raise ValueError(f"precision must be 'bf16', 'fp16' or 'exact', got '{precision}'")
+        # operands: the 16-bit MFMA operand type the weights are converted to at finalize ("bf16" | "fp16"; include/saber_amd.h:
+        # SABER_PRECISION_FP16).  Implied by `precision`; only a handle created with precision="exact" needs it spelled out, to say which
+        # 16-bit arithmetic set_precision can switch back to.
+        if operands is None:
+            operands = "fp16" if precision == "fp16" else "bf16"
+        if operands not in ("bf16", "fp16") or (precision in ("bf16", "fp16") and operands != precision):
+            raise ValueError(f"operands must be 'bf16' or 'fp16' and agree with precision, got operands='{operands}' precision='{precision}'")
+        self.operands = operands
         self.precision = precision
         self.has_exact = precision == "exact"      # fp32 weight copies are kept only when the handle was created in the exact mode
+        if operands == "fp16":
+            self._check(self.lib.saber_engine_set_precision(self.h, 2))
         if precision == "exact":         # fp32 operands everywhere (include/saber_amd.h: saber_engine_set_precision); keeps fp32 weight copies
             self._check(self.lib.saber_engine_set_precision(self.h, 1))
         if weights is None:
@@ -249,11 +260,11 @@ class Engine:
         return out
 
     def set_precision(self, precision: str):
-        """Switch between the bf16 production arithmetic and the fp32 exact mode (only on a handle created with precision="exact",
-        which keeps the fp32 weight copies)."""
-        if precision not in ("bf16", "exact"):
-            raise ValueError(f"precision must be 'bf16' or 'exact', got '{precision}'")
-        self._check(self.lib.saber_engine_set_precision(self.h, 1 if precision == "exact" else 0))
+        """Switch between the handle's 16-bit production arithmetic ("bf16" or "fp16": whichever its weights were converted to) and the
+        fp32 exact mode (only on a handle created with precision="exact", which keeps the fp32 weight copies)."""
+        if precision not in ("bf16", "fp16", "exact"):
+            raise ValueError(f"precision must be 'bf16', 'fp16' or 'exact', got '{precision}'")
+        self._check(self.lib.saber_engine_set_precision(self.h, {"bf16": 0, "exact": 1, "fp16": 2}[precision]))
         self.precision = precision
 
     def set_device_amg(self, enable: bool):

@@ -90,29 +90,6 @@ def test_gemm_p256(gpu_lib, M, N, K, act):
     assert errb < 5e-3, errb
 
 
-@pytest.mark.parametrize("M,N,K,act", [(777, 1000, 192, 0), (4096, 2304, 576, 1), (300, 264, 64, 0), (256 * 300 + 5, 512, 128, 0), (2560, 1728, 1152, 1)])
-def test_gemm_one_wave_per_simd(gpu_lib, M, N, K, act):
-    """gemm_w1.hip (opt-in experiment, 128x128 wave tiles, persistent K-step stream): ragged M / N, one K-step pair per tile (K = 64),
-    more tiles than workgroups (the stream crosses tile boundaries), GELU epilogue"""
-    g = torch.Generator().manual_seed(M + N + K + 1)
-    A, Ad = bf(torch.randn(M, K, generator=g))
-    W, Wd = bf(torch.randn(N, K, generator=g) / K ** 0.5)
-    bias = torch.randn(N, generator=g)
-    ref = A.double() @ W.double().T + bias.double()
-    ref = F.gelu(ref) if act == 1 else ref
-    out_b = torch.zeros(M, N, dtype=torch.int16, device="cuda")
-    bias_d = bias.cuda()
-    gpu_lib.saber_k_set_debug(131072 | 262144)
-    try:
-        kcall(gpu_lib, gpu_lib.saber_k_gemm(ptr(Ad), ptr(Wd), ptr(bias_d), None, None, ptr(out_b), M, N, K, act, 0, 0, 0, 0, None))
-    finally:
-        gpu_lib.saber_k_set_debug(0)
-    torch.cuda.synchronize()
-    scale = ref.abs().max().item() + 1e-6
-    errb = (from_bf(out_b).double() - ref).abs().max().item() / scale
-    assert errb < 5e-3, errb
-
-
 def test_gemm_act_last_and_res_mod(gpu_lib):
     g = torch.Generator().manual_seed(3)
     M, N, K = 640, 128, 64
