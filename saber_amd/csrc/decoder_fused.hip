@@ -857,6 +857,14 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 #ifndef UP_MFMA_HYPER
 #define UP_MFMA_HYPER 0
 #endif
+// Development build (make EXTRA=-DUP_DEV=1 BUILD=build_dev LIB=../libsaber_amd_dev.so; tools/upscale_ablate.py): run-time switches that
+// take single pieces of the prompt loop away (results are garbage) and per-phase s_memtime stamps, to see what the kernel's time is made
+// of.  0 in the shipped library: every UPD(..) below folds to false and the stamps disappear.
+#ifndef UP_DEV
+#define UP_DEV 0
+#endif
+#define UPD(bit) (UP_DEV && (dbg & (bit)))
+enum { UPD_NO_GELU = 1, UPD_NO_W1_READ = 2, UPD_NO_W2_READ = 4, UPD_NO_STORE = 8, UPD_NO_HYPER = 16, UPD_NO_XLOAD = 32, UPD_NO_LN = 64, UPD_NO_MFMA_A = 128, UPD_NO_MFMA_B = 256 };
 #define UP_W1S (256 * ROW_B)          // W1 [256 n][256 k] bf16, kswz
 #define UP_W2S (128 * 128)            // W2p [128 n2][64] bf16 (k-slots pre-permuted), swz128
 #define UP_LDS (UP_W1S + UP_W2S)
@@ -867,9 +875,12 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
                                                           const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
                                                           const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups,
-                                                          const uint8_t* __restrict__ live, const float* __restrict__ iou4, int multimask) {
+                                                          const uint8_t* __restrict__ live, const float* __restrict__ iou4, int multimask, int dbg,
+                                                          unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
+    unsigned long long ts[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define UP_STAMP(k) do { if (UP_DEV && stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
     char* w2s = w1s + UP_W1S;
     // 8 waves (two per SIMD: the epilogues are VALU-bound, a lone wave would issue at half rate):
     // wave = (token half mw) * 4 + (pos = ConvT1 output position)
@@ -941,6 +952,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
     auto next_live = [&](int q) { while (live && q < P && !live[q]) q += groups; return q; };     // block-uniform
     int p = next_live(grp);
     if (p < P) xload(p, xf);
+    if (UP_DEV && stamps) tprev = __builtin_amdgcn_s_memtime();
     for (int pn; p < P; p = pn) {
         pn = next_live(p + groups);
         // compiler fence: without it the loop-invariant weight fragments (32 + 16 ds_read_b128 per wave) are hoisted out of the
@@ -998,12 +1010,14 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const op16x8 wf = *reinterpret_cast<const op16x8*>(w1s + kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg));
-                acc[ni] = MFMA_16x16x32(wf, xf[ks], acc[ni], 0, 0, 0);
+                const op16x8 wf = *reinterpret_cast<const op16x8*>(w1s + (UPD(UPD_NO_W1_READ) ? kswz(fi, fg) : kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg)));
+                if (!UPD(UPD_NO_MFMA_A)) acc[ni] = MFMA_16x16x32(wf, xf[ks], acc[ni], 0, 0, 0);
+                else acc[ni][0] += __builtin_bit_cast(f32x4, wf)[0] + __builtin_bit_cast(f32x4, xf[ks])[0];
             }
         }
+        UP_STAMP(0);
         // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
-        if (pn < P) xload(pn, xf);
+        if (pn < P && !UPD(UPD_NO_XLOAD)) xload(pn, xf);
         // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
         op16x8 uf[2];
         {
@@ -1013,20 +1027,21 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 v[ni][0] = acc[ni][0]; v[ni][1] = acc[ni][1]; v[ni][2] = acc[ni][2]; v[ni][3] = acc[ni][3];
                 sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
             }
-            sum = xor32_sum(xor16_sum(sum));
+            if (!UPD(UPD_NO_LN)) sum = xor32_sum(xor16_sum(sum));
             const float mean = sum * (1.0f / 64.0f);
             float var = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
-            var = xor32_sum(xor16_sum(var));
+            if (!UPD(UPD_NO_LN)) var = xor32_sum(xor16_sum(var));
             const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / 64.0f) + 1e-6f);
             const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const f32x2 a = gelu_erf2(((f32x2){v[ni][0], v[ni][1]} - mean2) * rstd2 * (f32x2){gg[ni].x, gg[ni].y} + (f32x2){be[ni].x, be[ni].y});
-                const f32x2 b = gelu_erf2(((f32x2){v[ni][2], v[ni][3]} - mean2) * rstd2 * (f32x2){gg[ni].z, gg[ni].w} + (f32x2){be[ni].z, be[ni].w});
+                f32x2 a = ((f32x2){v[ni][0], v[ni][1]} - mean2) * rstd2 * (f32x2){gg[ni].x, gg[ni].y} + (f32x2){be[ni].x, be[ni].y};
+                f32x2 b = ((f32x2){v[ni][2], v[ni][3]} - mean2) * rstd2 * (f32x2){gg[ni].z, gg[ni].w} + (f32x2){be[ni].z, be[ni].w};
+                if (!UPD(UPD_NO_GELU)) { a = gelu_erf2(a); b = gelu_erf2(b); }
                 v[ni][0] = a.x; v[ni][1] = a.y; v[ni][2] = b.x; v[ni][3] = b.y;
             }
 #pragma unroll
@@ -1034,6 +1049,7 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 uf[ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
                                  v[2 * ks + 1][3]);
         }
+        UP_STAMP(1);
         // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
         float* orow = masks4 + (int64_t)p * 4 * 65536 + obase;
 #pragma unroll
@@ -1045,9 +1061,11 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int nl = 0; nl < 4; ++nl) {
-                    const op16x8 w2f = *reinterpret_cast<const op16x8*>(w2s + swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg));
-                    c2[nl] = MFMA_16x16x32(w2f, uf[ks], c2[nl], 0, 0, 0);
+                    const op16x8 w2f = *reinterpret_cast<const op16x8*>(w2s + (UPD(UPD_NO_W2_READ) ? swz128(fi, fg) : swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg)));
+                    if (!UPD(UPD_NO_MFMA_B)) c2[nl] = MFMA_16x16x32(w2f, uf[ks], c2[nl], 0, 0, 0);
+                    else c2[nl][0] += __builtin_bit_cast(f32x4, w2f)[0] + __builtin_bit_cast(f32x4, uf[ks])[0];
                 }
+            UP_STAMP(2);
             float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
@@ -1065,9 +1083,10 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int nl = 2 * pp + hh;
-                    const f32x2 ua = gelu_erf2((f32x2){c2[nl][0], c2[nl][1]});
-                    const f32x2 ub = gelu_erf2((f32x2){c2[nl][2], c2[nl][3]});
+                    f32x2 ua = (f32x2){c2[nl][0], c2[nl][1]}, ub = (f32x2){c2[nl][2], c2[nl][3]};
+                    if (!UPD(UPD_NO_GELU)) { ua = gelu_erf2(ua); ub = gelu_erf2(ub); }
                     const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
+                    if (UPD(UPD_NO_HYPER)) { part[hh] += u0 + u1 + u2 + u3; continue; }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if ((need >> k) & 1) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
@@ -1082,9 +1101,15 @@ __global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restri
                 if (pp == 0) px2.x = mine; else px2.y = mine;
 #endif
             }
-            if ((need >> fg) & 1) *reinterpret_cast<float2*>(orow + hb * 256) = px2;
+            UP_STAMP(3);
+            if (((need >> fg) & 1) && !UPD(UPD_NO_STORE)) *reinterpret_cast<float2*>(orow + hb * 256) = px2;
+            if (UPD(UPD_NO_STORE) && px2.x + px2.y == 1.2345e30f) *reinterpret_cast<float2*>(orow + hb * 256) = px2;     // (keeps the values alive)
         }
+        UP_STAMP(4);
     }
+    if (UP_DEV && stamps && lane == 0)
+        for (int k = 0; k < 5; ++k) stamps[((int64_t)blockIdx.x * 8 + wave) * 5 + k] = ts[k];
+#undef UP_STAMP
 }
 
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
@@ -1093,7 +1118,8 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
     if (P <= 0) return nullptr;
     if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
     const int groups = P >= 2 ? 2 : 1;   // 128 tiles x 2 groups = one resident block per CU
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups, live, iou4, multimask);
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups, live, iou4, multimask,
+                       UP_DEV ? (g_saber_debug_flags >> 8) & 0x1ff : 0, UP_DEV ? g_saber_stamp_buf : nullptr);
     return nullptr;
 }
 
