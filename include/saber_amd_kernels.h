@@ -139,6 +139,10 @@ int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* p
 int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pek, const uint16_t* Qt, const float* tq, float qscale, float* part_ws,
                     float* ml_ws, int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream);
 
+/* Development (co-residency experiments, tools/cu_mask_bench.py): a HIP stream restricted to CUs first_cu .. first_cu + n_cus - 1
+ * (hipExtStreamCreateWithCUMask), and its release. */
+int saber_k_stream_create_cu_range(int first_cu, int n_cus, void** out_stream);
+int saber_k_stream_destroy(void* stream);
 /* 16-bit operand type of every kernel-level entry point called from THIS thread (thread-local): 0 = bf16 (default), 1 = IEEE fp16.  The
  * uint16_t operands and outputs of saber_k_gemm*, saber_k_layernorm, saber_k_hiera_attention*, saber_k_dec_*, saber_k_flash256, ... are
  * then fp16 bit patterns; same kernels, compiled for v_mfma_f32_16x16x32_f16.  Returns the previous setting. */

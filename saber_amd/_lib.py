@@ -104,6 +104,8 @@ SIGNATURES = {
     "saber_k_mask_post": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "saber_k_perm_index": (_i, [_i, _i, _i]),
     "saber_k_set_operand_type": (_i, [_i]),
+    "saber_k_stream_create_cu_range": (_i, [_i, _i, C.POINTER(_vp)]),
+    "saber_k_stream_destroy": (_i, [_vp]),
     "saber_k_host_f32_to_f16": (None, [_vp, _vp, C.c_int64]),
     "saber_k_dec_i2t": (_i, [_vp, C.c_int64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp]),
     "saber_k_dec_t2i": (_i, [_vp, C.c_int64, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),

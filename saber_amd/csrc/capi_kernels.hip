@@ -123,6 +123,20 @@ thread_local int g_saber_op_f16 = 0;
 bf16_t saber_host_f2h(float f);          // engine.hip
 // host-side fp32 -> IEEE half conversion the engine converts its weights with (exposed for the CPU test against numpy.float16)
 extern "C" void saber_k_host_f32_to_f16(const float* in, uint16_t* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = saber_host_f2h(in[i]); }
+// A HIP stream whose kernels run on the first n_cus compute units of `first_cu`.. (hipExtStreamCreateWithCUMask; bit i of the mask = CU i in
+// the runtime's numbering, which interleaves the XCDs: consecutive indices are spread over all eight) - the co-residency experiment of
+// VERDICT r03 item 4 (tools/cu_mask_bench.py).  The handle can be wrapped in torch.cuda.ExternalStream.
+extern "C" int saber_k_stream_create_cu_range(int first_cu, int n_cus, void** out_stream) {
+    if (!out_stream || first_cu < 0 || n_cus < 1 || first_cu + n_cus > 1024) return kfail("stream_create_cu_range: bad argument");
+    uint32_t mask[32] = {0};
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t s = nullptr;
+    const hipError_t st = hipExtStreamCreateWithCUMask(&s, (uint32_t)((first_cu + n_cus + 31) / 32), mask);
+    if (st != hipSuccess) return kfail(hipGetErrorString(st));
+    *out_stream = (void*)s;
+    return 0;
+}
+extern "C" int saber_k_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : kfail("hipStreamDestroy failed"); }
 extern "C" int saber_k_set_operand_type(int f16) { const int prev = g_saber_op_f16; g_saber_op_f16 = f16 ? 1 : 0; return prev; }
 
 // ------------------------------------------------------------------------------------------------ video (memory) path kernels

@@ -860,10 +860,15 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 // Development build (make EXTRA=-DUP_DEV=1 BUILD=build_dev LIB=../libsaber_amd_dev.so; tools/upscale_ablate.py): run-time switches that
 // take single pieces of the prompt loop away (results are garbage) and per-phase s_memtime stamps, to see what the kernel's time is made
 // of.  0 in the shipped library: every UPD(..) below folds to false and the stamps disappear.
+// -DUP_ABL=<mask> instead: the same switches fixed at COMPILE time (no run-time branches: the register allocation and schedule of the
+// shipped kernel minus the piece; tools/upscale_ablate.sh builds one library variant per mask).
 #ifndef UP_DEV
 #define UP_DEV 0
 #endif
-#define UPD(bit) (UP_DEV && (dbg & (bit)))
+#ifndef UP_ABL
+#define UP_ABL 0
+#endif
+#define UPD(bit) ((UP_ABL & (bit)) || (UP_DEV && (dbg & (bit))))
 enum { UPD_NO_GELU = 1, UPD_NO_W1_READ = 2, UPD_NO_W2_READ = 4, UPD_NO_STORE = 8, UPD_NO_HYPER = 16, UPD_NO_XLOAD = 32, UPD_NO_LN = 64, UPD_NO_MFMA_A = 128, UPD_NO_MFMA_B = 256 };
 #define UP_W1S (256 * ROW_B)          // W1 [256 n][256 k] bf16, kswz
 #define UP_W2S (128 * 128)            // W2p [128 n2][64] bf16 (k-slots pre-permuted), swz128

@@ -32,6 +32,11 @@ def run(flag, reps=3):
     return prof["decoder_upscale"]["ms"] / reps
 
 
+if os.environ.get("UP_ONLY_FULL"):      # a compile-time variant of the library (tools/upscale_ablate.sh): one timing, no run-time switches, no stamps
+    ms = run(0, reps=5)
+    print(f"decoder_upscale {ms * 1e3:8.1f} us per {P}-prompt launch = {ms * 1e3 / (P / 2):6.3f} us per prompt and workgroup")
+    eng.close()
+    sys.exit(0)
 base = None
 for name, f in FLAGS.items():
     ms = run(f)
