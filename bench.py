@@ -43,6 +43,13 @@ def parse():
                     "arithmetic the reference enables, 1e-3 from the fp32 oracle); fp8: e4m3 weights (per-row power-of-two scales) for the stage-2/3 block GEMMs, "
                     "bf16 activations and MFMA operands, fp32 accumulate (BASELINE configs[4]); SEPARATE lines, never the headline (BASELINE configs[1] says bf16)")
     ap.add_argument("--no-alt-dtypes", action="store_true", help="skip the extra keys `alt_dtypes` (the fp16 and mxfp8 lines measured after the headline on fresh handles)")
+    ap.add_argument("--volume", type=int, default=0, metavar="Z", help="STRONG scaling of ONE tomogram of Z slices (BASELINE configs[2] / configs[3]: 64 / 512): "
+                    "contiguous z-chunks per rank, one RCCL all-gather of the label planes, 3-D connected components on the device; value = Z / end-to-end seconds "
+                    "INCLUDING gather and stitch (the north star's '>= 6x 1 -> 8 GPUs on a 512-slice tomogram'); --steps / --warmup are ignored")
+    ap.add_argument("--tomograms", type=int, default=0, metavar="T", help="BASELINE configs[4]: a batch of T tomograms dealt round-robin to the ranks "
+                    "(the reference's GPUPool semantics, saber/utils/parallelization.py:137-151: task i -> GPU i %% n_gpus), each segmented and stitched on its own GPU, "
+                    "no data-path collective; value = all slices / max-over-ranks seconds")
+    ap.add_argument("--tomogram-slices", type=int, default=256, help="slices per tomogram of --tomograms (configs[4]: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-encoder-only", action="store_true", help="skip the extra encoder-only timing (profiling runs: keeps the kernel population of the trace = whole slices)")
@@ -211,6 +218,99 @@ def precision_check(weights, img, operands="bf16"):
         e.close()
 
 
+def volume_modes(a, rank, world, rehearsal, engines, pool, params, dist):
+    """--volume Z: ONE tomogram z-sharded over the ranks (strong scaling, gather + stitch inside the timed region);
+    --tomograms T: T tomograms dealt round-robin to the ranks, each stitched where it was segmented.  Slices are the synthetic pool slices
+    cycled along z (resident in HBM when the timer starts, like the headline); every rank keeps `--workers` engine handles, one thread and
+    one HIP stream each, slices dealt round-robin (saber_amd.segmenters.slice_driver.segment_volume_sharded)."""
+    from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded, shard_bounds
+    eng = engines[0]
+    dev = pool[0].device
+
+    def fns_for(vol):
+        return [(lambda z, e_=e_: segment_slice_to_plane(e_, vol[z], params, min_mask_area=50)[0]) for e_ in engines]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    # warm-up: workspaces, hipGraph capture, communicator
+    warm = torch.stack([pool[i % len(pool)] for i in range(2 * len(engines) * max(1, world))])
+    segment_volume_sharded(warm, fns_for(warm), stitch=True, min_mask_area=100, engine=eng)
+    sync_all()
+    base = {"unit": "slices/s", "n_gpus": world, "steps": 1, "warmup": 1, "higher_is_better": True, "vs_baseline": None, "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "fp16", "fp8": "bf16 operands, e4m3 weights", "mxfp8": "mxfp8 operands on the fp8 MFMA (qkv / fc1 / fc2 of stages 2-3), bf16 elsewhere"}[a.dtype]}
+    note = " [REHEARSAL on one GPU (gloo): not a multi-GPU measurement]" if rehearsal else ""
+    if a.volume > 0:
+        Z = a.volume
+        vol = torch.stack([pool[z % len(pool)] for z in range(Z)])            # (Z, 1024, 1024) uint16 in HBM
+        z0, z1 = shard_bounds(Z, world, rank)
+        sync_all()
+        t0 = time.perf_counter()
+        planes = segment_volume_sharded(vol, fns_for(vol), stitch=False, engine=eng)      # local chunk + all-gather; host planes (Z, H, W) uint16
+        t_seg = time.perf_counter() - t0
+        sync_all()
+        # the timed form: segment + gather + device stitch, labels left on the device of every rank (the D2H copy of the uint32 volume is reported beside it)
+        t0 = time.perf_counter()
+        labels = segment_volume_sharded(vol, fns_for(vol), stitch=True, min_mask_area=100, engine=eng)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt, t_seg], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, t_seg = float(t[0].item()), float(t[1].item())
+        return dict(base, metric="EM slices/sec (1024^2, Hiera-L), one tomogram z-sharded", value=Z / dt, ms_per_step=dt * 1e3, scaling="strong",
+                    config={"workload": f"ONE 1024x1024x{Z} uint16 tomogram (BASELINE configs[{2 if Z <= 64 else 3}]): per slice prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults) -> dedup/sort -> label plane; "
+                                        f"contiguous z-chunks over {world} rank(s) x {len(engines)} engine handles, ONE all-gather of the uint16 planes, 3-D connected components "
+                                        f"(saber_separate_masks) on the device, uint32 labels back on the host: all inside the timed region" + note,
+                            "slices": Z, "labels": int(labels.max()) if labels.size else 0, "parallelism": f"STRONG scaling: total work fixed at {Z} slices"},
+                    without_stitch={"slices_per_s": Z / t_seg, "seconds": t_seg, "what": "the same run up to and including the all-gather and the D2H of the planes, no 3-D connected components"},
+                    seconds=dt)
+    T, Zt = a.tomograms, a.tomogram_slices
+    mine = [t for t in range(T) if t % world == rank]             # GPUPool: task i -> GPU i % n_gpus
+    vols = {t: torch.stack([pool[(z + t) % len(pool)] for z in range(Zt)]) for t in mine}
+    sync_all()
+    t0 = time.perf_counter()
+    n_lab = 0
+    for t in mine:
+        planes_dev = torch.zeros((Zt, 1024, 1024), dtype=torch.int16, device=dev)
+        fns = fns_for(vols[t])
+        import threading
+        errs = []
+
+        def work(w, fns=fns, planes_dev=planes_dev):
+            try:
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    for z in range(w, Zt, len(fns)):
+                        planes_dev[z] = fns[w](z).view(torch.int16)
+                    st.synchronize()
+            except Exception as ex:
+                errs.append(ex)
+        th = [threading.Thread(target=work, args=(w,)) for w in range(len(fns))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errs:
+            raise errs[0]
+        labels, n = eng.separate_masks(planes_dev, min_mask_area=100)
+        n_lab += n
+        labels_host = labels.cpu()                                   # each tomogram's labels leave the GPU, as the reference's writer would take them
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dict(base, metric="EM slices/sec (1024^2, Hiera-L), batch of tomograms, one per GPU at a time", value=T * Zt / dt, ms_per_step=dt * 1e3, scaling="strong",
+                config={"workload": f"{T} tomograms of 1024x1024x{Zt} uint16 (BASELINE configs[4]) dealt round-robin to {world} rank(s) (reference GPUPool: task i -> GPU i % n_gpus), each: slice loop on "
+                                    f"{len(engines)} engine handles -> 3-D connected components on its GPU -> uint32 labels to the host; no data-path collective" + note,
+                        "tomograms": T, "slices_per_tomogram": Zt, "labels_rank0": n_lab, "hipgraph_replay": os.environ.get("SABER_AMD_GRAPHS", "1") != "0",
+                        "parallelism": f"total work fixed at {T} tomograms; rank r takes tomograms r, r + {world}, ..."},
+                seconds=dt)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -291,6 +391,15 @@ def main():
         return sum(totals)
 
     img01_cpu = eng.prepare(pool[0]).cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None      # (input of the CPU baseline leg)
+    if a.volume > 0 or a.tomograms > 0:
+        out = volume_modes(a, rank, world, rehearsal, engines, pool, params, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        for e_ in engines:
+            e_.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     run_steps(0, max(a.warmup, len(engines) if a.warmup else 0))
     planes = torch.zeros((a.steps, 1024, 1024), dtype=torch.uint16, device="cuda")
     gathered = torch.zeros((world * a.steps, 1024, 1024), dtype=torch.uint16, device="cuda") if world > 1 else None

@@ -42,6 +42,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define RL_SPLIT 1
 #define RL_Q1 1
 #define RL_Q2 3
+// The timing-only switches of tools/rowln_bench.py (DBG=1024|2048|4096|8192|32768, the late-start sweep) exist in development builds only
+// (make EXTRA=-DRL_DEV=1 BUILD=build_dev LIB=...): as run-time tests inside the K loop they cost a live register and a branch around every
+// MFMA group, which pushed the fp16 build of the <2,4> configuration into spilling inside the loop.
+#ifndef RL_DEV
+#define RL_DEV 0
+#endif
+#define RL_DBG(bit) (RL_DEV && (p.dbg & (bit)))
 #ifndef RL_ANTIPHASE
 #define RL_ANTIPHASE 1               // the two waves of a SIMD issue their transfers at different points of the K-step (0: the lockstep loop of round 2)
 #endif
@@ -79,18 +86,21 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
     // rows.  Both operands go through buffer descriptors: ONE 32-bit offset register per piece, the K-step in the scalar offset, rows
     // beyond M (and the K tail of A beyond the buffer) read as zero by the range check.  Every wave issues exactly NQ pieces per
     // K-step (the surplus ones repeat the last W piece: same bytes, same place) so that the counted vmcnt is the same for all waves.
-    const int lrow = lane >> 2;
-    const int lchunk = (lane & 3) ^ rl_perm(lrow);            // logical 16-B chunk that lands at physical slot lane & 3
-    uint32_t voff[NQ];
-    int ldsoff[NQ];
+    // Per-lane offsets of the pieces are NOT kept in registers across the K loop: issue() re-derives them from the lane id (v_mbcnt through
+    // volatile asm, so that the compiler can neither hoist the arithmetic out of the loop nor keep its results alive) - ~12 VALU
+    // instructions per call against 36 MFMAs per K-step.  With the offsets live (first one register per piece, then two in all) the fp16
+    // build of the <2,4> / <4,2> configurations (144 accumulator registers of 256) spilled them and reloaded them in front of every issue,
+    // behind an s_waitcnt vmcnt(0) that drained the LDS-DMA ring: 584 us against 349 us on the fc2 shape (round 4; the bf16 build happened
+    // to keep them).  The W pieces' index is wave-uniform and goes into the scalar offset.
+    int ldsoff[NQ], woff_s[NQ];                               // wave-uniform (scalar registers)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (q * 8 < RA) {
-            voff[q] = (uint32_t)(((wave + 8 * q) * 16 + lrow) * (int)p.lda * 2 + lchunk * 16);
             ldsoff[q] = (wave + 8 * q) * 1024;
+            woff_s[q] = 0;
         } else {
             const int wp = min(wave + 8 * q - RA, RW - 1);      // wave-uniform
-            voff[q] = (uint32_t)(wp * 1024 + lane * 16);        // packed W: the K-step's tile is a straight copy
+            woff_s[q] = wp * 1024;
             ldsoff[q] = (RA + wp) * 1024;
         }
     }
@@ -104,11 +114,18 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         const int arows = min(R, p.M - tile * R);
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)tile * R * p.lda), 0, (int)((uint32_t)arows * (uint32_t)p.lda * 2u), 0x00020000);
         char* st = smem + (kt % 3) * STAGE;
+        uint32_t ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));      // lane id, opaque (see above)
+        const int lr = (int)(ln >> 2);
+        const uint32_t voff_a = (uint32_t)((wave * 16 + lr) * (int)p.lda * 2) + (((ln & 3u) ^ (uint32_t)rl_perm(lr)) << 4);   // logical 16-B chunk that lands at physical slot lane & 3
+        const uint32_t voff_w = ln * 16u;                         // packed W: the K-step's tile is a straight copy
+        const int qstride = 128 * (int)p.lda * 2;                 // bytes between the A pieces of one wave (8 pieces x 16 rows)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (q < q0 || q >= q1) continue;
-            if (q * 8 < RA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], kt * (RL_BK * 2), 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff[q], (int)(kt * (CF::N * 64)), 0, 0);
+            // (the row part of an A piece stays in the VECTOR offset: the descriptor's range check - rows beyond M read as zero - looks at it)
+            if (q * 8 < RA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lptr_r)(st + ldsoff[q]), 16, (int)(voff_a + (uint32_t)(q * qstride)), kt * (RL_BK * 2), 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff_w, (int)(kt * (CF::N * 64)) + woff_s[q], 0, 0);
         }
     };
     static_assert(NQ == 6 || NQ == 5, "piece counts handled: 5 or 6 per wave");
@@ -124,9 +141,9 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
     // stage 1 556 -> 535 / 807 -> 776 us (tools/rowln_bench.py; delaying workgroups WITH a full walk loses, as it must).
     {
         const int my_tiles = (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1, max_tiles = (tiles - 1) / (int)gridDim.x + 1;
-        if (my_tiles < max_tiles && !(p.dbg & 32768)) {
+        if (my_tiles < max_tiles && !RL_DBG(32768)) {
             unsigned long long late = 1080ull * (unsigned)nk + 40000ull;                // shader cycles: 0.4 x (2 700 per K-step + ~100 000 of epilogue)
-            if ((p.dbg >> 21) & 127) late = (unsigned long long)((p.dbg >> 21) & 127) * 4096ull;      // development: tools/rowln_bench.py DBGS sweep (micro-benchmark only: the decoder reads these bits too)
+            if (RL_DEV && ((p.dbg >> 21) & 127)) late = (unsigned long long)((p.dbg >> 21) & 127) * 4096ull;      // development: tools/rowln_bench.py DBGS sweep (micro-benchmark only: the decoder reads these bits too)
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while (__builtin_amdgcn_s_memtime() - t0 < late) __builtin_amdgcn_s_sleep(32);
         }
@@ -158,20 +175,24 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             const char* sa = smem + (kt % 3) * STAGE;
             const char* sw = sa + RA * 1024;
             if (!PH && more) issue(wrsrc, t, kt + 2, 0, 2);
+            // fragment addresses from a fresh (opaque) lane id: like the pieces' offsets they must not live across the K loop (see issue())
+            uint32_t lk;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lk));
+            const int kfi = (int)(lk & 15u), kfg = (int)(lk >> 4);
             op16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + rl_swz(wm * 64 + i * 16 + kfi, kfg));
 #pragma unroll
             for (int jg = 0; jg < 3; ++jg) {
                 op16x8 wf[3];
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const op16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
+                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const op16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + kfi, kfg));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj)
-                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = MFMA_16x16x32(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+                        if (!RL_DBG(8192)) acc[i][jg * 3 + jj] = MFMA_16x16x32(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     if (!PH) { if (jg == 0) issue(wrsrc, t, kt + 2, 2, 4); else if (jg == 1) issue(wrsrc, t, kt + 2, 4, NQ); }
@@ -196,19 +217,22 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             const char* sw = sa + RA * 1024;
             // fragments in three column groups of 3 tiles: 16 + 12 live operand registers instead of 52 (the kernel lives on 256 VGPRs
             // with 144 of them accumulators)
+            uint32_t lk;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lk));      // (see the anti-phase loop)
+            const int kfi = (int)(lk & 15u), kfg = (int)(lk >> 4);
             op16x8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + rl_swz(wm * 64 + i * 16 + fi, fg));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const op16x8*>(sa + rl_swz(wm * 64 + i * 16 + kfi, kfg));
 #pragma unroll
             for (int jg = 0; jg < 3; ++jg) {
                 op16x8 wf[3];
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const op16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + fi, fg));
+                for (int jj = 0; jj < 3; ++jj) wf[jj] = *reinterpret_cast<const op16x8*>(sw + rl_swz(wn * 144 + (jg * 3 + jj) * 16 + kfi, kfg));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj)
-                        if (!(p.dbg & 8192)) acc[i][jg * 3 + jj] = MFMA_16x16x32(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
+                        if (!RL_DBG(8192)) acc[i][jg * 3 + jj] = MFMA_16x16x32(wf[jj], af[i], acc[i][jg * 3 + jj], 0, 0, 0);
 #if RL_SPLIT
                 if (kt + 2 < nk) { if (jg == 0) issue(wrsrc, t, kt + 2, RL_Q1, RL_Q2); else if (jg == 1) issue(wrsrc, t, kt + 2, RL_Q2, NQ); }
 #endif
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
         const uint32_t roff = (uint32_t)((trow * (int)ldr + ncol) * 4), coff = (uint32_t)((trow * (int)p.ldcf + ncol) * 4);
         const uint32_t rstep = (uint32_t)(16 * (int)ldr * 4), cstep = (uint32_t)(16 * (int)p.ldcf * 4);
         const bool has_res = p.res != nullptr;
-        const bool dbg_nores = p.dbg & 1024, dbg_nof32 = p.dbg & 2048, dbg_nobf = p.dbg & 4096;   // development: timing-only switches (tools/rowln_bench.py)
+        const bool dbg_nores = RL_DBG(1024), dbg_nof32 = RL_DBG(2048), dbg_nobf = RL_DBG(4096);   // development: timing-only switches (tools/rowln_bench.py)
         // No direct-to-LDS load is in flight here (the last K-step ended with vmcnt(0)), so hipcc counts these loads instead of draining
         // the queue at every use; the residual rows of group i + 1 are requested before group i is added and stored.
         u32x4 ra[9], rb[9];

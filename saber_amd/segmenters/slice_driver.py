@@ -116,7 +116,14 @@ def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area:
     if world > 1:
         full = torch.empty((world * chunk, H, W), dtype=torch.int16, device=dev)
         # byte view: gloo (CPU tests) has no int16 collectives; RCCL moves the same bytes
-        dist.all_gather_into_tensor(full.view(torch.uint8), local.view(torch.uint8), group=group)
+        if local.is_cuda and dist.get_backend(group) != "nccl":
+            # device planes under a host backend (the one-GPU rehearsal of the multi-rank control flow, bench.py SABER_AMD_BENCH_REHEARSAL=1):
+            # staged through host memory
+            host = torch.empty(full.view(torch.uint8).shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, local.view(torch.uint8).cpu(), group=group)
+            full.view(torch.uint8).copy_(host)
+        else:
+            dist.all_gather_into_tensor(full.view(torch.uint8), local.view(torch.uint8), group=group)
     else:
         full = local
     if stitch and engine is not None and full.is_cuda:
