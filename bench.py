@@ -50,6 +50,8 @@ def parse():
                     "(the reference's GPUPool semantics, saber/utils/parallelization.py:137-151: task i -> GPU i %% n_gpus), each segmented and stitched on its own GPU, "
                     "no data-path collective; value = all slices / max-over-ranks seconds")
     ap.add_argument("--tomogram-slices", type=int, default=256, help="slices per tomogram of --tomograms (configs[4]: 256)")
+    ap.add_argument("--cu-split", type=int, default=0, metavar="N", help="co-residency experiment (DESIGN.md section 4): every handle's decoder kernels on a stream "
+                    "restricted to CUs 0..N-1, its encoder passes on a stream restricted to CUs N..255 (hipExtStreamCreateWithCUMask); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-encoder-only", action="store_true", help="skip the extra encoder-only timing (profiling runs: keeps the kernel population of the trace = whole slices)")
@@ -361,6 +363,16 @@ def main():
 
     engines = [eng] + [mk_engine(a.dtype) for _ in range(a.workers - 1)]
     streams = [torch.cuda.Stream() for _ in engines]
+    if a.cu_split > 0:
+        import ctypes as C_
+        raw = []
+        for w, e_ in enumerate(engines):
+            hd, he = C_.c_void_p(), C_.c_void_p()
+            assert e_.lib.saber_k_stream_create_cu_range(0, a.cu_split, C_.byref(hd)) == 0, e_.lib.saber_k_last_error()
+            assert e_.lib.saber_k_stream_create_cu_range(a.cu_split, 256 - a.cu_split, C_.byref(he)) == 0, e_.lib.saber_k_last_error()
+            streams[w] = torch.cuda.ExternalStream(hd.value)
+            e_.set_encoder_stream(he.value)
+            raw += [hd, he]
     # The headline runs with the m2m IoU pruning OFF (every one of the 9 216 refined candidates is upscaled, as in rounds 1-2): how much work the
     # production default (pruning on, identical results) skips depends on the IoU head - a property of the weights, not of the kernels - so the
     # metric does not lean on it.  The time with pruning on and the fraction it pruned are reported beside it (`iou_pruning`).

@@ -197,6 +197,10 @@ int saber_engine_set_precision(saber_engine* e, int precision);
  * replayed from then on (needs a non-default stream; on by default, SABER_AMD_GRAPHS=0 or saber_engine_set_graphs(e, 0) turns it off).
  * saber_engine_graph_stats: sequences captured / replayed so far on this handle. */
 int saber_engine_set_graphs(saber_engine* e, int enable);
+/* Co-residency experiment (round 4): the batched encoder passes of saber_amg_generate run on `stream` instead of the
+ * call's own stream (fenced by events on both sides: results are identical); NULL restores the default.  With CU-masked streams
+ * (saber_k_stream_create_cu_range) one handle's MFMA-bound encoder and another handle's HBM-bound decoder can be given disjoint sets of CUs. */
+int saber_engine_set_encoder_stream(saber_engine* e, void* stream);
 int saber_engine_graph_stats(const saber_engine* e, int* captures, int* replays);
 
 /* Host synchronisations (hipStreamSynchronize) the last saber_amg_generate call on this handle needed: 2 per group of crops decoded

@@ -72,6 +72,7 @@ SIGNATURES = {
     "saber_engine_set_device_amg": (_i, [_vp, _i]),
     "saber_amg_last_pruning": (_i, [_vp, _vp, _vp]),
     "saber_engine_set_graphs": (_i, [_vp, _i]),
+    "saber_engine_set_encoder_stream": (_i, [_vp, _vp]),
     "saber_engine_set_weight_format": (_i, [_vp, _i]),
     "saber_engine_set_precision": (_i, [_vp, _i]),
     "saber_engine_graph_stats": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),

@@ -223,8 +223,20 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
             // the crop boxes go through the pinned buffer the (possibly replayed) H2D copy of eng_encode reads at execution time
             if (!e->crops_pin) ENG_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->crops_pin), sizeof(int) * 256 * 8));
             std::copy(cb.begin(), cb.begin() + 4 * ncb, e->crops_pin);
-            TRY(eng_graphed(e, "enc," + key_of({(long long)(uintptr_t)img, H, W, channels, ncb, c0, prm->crop_n_layers, (long long)(prm->crop_overlap_ratio * 1e6)}), s,
-                            [&]() { return eng_encode(e, img, H, W, channels, e->crops_pin, ncb, 0, s); }));
+            // (saber_engine_set_encoder_stream: the pass runs on the engine's encoder stream - e.g. one restricted to a subset of the CUs -
+            // after everything queued on s so far, and s continues after it)
+            hipStream_t es = e->enc_stream ? e->enc_stream : s;
+            if (es != s) {
+                for (int k = 0; k < 2; ++k) if (!e->enc_ev[k]) ENG_HIP(e, hipEventCreateWithFlags(&e->enc_ev[k], hipEventDisableTiming));
+                ENG_HIP(e, hipEventRecord(e->enc_ev[0], s));
+                ENG_HIP(e, hipStreamWaitEvent(es, e->enc_ev[0], 0));
+            }
+            TRY(eng_graphed(e, "enc," + key_of({(long long)(uintptr_t)img, H, W, channels, ncb, c0, prm->crop_n_layers, (long long)(prm->crop_overlap_ratio * 1e6), (long long)(uintptr_t)es}), es,
+                            [&]() { return eng_encode(e, img, H, W, channels, e->crops_pin, ncb, 0, es); }));
+            if (es != s) {
+                ENG_HIP(e, hipEventRecord(e->enc_ev[1], es));
+                ENG_HIP(e, hipStreamWaitEvent(s, e->enc_ev[1], 0));
+            }
             // host-side bookkeeping of eng_encode, which a replay does not execute
             for (int i = 0; i < ncb; ++i) { e->slot_valid[i] = 1; e->slot_shared_valid[i] = 0; e->slot_embb_valid[i] = 0; }
         }

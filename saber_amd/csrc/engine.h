@@ -141,6 +141,10 @@ struct saber_engine {
     int crops_next = 1;
     int *rm_to_eng = nullptr, *eng_to_rm = nullptr;   // 64x64 grid: row-major (y * 64 + x) <-> engine token order (video path, on demand)
     int amg_last_syncs = 0;           // host synchronisations of the last saber_amg_generate call (saber_amg_last_syncs)
+    // co-residency experiment (saber_engine_set_encoder_stream): the mask generator's encoder passes run on this stream, fenced against the
+    // caller's stream by two events; nullptr = everything on the caller's stream
+    hipStream_t enc_stream = nullptr;
+    hipEvent_t enc_ev[2] = {nullptr, nullptr};
 
     // optional per-launch HIP-event profiling (saber_profile_begin / saber_profile_end)
     bool prof_on = false;

@@ -160,6 +160,11 @@ extern "C" int saber_engine_set_iou_pruning(saber_engine* e, int enable) {
     if ((bool)enable != e->iou_prune) { e->iou_prune = enable != 0; eng_graphs_flush(e); }      // (captured decode sequences contain the choice)
     return SABER_OK;
 }
+extern "C" int saber_engine_set_encoder_stream(saber_engine* e, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if ((hipStream_t)stream != e->enc_stream) { eng_graphs_flush(e); e->enc_stream = (hipStream_t)stream; }     // (captured encoder passes belong to their stream)
+    return SABER_OK;
+}
 extern "C" int saber_engine_set_graphs(saber_engine* e, int enable) {
     if (!e) return SABER_ERR_INVALID;
     e->graphs_on = enable != 0;
@@ -217,6 +222,7 @@ extern "C" void saber_engine_destroy(saber_engine* e) {
     exact_release(e);
     if (e->crops_pin) (void)hipHostFree(e->crops_pin);
     for (hipEvent_t ev : e->crops_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->enc_ev) if (ev) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmParams p) {
             if (q < q0 || q >= q1) continue;
             // (the row part of an A piece stays in the VECTOR offset: the descriptor's range check - rows beyond M read as zero - looks at it)
             if (q * 8 < RA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lptr_r)(st + ldsoff[q]), 16, (int)(voff_a + (uint32_t)(q * qstride)), kt * (RL_BK * 2), 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff_w, (int)(kt * (CF::N * 64)) + woff_s[q], 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_r)(st + ldsoff[q]), 16, (int)voff_w, (int)(kt * (CF::N * 64) + woff_s[q]), 0, 0);      // (explicit casts: a type-dependent argument - woff_s has a template-dependent bound - silently drops the kernel's HOST stub)
         }
     };
     static_assert(NQ == 6 || NQ == 5, "piece counts handled: 5 or 6 per wave");

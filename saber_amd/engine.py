@@ -267,6 +267,10 @@ class Engine:
         self._check(self.lib.saber_engine_set_precision(self.h, {"bf16": 0, "exact": 1, "fp16": 2}[precision]))
         self.precision = precision
 
+    def set_encoder_stream(self, stream_ptr):
+        """The mask generator's encoder passes on another HIP stream (include/saber_amd.h: saber_engine_set_encoder_stream); None = default."""
+        self._check(self.lib.saber_engine_set_encoder_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
     def set_device_amg(self, enable: bool):
         """Filters / NMS / compaction of the mask generator on the device (default) or on the host (include/saber_amd.h: saber_engine_set_device_amg)."""
         self._check(self.lib.saber_engine_set_device_amg(self.h, int(bool(enable))))
