@@ -85,9 +85,10 @@ class SAM2Adapter(BaseAdapter):
         return state.add_new_mask(frame_idx, obj_id, mask)
 
     def add_new_points_or_box(self, frame_idx: int, obj_id: int, inference_state=None, **kwargs) -> Tuple:
-        """predictor.py:171-180: delegates to the video predictor (points=, labels=, clear_old_points=, normalize_coords=, box=).  Built for
-        one click per call on a frame that has not been tracked yet; boxes, several clicks and corrections raise NotImplementedError
-        (no SABER caller uses them: segmenters/base.py:265-280 seeds propagation with masks)."""
+        """predictor.py:171-180: delegates to the video predictor (points=, labels=, clear_old_points=, normalize_coords=, box=).  Clicks,
+        several clicks per call, boxes and corrections of tracked frames follow upstream (adapters/sam2/video.py); prompts of more than one
+        point are decoded in the engine's exact precision mode, which the handle must have been created with (NotImplementedError says so
+        otherwise).  No SABER caller uses them: segmenters/base.py:265-280 seeds propagation with masks."""
         state = inference_state or self.inference_state
         if state is None:
             raise RuntimeError("Call set_volume() before add_new_points_or_box().")

