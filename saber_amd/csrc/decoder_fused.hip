@@ -850,13 +850,28 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 // GELU outputs feed phase B straight from registers (k-slot permutation, W2 pre-permuted on the host).
 // Phase B: [(pos w, 32 tok)] x [128 = pos2*32+ch2] over K=64, epilogue = +feat_s0, GELU, 4 dot products with hyper.
 // The 32-channel 256x256 upscaled embedding (8 MB fp32 per prompt) never exists in memory.
-#define UP_TOK 32
-// Experiment (round 3, off): the hypernetwork product on the matrix cores.  -55 static VALU instructions per prompt (7 %), 26 registers
-// fewer, the same 26 ms per slice on the same box, +4 % decoder error (u2 rounded to bf16): the kernel is not bound by the VALU work
-// of that product.  make EXTRA=-DUP_MFMA_HYPER=1 builds it.
-#ifndef UP_MFMA_HYPER
-#define UP_MFMA_HYPER 0
+// Round 4: THREE waves per SIMD.  SQ counters under the 8-wave kernel (profiles/r04_upscale_sq_counters.txt, tools/upscale_pmc.sh): a wave
+// spends 46 % of its cycles executing VALU instructions (703 per prompt at 4.6 cycles each: a single wave issues one VALU instruction per
+// 4 cycles, the SIMD-32 pipe takes one per 2), 29 % waiting to issue and 17 % parked at a waitcnt; compile-time ablations (UP_ABL,
+// tools/upscale_ablate.sh): GELU -33 %, hypernetwork product -13 %, X loads -3 %, LayerNorm reductions / stores / MFMAs ~0, everything
+// arithmetic off: still 49 % (the 48 weight-fragment reads per wave and prompt, 384 KB of LDS traffic per prompt and CU).  So the kernel is
+// bound by instruction latency at two waves per SIMD, not by a pipe: the fix is a third wave, which needs <= 168 registers (220 before):
+//   * the hypernetwork product runs on the matrix cores (the round-3 experiment UP_MFMA_HYPER: 8 operand registers instead of 32; u2 is
+//     rounded to the 16-bit operand type there),
+//   * the LayerNorm gain / bias live in 512 B of LDS instead of 32 registers,
+//   * X rows are addressed through a per-prompt buffer descriptor (one 32-bit lane offset).
+// 12 waves = 4 ConvT1 positions x UP_NTG = 3 groups of 16 tokens: a tile is 48 tokens, 4096 = 85 x 48 + 16, so the (tile, prompt) units are
+// dealt to ONE resident workgroup per CU as equal contiguous ranges (tile-major) instead of a tile per workgroup.
+// make EXTRA="-DUP_NTG=2 -DUP_MFMA_HYPER=0" rebuilds the round-3 configuration (8 waves, VALU hypernetwork product) for A/Bs.
+#ifndef UP_NTG
+#define UP_NTG 3
 #endif
+#ifndef UP_MFMA_HYPER
+#define UP_MFMA_HYPER 1
+#endif
+#define UP_TOK (16 * UP_NTG)
+#define UP_TILES ((4096 + UP_TOK - 1) / UP_TOK)
+#define UP_THREADS (256 * UP_NTG)
 // Development build (make EXTRA=-DUP_DEV=1 BUILD=build_dev LIB=../libsaber_amd_dev.so; tools/upscale_ablate.py): run-time switches that
 // take single pieces of the prompt loop away (results are garbage) and per-phase s_memtime stamps, to see what the kernel's time is made
 // of.  0 in the shipped library: every UPD(..) below folds to false and the stamps disappear.
@@ -872,248 +887,261 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 enum { UPD_NO_GELU = 1, UPD_NO_W1_READ = 2, UPD_NO_W2_READ = 4, UPD_NO_STORE = 8, UPD_NO_HYPER = 16, UPD_NO_XLOAD = 32, UPD_NO_LN = 64, UPD_NO_MFMA_A = 128, UPD_NO_MFMA_B = 256 };
 #define UP_W1S (256 * ROW_B)          // W1 [256 n][256 k] bf16, kswz
 #define UP_W2S (128 * 128)            // W2p [128 n2][64] bf16 (k-slots pre-permuted), swz128
-#define UP_LDS (UP_W1S + UP_W2S)
+#define UP_LNS 512                    // LayerNorm gain [64] + bias [64], fp32
+#define UP_LDS (UP_W1S + UP_W2S + UP_LNS)
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(512) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
-                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                          const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
-                                                          const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
-                                                          const float* __restrict__ hyper, float* __restrict__ masks4, int P, int groups,
-                                                          const uint8_t* __restrict__ live, const float* __restrict__ iou4, int multimask, int dbg,
-                                                          unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                                 const bf16_t* __restrict__ W2p, const float* __restrict__ b2,
+                                                                 const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
+                                                                 const float* __restrict__ hyper, float* __restrict__ masks4, int P,
+                                                                 const uint8_t* __restrict__ live, const float* __restrict__ iou4, int multimask, int dbg,
+                                                                 unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
+    char* w2s = w1s + UP_W1S;
+    float* lnp = reinterpret_cast<float*>(w2s + UP_W2S);
     unsigned long long ts[5] = {0, 0, 0, 0, 0}, tprev = 0;
 #define UP_STAMP(k) do { if (UP_DEV && stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
-    char* w2s = w1s + UP_W1S;
-    // 8 waves (two per SIMD: the epilogues are VALU-bound, a lone wave would issue at half rate):
-    // wave = (token half mw) * 4 + (pos = ConvT1 output position)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = wave & 3, mw = wave >> 2;
+    // wave = (token group tg) * 4 + (pos = ConvT1 output position); UP_NTG waves per SIMD (the epilogues are bound by VALU latency: see above)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pos = wave & 3, tg = wave >> 2;
     const int fi = lane & 15, fg = lane >> 4;
-    const int tile = blockIdx.x % 128, grp = blockIdx.x / 128;
 
     // resident weights
-    for (int idx = tid; idx < 256 * 32; idx += 512) {
+    for (int idx = tid; idx < 256 * 32; idx += UP_THREADS) {
         const int row = idx >> 5, ch = idx & 31;
         *reinterpret_cast<u32x4*>(w1s + kswz(row, ch)) = *reinterpret_cast<const u32x4*>(W1 + row * 256 + ch * 8);
     }
-    for (int idx = tid; idx < 128 * 8; idx += 512) {
+    for (int idx = tid; idx < 128 * 8; idx += UP_THREADS) {
         const int row = idx >> 3, ch = idx & 7;
         *reinterpret_cast<u32x4*>(w2s + swz128(row, ch)) = *reinterpret_cast<const u32x4*>(W2p + row * 64 + ch * 8);
     }
-    // per-lane constants of this tile: feat_s1 + b1 and feat_s0 + b2 (fp32: they are the C operands of the first MFMA of their
-    // accumulator, so adding them costs nothing), LN parameters
-    const int tl = mw * 16 + fi;                        // token within the tile: bits [X3 X2 X1][Y0][X0]
-    const int tok = tile * UP_TOK + tl;
-    float4 f1[4], gg[4], be[4];
-    f32x4 f0[4][2];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        gg[ni] = *reinterpret_cast<const float4*>(ln_g + ni * 16 + 4 * fg);
-        be[ni] = *reinterpret_cast<const float4*>(ln_b + ni * 16 + 4 * fg);
-    }
-    // the high-resolution features belong to the crop (slot) of the prompt: prompts of one slot are contiguous, so a block
-    // re-reads them only when its prompt sequence crosses into the next slot
-    int cur_slot = -1;
-    auto load_feats = [&](int slot) {
-        const float* s1 = fs1 + (int64_t)slot * 16384 * 64;
-        const float* s0 = fs0 + (int64_t)slot * 65536 * 32;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const float4 r = *reinterpret_cast<const float4*>(s1 + ((int64_t)tok * 4 + pos) * 64 + ni * 16 + 4 * fg);
-            const float4 b = *reinterpret_cast<const float4*>(b1 + pos * 64 + ni * 16 + 4 * fg);
-            f1[ni] = make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
-        }
-#pragma unroll
-        for (int pos2 = 0; pos2 < 4; ++pos2)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const float4 r = *reinterpret_cast<const float4*>(s0 + (((int64_t)tok * 4 + pos) * 4 + pos2) * 32 + hh * 16 + 4 * fg);
-                const float4 b = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
-                f0[pos2][hh] = (f32x4){r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w};
-            }
-    };
-    const int dy1 = pos >> 1, dx1 = pos & 1;
-    const int ty = (tl >> 1) & 1, tx = ((tl >> 2) & 7) * 2 + (tl & 1);
-    int ty0, tx0;
-    perm_coords(tile * UP_TOK, 2, &ty0, &tx0);
-
-    // B-operand fragments of the wave's 16 tokens: lane (fi, fg) holds X[tok][32 ks + 8 fg .. +7], ks = 0..7
-    const int64_t xrow = ((int64_t)tile * UP_TOK + tl) * DC + 8 * fg;
-    op16x8 xf[8];
-    auto xload = [&](int p, op16x8 (&dst)[8]) {
-        const bf16_t* Xt = X + (int64_t)p * 4096 * DC + xrow;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) dst[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const u32x4*>(Xt + 32 * ks));
-    };
-    // output pixels of this lane: token (gy, gx) on the 64x64 grid, ConvT1 position (dy1, dx1); mask k = fg
-    const int gy = ty0 + ty, gx = tx0 + tx;
-    const int64_t obase = ((int64_t)fg * 256 + gy * 4 + dy1 * 2) * 256 + gx * 4 + dx1 * 2;
-    const bool fb0 = fg & 1, fb1 = fg >> 1;
+    if (tid < 64) { lnp[tid] = ln_g[tid]; lnp[64 + tid] = ln_b[tid]; }
     __syncthreads();   // resident weights visible; the only workgroup barrier of the kernel
+
+    // this workgroup's share of the (tile, prompt) units, tile-major: [u0, u1)
+    const long long U = (long long)UP_TILES * P;
+    const long long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+    const int dy1 = pos >> 1, dx1 = pos & 1;
+    const bool fb0 = fg & 1, fb1 = fg >> 1;
     // live (optional): prompts whose flag is 0 are skipped altogether (their masks are never read: engine.hip decode_chunk, IoU pruning)
-    auto next_live = [&](int q) { while (live && q < P && !live[q]) q += groups; return q; };     // block-uniform
-    int p = next_live(grp);
-    if (p < P) xload(p, xf);
-    if (UP_DEV && stamps) tprev = __builtin_amdgcn_s_memtime();
-    for (int pn; p < P; p = pn) {
-        pn = next_live(p + groups);
-        // compiler fence: without it the loop-invariant weight fragments (32 + 16 ds_read_b128 per wave) are hoisted out of the
-        // prompt loop and spill
-        asm volatile("" ::: "memory");
-        {
-            const int slot = (p + s_off) / s_div;     // block-uniform
-            if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
-        }
-        // Planes anybody reads afterwards (iou4 given): a multimask decode returns masks 1-3; a single-mask decode returns mask 0 or, when
-        // that one is unstable, the best of 1-3 by predicted IoU (first maximum: mask_pick_kernel / mask_select_dynamic_kernel) - the other
-        // hypernetwork products and their 256-KB planes are skipped.  Block-uniform.
-        int need = 0xF;
-        if (iou4) {
-            if (multimask) need = 0xE;
-            else {
-                int best = 1;
-                float bv = iou4[p * 4 + 1];
-                if (iou4[p * 4 + 2] > bv) { bv = iou4[p * 4 + 2]; best = 2; }
-                if (iou4[p * 4 + 3] > bv) best = 3;
-                need = 1 | (1 << best);
-            }
-            need = __builtin_amdgcn_readfirstlane(need);
-        }
-#if UP_MFMA_HYPER
-        // The hypernetwork product masks[k] = hyper[k] . u2 on the matrix cores (instead of 128 FMAs + a 3-step lane transpose per lane and
-        // prompt).  A operand:
-        // row fi = mask fi >> 2 (each mask's row four times), k-slot 8 fg + j = channel 4 fg + j (j < 4) | 16 + 4 fg + (j - 4): the order
-        // phase B leaves its GELU outputs in, so they are packed into the B operand as they stand.  Every row 4 fg + r of the result is
-        // mask fg of token fi: the lane reads its own mask from register 0, no lane movement.  hyper enters as a bf16 hi + lo pair (two
-        // MFMAs, exact to 2^-17); u2 is rounded to bf16 (2^-9 per element, averaged over the 32-term sum).
-        op16x8 hy_hi, hy_lo;
-        {
-            const float* hp = hyper + (int64_t)p * 128 + (fi >> 2) * 32 + 4 * fg;
-            const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 16);
-            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            float l[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) l[j] = v[j] - op2f(f2op(v[j]));
-            hy_hi = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            hy_lo = pack8_d(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]);
-        }
-#else
-        float4 hy[2][4];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hyper + (int64_t)p * 128 + k * 32 + hh * 16 + 4 * fg);
-#endif
-        // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256
-        f32x4 acc[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){f1[ni].x, f1[ni].y, f1[ni].z, f1[ni].w};       // bias + feat_s1 enter as the C operand
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+    auto next_live = [&](int q, int qe) { while (live && q < qe && !live[q]) ++q; return q; };     // block-uniform
+
+    for (long long u = u0; u < u1;) {
+        const int tile = (int)(u / P);
+        const int p_begin = (int)(u - (long long)tile * P);
+        const int p_end = (int)((u1 - (long long)tile * P) < (long long)P ? (u1 - (long long)tile * P) : (long long)P);
+        u = (long long)tile * P + p_end;
+        const int tok = tile * UP_TOK + tg * 16 + fi;
+        if (tile * UP_TOK + tg * 16 >= 4096) continue;          // wave-uniform: the last tile holds 16 tokens (4096 = 85 x 48 + 16)
+        // per-lane constants of this tile: feat_s1 + b1 and feat_s0 + b2 (fp32: they are the C operands of the first MFMA of their
+        // accumulator, so adding them costs nothing)
+        float4 f1[4];
+        f32x4 f0[4][2];
+        // the high-resolution features belong to the crop (slot) of the prompt: prompts of one slot are contiguous, so a wave
+        // re-reads them only when its prompt sequence crosses into the next slot
+        int cur_slot = -1;
+        auto load_feats = [&](int slot) {
+            const float* s1 = fs1 + (int64_t)slot * 16384 * 64;
+            const float* s0 = fs0 + (int64_t)slot * 65536 * 32;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const op16x8 wf = *reinterpret_cast<const op16x8*>(w1s + (UPD(UPD_NO_W1_READ) ? kswz(fi, fg) : kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg)));
-                if (!UPD(UPD_NO_MFMA_A)) acc[ni] = MFMA_16x16x32(wf, xf[ks], acc[ni], 0, 0, 0);
-                else acc[ni][0] += __builtin_bit_cast(f32x4, wf)[0] + __builtin_bit_cast(f32x4, xf[ks])[0];
-            }
-        }
-        UP_STAMP(0);
-        // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
-        if (pn < P && !UPD(UPD_NO_XLOAD)) xload(pn, xf);
-        // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
-        op16x8 uf[2];
-        {
-            float v[4][4], sum = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                v[ni][0] = acc[ni][0]; v[ni][1] = acc[ni][1]; v[ni][2] = acc[ni][2]; v[ni][3] = acc[ni][3];
-                sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
-            }
-            if (!UPD(UPD_NO_LN)) sum = xor32_sum(xor16_sum(sum));
-            const float mean = sum * (1.0f / 64.0f);
-            float var = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
-            if (!UPD(UPD_NO_LN)) var = xor32_sum(xor16_sum(var));
-            const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / 64.0f) + 1e-6f);
-            const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                f32x2 a = ((f32x2){v[ni][0], v[ni][1]} - mean2) * rstd2 * (f32x2){gg[ni].x, gg[ni].y} + (f32x2){be[ni].x, be[ni].y};
-                f32x2 b = ((f32x2){v[ni][2], v[ni][3]} - mean2) * rstd2 * (f32x2){gg[ni].z, gg[ni].w} + (f32x2){be[ni].z, be[ni].w};
-                if (!UPD(UPD_NO_GELU)) { a = gelu_erf2(a); b = gelu_erf2(b); }
-                v[ni][0] = a.x; v[ni][1] = a.y; v[ni][2] = b.x; v[ni][3] = b.y;
+                const float4 r = *reinterpret_cast<const float4*>(s1 + ((int64_t)tok * 4 + pos) * 64 + ni * 16 + 4 * fg);
+                const float4 b = *reinterpret_cast<const float4*>(b1 + pos * 64 + ni * 16 + 4 * fg);
+                f1[ni] = make_float4(r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w);
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                uf[ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
-                                 v[2 * ks + 1][3]);
-        }
-        UP_STAMP(1);
-        // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
-        float* orow = masks4 + (int64_t)p * 4 * 65536 + obase;
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            f32x4 c2[4];
-#pragma unroll
-            for (int nl = 0; nl < 4; ++nl) c2[nl] = f0[2 * hb + (nl >> 1)][nl & 1];                       // bias + feat_s0 enter as the C operand
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int nl = 0; nl < 4; ++nl) {
-                    const op16x8 w2f = *reinterpret_cast<const op16x8*>(w2s + (UPD(UPD_NO_W2_READ) ? swz128(fi, fg) : swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg)));
-                    if (!UPD(UPD_NO_MFMA_B)) c2[nl] = MFMA_16x16x32(w2f, uf[ks], c2[nl], 0, 0, 0);
-                    else c2[nl][0] += __builtin_bit_cast(f32x4, w2f)[0] + __builtin_bit_cast(f32x4, uf[ks])[0];
-                }
-            UP_STAMP(2);
-            float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
-#if UP_MFMA_HYPER
-                const f32x2 ua0 = gelu_erf2((f32x2){c2[2 * pp][0], c2[2 * pp][1]}), ub0 = gelu_erf2((f32x2){c2[2 * pp][2], c2[2 * pp][3]});
-                const f32x2 ua1 = gelu_erf2((f32x2){c2[2 * pp + 1][0], c2[2 * pp + 1][1]}), ub1 = gelu_erf2((f32x2){c2[2 * pp + 1][2], c2[2 * pp + 1][3]});
-                const op16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
-                f32x4 dm = MFMA_16x16x32(hy_hi, uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dm = MFMA_16x16x32(hy_lo, uop, dm, 0, 0, 0);
-                if (pp == 0) px2.x = dm[0]; else px2.y = dm[0];
-                continue;
-#else
-                const int pos2 = 2 * hb + pp;
-                float part[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int pos2 = 0; pos2 < 4; ++pos2)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int nl = 2 * pp + hh;
-                    f32x2 ua = (f32x2){c2[nl][0], c2[nl][1]}, ub = (f32x2){c2[nl][2], c2[nl][3]};
-                    if (!UPD(UPD_NO_GELU)) { ua = gelu_erf2(ua); ub = gelu_erf2(ub); }
-                    const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
-                    if (UPD(UPD_NO_HYPER)) { part[hh] += u0 + u1 + u2 + u3; continue; }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if ((need >> k) & 1) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
+                    const float4 r = *reinterpret_cast<const float4*>(s0 + (((int64_t)tok * 4 + pos) * 4 + pos2) * 32 + hh * 16 + 4 * fg);
+                    const float4 b = *reinterpret_cast<const float4*>(b2 + pos2 * 32 + hh * 16 + 4 * fg);
+                    f0[pos2][hh] = (f32x4){r.x + b.x, r.y + b.y, r.z + b.z, r.w + b.w};
                 }
-                // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
-                // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
-                float k0 = fb0 ? part[1] : part[0], k1 = fb0 ? part[3] : part[2];
-                k0 += shfl_xor16(fb0 ? part[0] : part[1], (lane >> 4) & 1);
-                k1 += shfl_xor16(fb0 ? part[2] : part[3], (lane >> 4) & 1);
-                float mine = fb1 ? k1 : k0;
-                mine += shfl_xor32(fb1 ? k0 : k1, lane >= 32);
-                if (pp == 0) px2.x = mine; else px2.y = mine;
-#endif
+        };
+        // B-operand fragments of the wave's 16 tokens: lane (fi, fg) holds X[tok][32 ks + 8 fg .. +7], ks = 0..7; one 32-bit lane offset into
+        // a per-prompt buffer descriptor (the prompt's 2-MB state)
+        const uint32_t xoff = (uint32_t)((tok * DC + 8 * fg) * 2);
+        op16x8 xf[8];
+        auto xload = [&](int p, op16x8 (&dst)[8]) {
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (int64_t)p * 4096 * DC), 0, 4096 * DC * 2, 0x00020000);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) dst[ks] = __builtin_bit_cast(op16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff + 64 * ks, 0, 0));
+        };
+        // output pixels of this lane: token (gy, gx) on the 64x64 grid, ConvT1 position (dy1, dx1); mask k = fg
+        int gy, gx;
+        perm_coords(tok, 2, &gy, &gx);
+        const int64_t obase = ((int64_t)fg * 256 + gy * 4 + dy1 * 2) * 256 + gx * 4 + dx1 * 2;
+
+        int p = next_live(p_begin, p_end);
+        if (p < p_end) xload(p, xf);
+        if (UP_DEV && stamps) tprev = __builtin_amdgcn_s_memtime();
+        for (int pn; p < p_end; p = pn) {
+            pn = next_live(p + 1, p_end);
+            // compiler fence: without it the loop-invariant weight fragments (32 + 16 ds_read_b128 per wave) are hoisted out of the
+            // prompt loop and spill
+            asm volatile("" ::: "memory");
+            {
+                const int slot = (p + s_off) / s_div;     // block-uniform
+                if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
             }
-            UP_STAMP(3);
-            if (((need >> fg) & 1) && !UPD(UPD_NO_STORE)) *reinterpret_cast<float2*>(orow + hb * 256) = px2;
-            if (UPD(UPD_NO_STORE) && px2.x + px2.y == 1.2345e30f) *reinterpret_cast<float2*>(orow + hb * 256) = px2;     // (keeps the values alive)
+            // Planes anybody reads afterwards (iou4 given): a multimask decode returns masks 1-3; a single-mask decode returns mask 0 or, when
+            // that one is unstable, the best of 1-3 by predicted IoU (first maximum: mask_pick_kernel / mask_select_dynamic_kernel) - the other
+            // planes are not written (with the hypernetwork product on the VALU their dot products are skipped too).  Block-uniform.
+            int need = 0xF;
+            if (iou4) {
+                if (multimask) need = 0xE;
+                else {
+                    int best = 1;
+                    float bv = iou4[p * 4 + 1];
+                    if (iou4[p * 4 + 2] > bv) { bv = iou4[p * 4 + 2]; best = 2; }
+                    if (iou4[p * 4 + 3] > bv) best = 3;
+                    need = 1 | (1 << best);
+                }
+                need = __builtin_amdgcn_readfirstlane(need);
+            }
+#if UP_MFMA_HYPER
+            // The hypernetwork product masks[k] = hyper[k] . u2 on the matrix cores (instead of 128 FMAs + a 3-step lane transpose per lane and
+            // prompt).  A operand:
+            // row fi = mask fi >> 2 (each mask's row four times), k-slot 8 fg + j = channel 4 fg + j (j < 4) | 16 + 4 fg + (j - 4): the order
+            // phase B leaves its GELU outputs in, so they are packed into the B operand as they stand.  Every row 4 fg + r of the result is
+            // mask fg of token fi: the lane reads its own mask from register 0, no lane movement.  hyper enters as a hi + lo pair of the 16-bit
+            // operand type (two MFMAs, exact to 2^-17 / 2^-23); u2 is rounded to that type (2^-9 / 2^-12 per element, averaged over the 32-term sum).
+            op16x8 hy_hi, hy_lo;
+            {
+                const float* hp = hyper + (int64_t)p * 128 + (fi >> 2) * 32 + 4 * fg;
+                const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 16);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                float l[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) l[j] = v[j] - op2f(f2op(v[j]));
+                hy_hi = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                hy_lo = pack8_d(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]);
+            }
+#else
+            float4 hy[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hyper + (int64_t)p * 128 + k * 32 + hh * 16 + 4 * fg);
+#endif
+            // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256
+            f32x4 acc[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){f1[ni].x, f1[ni].y, f1[ni].z, f1[ni].w};       // bias + feat_s1 enter as the C operand
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const op16x8 wf = *reinterpret_cast<const op16x8*>(w1s + (UPD(UPD_NO_W1_READ) ? kswz(fi, fg) : kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg)));
+                    if (!UPD(UPD_NO_MFMA_A)) acc[ni] = MFMA_16x16x32(wf, xf[ks], acc[ni], 0, 0, 0);
+                    else acc[ni][0] += __builtin_bit_cast(f32x4, wf)[0] + __builtin_bit_cast(f32x4, xf[ks])[0];
+                }
+            }
+            UP_STAMP(0);
+            // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
+            if (pn < p_end && !UPD(UPD_NO_XLOAD)) xload(pn, xf);
+            // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
+            op16x8 uf[2];
+            {
+                float v[4][4], sum = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    v[ni][0] = acc[ni][0]; v[ni][1] = acc[ni][1]; v[ni][2] = acc[ni][2]; v[ni][3] = acc[ni][3];
+                    sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
+                }
+                if (!UPD(UPD_NO_LN)) sum = xor32_sum(xor16_sum(sum));
+                const float mean = sum * (1.0f / 64.0f);
+                float var = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = v[ni][r] - mean; var += d * d; }
+                if (!UPD(UPD_NO_LN)) var = xor32_sum(xor16_sum(var));
+                const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / 64.0f) + 1e-6f);
+                const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(lnp + ni * 16 + 4 * fg), b4 = *reinterpret_cast<const float4*>(lnp + 64 + ni * 16 + 4 * fg);
+                    f32x2 a = ((f32x2){v[ni][0], v[ni][1]} - mean2) * rstd2 * (f32x2){g4.x, g4.y} + (f32x2){b4.x, b4.y};
+                    f32x2 b = ((f32x2){v[ni][2], v[ni][3]} - mean2) * rstd2 * (f32x2){g4.z, g4.w} + (f32x2){b4.z, b4.w};
+                    if (!UPD(UPD_NO_GELU)) { a = gelu_erf2(a); b = gelu_erf2(b); }
+                    v[ni][0] = a.x; v[ni][1] = a.y; v[ni][2] = b.x; v[ni][3] = b.y;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    uf[ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
+                                     v[2 * ks + 1][3]);
+            }
+            UP_STAMP(1);
+            // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
+            float* orow = masks4 + (int64_t)p * 4 * 65536 + obase;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                f32x4 c2[4];
+#pragma unroll
+                for (int nl = 0; nl < 4; ++nl) c2[nl] = f0[2 * hb + (nl >> 1)][nl & 1];                       // bias + feat_s0 enter as the C operand
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nl = 0; nl < 4; ++nl) {
+                        const op16x8 w2f = *reinterpret_cast<const op16x8*>(w2s + (UPD(UPD_NO_W2_READ) ? swz128(fi, fg) : swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg)));
+                        if (!UPD(UPD_NO_MFMA_B)) c2[nl] = MFMA_16x16x32(w2f, uf[ks], c2[nl], 0, 0, 0);
+                        else c2[nl][0] += __builtin_bit_cast(f32x4, w2f)[0] + __builtin_bit_cast(f32x4, uf[ks])[0];
+                    }
+                UP_STAMP(2);
+                float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
+#if UP_MFMA_HYPER
+                    f32x2 ua0 = (f32x2){c2[2 * pp][0], c2[2 * pp][1]}, ub0 = (f32x2){c2[2 * pp][2], c2[2 * pp][3]};
+                    f32x2 ua1 = (f32x2){c2[2 * pp + 1][0], c2[2 * pp + 1][1]}, ub1 = (f32x2){c2[2 * pp + 1][2], c2[2 * pp + 1][3]};
+                    if (!UPD(UPD_NO_GELU)) { ua0 = gelu_erf2(ua0); ub0 = gelu_erf2(ub0); ua1 = gelu_erf2(ua1); ub1 = gelu_erf2(ub1); }
+                    float mine;
+                    if (UPD(UPD_NO_HYPER)) mine = ua0.x + ub0.y + ua1.x + ub1.y;
+                    else {
+                        const op16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
+                        f32x4 dm = MFMA_16x16x32(hy_hi, uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        dm = MFMA_16x16x32(hy_lo, uop, dm, 0, 0, 0);
+                        mine = dm[0];
+                    }
+                    if (pp == 0) px2.x = mine; else px2.y = mine;
+#else
+                    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int nl = 2 * pp + hh;
+                        f32x2 ua = (f32x2){c2[nl][0], c2[nl][1]}, ub = (f32x2){c2[nl][2], c2[nl][3]};
+                        if (!UPD(UPD_NO_GELU)) { ua = gelu_erf2(ua); ub = gelu_erf2(ub); }
+                        const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
+                        if (UPD(UPD_NO_HYPER)) { part[hh] += u0 + u1 + u2 + u3; continue; }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if ((need >> k) & 1) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
+                    }
+                    // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
+                    // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
+                    float k0 = fb0 ? part[1] : part[0], k1 = fb0 ? part[3] : part[2];
+                    k0 += shfl_xor16(fb0 ? part[0] : part[1], (lane >> 4) & 1);
+                    k1 += shfl_xor16(fb0 ? part[2] : part[3], (lane >> 4) & 1);
+                    float mine = fb1 ? k1 : k0;
+                    mine += shfl_xor32(fb1 ? k0 : k1, lane >= 32);
+                    if (pp == 0) px2.x = mine; else px2.y = mine;
+#endif
+                }
+                UP_STAMP(3);
+                if (((need >> fg) & 1) && !UPD(UPD_NO_STORE)) *reinterpret_cast<float2*>(orow + hb * 256) = px2;
+                if (UPD(UPD_NO_STORE) && px2.x + px2.y == 1.2345e30f) *reinterpret_cast<float2*>(orow + hb * 256) = px2;     // (keeps the values alive)
+            }
+            UP_STAMP(4);
         }
-        UP_STAMP(4);
     }
+    (void)fb0; (void)fb1;
     if (UP_DEV && stamps && lane == 0)
-        for (int k = 0; k < 5; ++k) stamps[((int64_t)blockIdx.x * 8 + wave) * 5 + k] = ts[k];
+        for (int k = 0; k < 5; ++k) stamps[((int64_t)blockIdx.x * (4 * UP_NTG) + wave) * 5 + k] = ts[k];
 #undef UP_STAMP
 }
 
@@ -1122,8 +1150,12 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
                                hipStream_t s, const uint8_t* live, const float* iou4, int multimask) {
     if (P <= 0) return nullptr;
     if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
-    const int groups = P >= 2 ? 2 : 1;   // 128 tiles x 2 groups = one resident block per CU
-    hipLaunchKernelGGL(dec_upscale_kernel, dim3(128 * groups), dim3(512), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, groups, live, iou4, multimask,
+    // one resident workgroup per CU; each takes an equal contiguous share of the UP_TILES x P (tile, prompt) units
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+    const long long units = (long long)UP_TILES * P;
+    const int grid = (int)(units < n_cu ? units : n_cu);
+    hipLaunchKernelGGL(dec_upscale_kernel, dim3(grid), dim3(UP_THREADS), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, live, iou4, multimask,
                        UP_DEV ? (g_saber_debug_flags >> 8) & 0x1ff : 0, UP_DEV ? g_saber_stamp_buf : nullptr);
     return nullptr;
 }

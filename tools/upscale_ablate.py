@@ -43,14 +43,15 @@ for name, f in FLAGS.items():
     base = base or ms
     print(f"{name:45s} {ms * 1e3:8.1f} us per {P}-prompt launch  ({ms / base * 100:5.1f} %)  = {ms * 1e3 / (P / 2):6.3f} us per prompt and workgroup")
 # per-phase stamps of the full kernel (s_memtime ticks = 100 MHz constant clock on gfx950: 10 ns each)
-st = torch.zeros(256 * 8 * 5, dtype=torch.int64, device="cuda")
+NW = 4 * int(os.environ.get("UP_NTG", "3"))      # waves per workgroup of the build under test
+st = torch.zeros(256 * NW * 5, dtype=torch.int64, device="cuda")
 for _ in range(2):
     eng.decode_points(pts, slot=0, multimask=True)
 lib.saber_k_set_stamp_buffer(C.c_void_p(st.data_ptr()))
 eng.decode_points(pts, slot=0, multimask=True)
 torch.cuda.synchronize()
 lib.saber_k_set_stamp_buffer(None)
-s = st.view(256, 8, 5).double().cpu() / (P / 2)
+s = st.view(256, NW, 5).double().cpu() / (P * 86.0 / 256.0)       # per (tile, prompt) unit
 names = ["phase A: 32 ds_read_b128 + 32 MFMA", "epilogue A: LayerNorm, 16 GELU, pack", "phase B MFMAs (2 x (8 ds_read + 8 MFMA))", "epilogue B: 32 GELU, hyper product, transposes", "stores + loop"]
 print("s_memtime ticks per prompt, mean over blocks and waves (a wave's own elapsed time between stamps, so it contains the time its SIMD partner held the issue port):")
 tot = s.sum(-1).mean().item()
