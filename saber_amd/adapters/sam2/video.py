@@ -174,6 +174,14 @@ class VideoPredictor:
         self.num_maskmem = num_maskmem
         self.image_size = 1024
         self.shard_encodes = os.environ.get("SABER_AMD_VIDEO_SHARD", "1") != "0"
+        # what the sharded window encodes ship through the all-gather: "fp32" (default; 16 MiB per frame, every rank ends up with the bits a
+        # single process computes) or "op16" (the three feature arrays rounded to the handle's 16-bit operand type: 8 MiB per frame - SURVEY.md
+        # 8f-1 sized the exchange that way; every rank, the encoding one included, then decodes from the ROUNDED features, so the ranks agree
+        # bit for bit with each other but not with an unsharded run: +4e-3 (bf16) / +5e-4 (fp16) on the features).  Over xGMI the fp32 gather
+        # of a 16-frame window is ~2 ms against ~55 ms of work per window, so precision is the default and bytes are the option.
+        self.gather_dtype = os.environ.get("SABER_AMD_VIDEO_GATHER", "fp32")
+        if self.gather_dtype not in ("fp32", "op16"):
+            raise ValueError("SABER_AMD_VIDEO_GATHER must be 'fp32' or 'op16'")
         self._keep: List[torch.Tensor] = []
         W = weights
         missing = [k for k in ("memory_attention.norm.weight", "memory_encoder.out_proj.weight", "obj_ptr_proj.layers.0.weight", "maskmem_tpos_enc") if k not in W]
@@ -326,8 +334,19 @@ class VideoPredictor:
         self.eng._check(self.lib.saber_export_slots(self.eng.h, 0, n, self._p(mine[0]), self._p(mine[1]), self._p(mine[2]), self._s()))
         every = [torch.empty((world * per, sz), dtype=torch.float32, device=self.dev) for sz in sizes]
         on_device = dist.get_backend() == "nccl"
+        t16 = None if self.gather_dtype == "fp32" else (torch.float16 if self.f16 else torch.bfloat16)
         for src, dst in zip(mine, every):
-            if on_device:
+            if t16 is not None:                      # 16-bit exchange: the same bytes through an int16 view (gloo has no bf16 collectives)
+                src16 = src.to(t16).view(torch.int16)
+                dst16 = torch.empty(dst.shape, dtype=torch.int16, device=self.dev)
+                if on_device:
+                    dist.all_gather_into_tensor(dst16, src16)
+                else:
+                    host = torch.empty(dst.shape, dtype=torch.int16)
+                    dist.all_gather_into_tensor(host, src16.cpu())
+                    dst16.copy_(host)
+                dst.copy_(dst16.view(t16))
+            elif on_device:
                 dist.all_gather_into_tensor(dst, src)
             else:
                 host = torch.empty(dst.shape, dtype=torch.float32)

@@ -850,7 +850,7 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 // GELU outputs feed phase B straight from registers (k-slot permutation, W2 pre-permuted on the host).
 // Phase B: [(pos w, 32 tok)] x [128 = pos2*32+ch2] over K=64, epilogue = +feat_s0, GELU, 4 dot products with hyper.
 // The 32-channel 256x256 upscaled embedding (8 MB fp32 per prompt) never exists in memory.
-// Round 4: THREE waves per SIMD.  SQ counters under the 8-wave kernel (profiles/r04_upscale_sq_counters.txt, tools/upscale_pmc.sh): a wave
+// Round 4: THREE waves per SIMD.  SQ counters under the 8-wave kernel (profiles/r04_decoder_sq_counters_8wave.txt, tools/sq_counters.sh): a wave
 // spends 46 % of its cycles executing VALU instructions (703 per prompt at 4.6 cycles each: a single wave issues one VALU instruction per
 // 4 cycles, the SIMD-32 pipe takes one per 2), 29 % waiting to issue and 17 % parked at a waitcnt; compile-time ablations (UP_ABL,
 // tools/upscale_ablate.sh): GELU -33 %, hypernetwork product -13 %, X loads -3 %, LayerNorm reductions / stores / MFMAs ~0, everything

@@ -419,6 +419,31 @@ def test_window_encodes_sharded_over_ranks(tmp_path):
         assert np.array_equal(got["vol"], one["vol"]) and np.array_equal(got["scores"], one["scores"]), r
 
 
+def test_window_encodes_sharded_with_16_bit_gather(tmp_path):
+    """SABER_AMD_VIDEO_GATHER=op16: the sharded window encodes ship their features as 16-bit (8 MiB per frame instead of 16).  Every rank
+    decodes from the same rounded features, so the two ranks agree bit for bit; against the unsharded run the volume differs by the rounding
+    of the features only."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "video_shard_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base = str(tmp_path / "one.npz")
+    subprocess.run([sys.executable, worker, base], check=True, env=env, timeout=300)
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", SABER_AMD_VIDEO_GATHER="op16")
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path / f"h{r}.npz")], env=e))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    one, g0, g1 = np.load(base), np.load(str(tmp_path / "h0.npz")), np.load(str(tmp_path / "h1.npz"))
+    assert int(g0["sharded"]) == 2 and int(g1["sharded"]) == 2
+    assert np.array_equal(g0["vol"], g1["vol"]) and np.array_equal(g0["scores"], g1["scores"])
+    a, b = g0["vol"] > 0, one["vol"] > 0
+    iou = (a & b).sum() / max(1, (a | b).sum())
+    print("16-bit gather vs unsharded: volume IoU", iou, "max |score diff|", np.abs(g0["scores"] - one["scores"]).max())
+    assert iou > 0.99 and np.abs(g0["scores"] - one["scores"]).max() < 0.1
+
+
 def test_frames_larger_than_1024_px_on_the_device(gpu_lib):
     """load_tomogram_frames_device on a tomogram above the model's resolution (Gaussian anti-aliasing as skimage's down-sampling resize
     applies it, saber/adapters/preprocessing.py:21) against the oracle's scipy restatement; mixed case: one axis down-, one up-sampled."""

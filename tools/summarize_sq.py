@@ -1,4 +1,4 @@
-"""Per-kernel sums of the SQ counters of rocprofv3 --pmc passes (tools/upscale_pmc.sh): python tools/summarize_sq.py <pass dir> [<pass dir> ...]
+"""Per-kernel sums of the SQ counters of rocprofv3 --pmc passes (tools/sq_counters.sh): python tools/summarize_sq.py <pass dir> [<pass dir> ...]
 Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_BUSY_CYCLES per SE-ish;
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles.  Ratios of same-unit counters are what the table is for."""
 import csv, glob, os, sys, collections
