@@ -220,6 +220,62 @@ def test_exact_default_grid_amg_golden(large_weights):
         eng.close()
 
 
+def _amg_vs_golden(eng, name, amg):
+    from oracle import saber_ref
+    from saber_amd.engine import make_amg_params, unpack_bits
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    img = eng.prepare(torch.from_numpy(saber_ref.synthetic_slice(seed=0)).cuda())
+    bits, meta = eng.amg_generate(img, make_amg_params(amg), max_masks=4096)
+    torch.cuda.synchronize()
+    got = unpack_bits(bits, 1024)[:, 2::4, 2::4] if len(meta) else np.zeros((0, 256, 256), dtype=bool)
+    ref = np.unpackbits(G["quarter_bits"], axis=-1).astype(bool)
+    return G, meta, got, ref
+
+
+def test_exact_default_grid_filters_goldens(large_weights):
+    """The generator's FILTERS at the default grid against the fp32 oracle (what the seeded weights allow: DESIGN.md section 3).
+    (a) stability_score_thresh and pred_iou_thresh at the candidates' medians, NMS off: each score filter removes about half, the survivors and
+    their ORDER must be the oracle's; (b) cfgAMG's own stability 0.92 / box NMS 0.7 / crop NMS 0.7 with pred_iou_thresh 0: per-crop NMS and the
+    cross-crop NMS (score 1 / crop area) leave one mask - the same one."""
+    from saber_amd.engine import Engine
+    cfg, W = large_weights
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    if not (os.path.exists(os.path.join(gold, "amg_default_grid_stability_seed0.npz")) and os.path.exists(os.path.join(gold, "amg_default_grid_cfgamg_seed0.npz"))):
+        pytest.skip("filters goldens not generated (python -m oracle.make_golden_amg with VARIANT=stability / cfgamg: ~40 min of CPU each)")
+    eng = Engine("large", device=0, weights=W, max_images=21, max_prompts=1024, precision="exact")
+    try:
+        # (a) the two score filters
+        G, meta, got, ref = _amg_vs_golden(eng, "amg_default_grid_stability_seed0.npz",
+                                           dict(npoints=32, crop_n_layers=2, pred_iou_thresh=0.7459, stability_score_thresh=0.9071, box_nms_thresh=1.0, crop_nms_thresh=1.0))
+        n_ref, n_got = int(G["count"]), len(meta)
+        # a candidate whose stability score (a ratio of two pixel counts) or predicted IoU sits on the threshold to 1e-6 may fall on either side
+        edge = int((np.abs(G["stability_score"] - 0.9071) < 2e-6).sum() + (np.abs(G["predicted_iou"] - 0.7459) < 2e-6).sum())
+        print(f"filters golden (a): oracle {n_ref} masks, engine {n_got} (oracle masks within 2e-6 of a threshold: {edge})")
+        assert abs(n_got - n_ref) <= edge
+        gp = np.array([[m.point_xy[0], m.point_xy[1]] + list(m.crop_box_xywh) for m in meta], dtype=np.float32)
+        rp = np.concatenate([G["point"], G["crop_box"]], 1)
+        if n_got == n_ref:
+            assert np.allclose(gp, rp, atol=1e-3)                                  # same candidates in the same ORDER
+            inter = (got & ref).reshape(n_ref, -1).sum(1).astype(np.float64)
+            uni = (got | ref).reshape(n_ref, -1).sum(1).astype(np.float64)
+            dev = 1.0 - inter / np.maximum(uni, 1)
+            st = np.array([m.stability_score for m in meta])
+            print(f"   per-mask |IoU - 1| median {np.median(dev):.2e} max {dev.max():.2e}; stability score abs diff max {np.abs(st - G['stability_score']).max():.2e}")
+            assert np.median(dev) <= TOL and dev.max() < 1e-2 and np.abs(st - G["stability_score"]).max() < TOL
+        # (b) cfgAMG's own filters
+        G, meta, got, ref = _amg_vs_golden(eng, "amg_default_grid_cfgamg_seed0.npz",
+                                           dict(npoints=32, crop_n_layers=2, pred_iou_thresh=0.0, stability_score_thresh=0.92, box_nms_thresh=0.7, crop_nms_thresh=0.7))
+        n_ref = int(G["count"])
+        print(f"filters golden (b): oracle {n_ref} masks, engine {len(meta)}")
+        assert len(meta) == n_ref
+        for i in range(n_ref):
+            assert np.allclose([meta[i].point_xy[0], meta[i].point_xy[1]], G["point"][i], atol=1e-3) and np.allclose(list(meta[i].crop_box_xywh), G["crop_box"][i], atol=1e-3)
+            iou = (got[i] & ref[i]).sum() / max(1, (got[i] | ref[i]).sum())
+            assert 1.0 - iou <= TOL
+    finally:
+        eng.close()
+
+
 def test_exact_mode_prompts_of_several_points_and_boxes(engine_exact, image, oracle_feats, oracle_large):
     """saber_decode_prompts (a box = its two corner points with labels 2 / 3, then clicks, then upstream's padding point: 9 / 10 decoder
     tokens) against oracle/sam2_ref.prompt_encoder + mask_decoder on the oracle's own features; the bf16 precision refuses such prompts
