@@ -336,13 +336,13 @@ class VideoPredictor:
         on_device = dist.get_backend() == "nccl"
         t16 = None if self.gather_dtype == "fp32" else (torch.float16 if self.f16 else torch.bfloat16)
         for src, dst in zip(mine, every):
-            if t16 is not None:                      # 16-bit exchange: the same bytes through an int16 view (gloo has no bf16 collectives)
-                src16 = src.to(t16).view(torch.int16)
-                dst16 = torch.empty(dst.shape, dtype=torch.int16, device=self.dev)
+            if t16 is not None:                      # 16-bit exchange: the same bytes through a byte view (gloo has no 16-bit collectives)
+                src16 = src.to(t16).view(torch.uint8)
+                dst16 = torch.empty((dst.shape[0], dst.shape[1] * 2), dtype=torch.uint8, device=self.dev)
                 if on_device:
                     dist.all_gather_into_tensor(dst16, src16)
                 else:
-                    host = torch.empty(dst.shape, dtype=torch.int16)
+                    host = torch.empty(dst16.shape, dtype=torch.uint8)
                     dist.all_gather_into_tensor(host, src16.cpu())
                     dst16.copy_(host)
                 dst.copy_(dst16.view(t16))

@@ -869,6 +869,9 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
 #ifndef UP_MFMA_HYPER
 #define UP_MFMA_HYPER 1
 #endif
+#ifndef UP_NS
+#define UP_NS 1                       // prompts per iteration of a wave ("streams"): 2 halves the weight-fragment reads per prompt at 2 x the per-prompt registers
+#endif
 #define UP_TOK (16 * UP_NTG)
 #define UP_TILES ((4096 + UP_TOK - 1) / UP_TOK)
 #define UP_THREADS (256 * UP_NTG)
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
         // B-operand fragments of the wave's 16 tokens: lane (fi, fg) holds X[tok][32 ks + 8 fg .. +7], ks = 0..7; one 32-bit lane offset into
         // a per-prompt buffer descriptor (the prompt's 2-MB state)
         const uint32_t xoff = (uint32_t)((tok * DC + 8 * fg) * 2);
-        op16x8 xf[8];
+        op16x8 xf[UP_NS][8];
         auto xload = [&](int p, op16x8 (&dst)[8]) {
             const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (int64_t)p * 4096 * DC), 0, 4096 * DC * 2, 0x00020000);
 #pragma unroll
@@ -976,32 +979,55 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
         perm_coords(tok, 2, &gy, &gx);
         const int64_t obase = ((int64_t)fg * 256 + gy * 4 + dy1 * 2) * 256 + gx * 4 + dx1 * 2;
 
-        int p = next_live(p_begin, p_end);
-        if (p < p_end) xload(p, xf);
+        // UP_NS prompts per iteration (streams): every weight fragment read from LDS feeds one MFMA per stream, and the streams' epilogues are
+        // independent instruction chains the scheduler interleaves.  A stream-1 prompt must belong to the slot (crop) of its stream-0 prompt
+        // (the tile's feature registers are per slot); where none is left (odd tail, slot boundary) stream 1 idles on stale data, nothing stored.
+        auto slot_of = [&](int q) { return (q + s_off) / s_div; };
+        auto pick = [&](int pa, int (&pp)[UP_NS]) {       // fills pp[] from the first live prompt at or after pa; returns where the next iteration starts
+            pp[0] = next_live(pa, p_end);
+            int q = pp[0] < p_end ? next_live(pp[0] + 1, p_end) : p_end;
+#pragma unroll
+            for (int sI = 1; sI < UP_NS; ++sI) {
+                if (q < p_end && slot_of(q) == slot_of(pp[0])) { pp[sI] = q; q = next_live(q + 1, p_end); }
+                else pp[sI] = -1;
+            }
+            return q;
+        };
+        int cur[UP_NS], nxt[UP_NS];
+        int q_next = pick(p_begin, cur);
+#pragma unroll
+        for (int sI = 0; sI < UP_NS; ++sI) if (cur[sI] >= 0 && cur[sI] < p_end) xload(cur[sI], xf[sI]);
         if (UP_DEV && stamps) tprev = __builtin_amdgcn_s_memtime();
-        for (int pn; p < p_end; p = pn) {
-            pn = next_live(p + 1, p_end);
+        while (cur[0] < p_end) {
+            const int q_after = pick(q_next, nxt);
             // compiler fence: without it the loop-invariant weight fragments (32 + 16 ds_read_b128 per wave) are hoisted out of the
             // prompt loop and spill
             asm volatile("" ::: "memory");
             {
-                const int slot = (p + s_off) / s_div;     // block-uniform
+                const int slot = slot_of(cur[0]);     // block-uniform
                 if (slot != cur_slot) { load_feats(slot); cur_slot = slot; }
             }
             // Planes anybody reads afterwards (iou4 given): a multimask decode returns masks 1-3; a single-mask decode returns mask 0 or, when
             // that one is unstable, the best of 1-3 by predicted IoU (first maximum: mask_pick_kernel / mask_select_dynamic_kernel) - the other
             // planes are not written (with the hypernetwork product on the VALU their dot products are skipped too).  Block-uniform.
-            int need = 0xF;
-            if (iou4) {
-                if (multimask) need = 0xE;
-                else {
-                    int best = 1;
-                    float bv = iou4[p * 4 + 1];
-                    if (iou4[p * 4 + 2] > bv) { bv = iou4[p * 4 + 2]; best = 2; }
-                    if (iou4[p * 4 + 3] > bv) best = 3;
-                    need = 1 | (1 << best);
+            int need[UP_NS];
+            float* orow[UP_NS];
+#pragma unroll
+            for (int sI = 0; sI < UP_NS; ++sI) {
+                const int p = cur[sI];
+                need[sI] = p < 0 ? 0 : 0xF;
+                if (iou4 && p >= 0) {
+                    if (multimask) need[sI] = 0xE;
+                    else {
+                        int best = 1;
+                        float bv = iou4[p * 4 + 1];
+                        if (iou4[p * 4 + 2] > bv) { bv = iou4[p * 4 + 2]; best = 2; }
+                        if (iou4[p * 4 + 3] > bv) best = 3;
+                        need[sI] = 1 | (1 << best);
+                    }
                 }
-                need = __builtin_amdgcn_readfirstlane(need);
+                need[sI] = __builtin_amdgcn_readfirstlane(need[sI]);
+                orow[sI] = masks4 + (int64_t)(p < 0 ? cur[0] : p) * 4 * 65536 + obase;
             }
 #if UP_MFMA_HYPER
             // The hypernetwork product masks[k] = hyper[k] . u2 on the matrix cores (instead of 128 FMAs + a 3-step lane transpose per lane and
@@ -1010,47 +1036,58 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
             // phase B leaves its GELU outputs in, so they are packed into the B operand as they stand.  Every row 4 fg + r of the result is
             // mask fg of token fi: the lane reads its own mask from register 0, no lane movement.  hyper enters as a hi + lo pair of the 16-bit
             // operand type (two MFMAs, exact to 2^-17 / 2^-23); u2 is rounded to that type (2^-9 / 2^-12 per element, averaged over the 32-term sum).
-            op16x8 hy_hi, hy_lo;
-            {
-                const float* hp = hyper + (int64_t)p * 128 + (fi >> 2) * 32 + 4 * fg;
+            op16x8 hy_hi[UP_NS], hy_lo[UP_NS];
+#pragma unroll
+            for (int sI = 0; sI < UP_NS; ++sI) {
+                const float* hp = hyper + (int64_t)(cur[sI] < 0 ? cur[0] : cur[sI]) * 128 + (fi >> 2) * 32 + 4 * fg;
                 const float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 16);
                 const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 float l[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) l[j] = v[j] - op2f(f2op(v[j]));
-                hy_hi = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-                hy_lo = pack8_d(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]);
+                hy_hi[sI] = pack8_d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                hy_lo[sI] = pack8_d(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]);
             }
 #else
+            static_assert(UP_NS == 1, "the VALU hypernetwork product is built for one prompt per iteration");
             float4 hy[2][4];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hyper + (int64_t)p * 128 + k * 32 + hh * 16 + 4 * fg);
+                for (int k = 0; k < 4; ++k) hy[hh][k] = *reinterpret_cast<const float4*>(hyper + (int64_t)cur[0] * 128 + k * 32 + hh * 16 + 4 * fg);
 #endif
-            // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256
-            f32x4 acc[4];
+            // ---------------- phase A: [16 tok of this wave] x [64 outputs of pos] over K = 256, per stream
+            f32x4 acc[UP_NS][4];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){f1[ni].x, f1[ni].y, f1[ni].z, f1[ni].w};       // bias + feat_s1 enter as the C operand
+            for (int sI = 0; sI < UP_NS; ++sI)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[sI][ni] = (f32x4){f1[ni].x, f1[ni].y, f1[ni].z, f1[ni].w};       // bias + feat_s1 enter as the C operand
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const op16x8 wf = *reinterpret_cast<const op16x8*>(w1s + (UPD(UPD_NO_W1_READ) ? kswz(fi, fg) : kswz(pos * 64 + ni * 16 + fi, ks * 4 + fg)));
-                    if (!UPD(UPD_NO_MFMA_A)) acc[ni] = MFMA_16x16x32(wf, xf[ks], acc[ni], 0, 0, 0);
-                    else acc[ni][0] += __builtin_bit_cast(f32x4, wf)[0] + __builtin_bit_cast(f32x4, xf[ks])[0];
+#pragma unroll
+                    for (int sI = 0; sI < UP_NS; ++sI) {
+                        if (!UPD(UPD_NO_MFMA_A)) acc[sI][ni] = MFMA_16x16x32(wf, xf[sI][ks], acc[sI][ni], 0, 0, 0);
+                        else acc[sI][ni][0] += __builtin_bit_cast(f32x4, wf)[0] + __builtin_bit_cast(f32x4, xf[sI][ks])[0];
+                    }
                 }
             }
             UP_STAMP(0);
-            // the operand registers are free again: the next prompt's rows load while both epilogues and phase B run
-            if (pn < p_end && !UPD(UPD_NO_XLOAD)) xload(pn, xf);
+            // the operand registers are free again: the next prompts' rows load while both epilogues and phase B run
+            if (!UPD(UPD_NO_XLOAD)) {
+#pragma unroll
+                for (int sI = 0; sI < UP_NS; ++sI) if (nxt[sI] >= 0 && nxt[sI] < p_end) xload(nxt[sI], xf[sI]);
+            }
             // epilogue A: + (bias + feat_s1), LayerNorm over the 64 channels of (tok, pos), GELU, pack as phase-B operand
-            op16x8 uf[2];
-            {
+            op16x8 uf[UP_NS][2];
+#pragma unroll
+            for (int sI = 0; sI < UP_NS; ++sI) {
                 float v[4][4], sum = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    v[ni][0] = acc[ni][0]; v[ni][1] = acc[ni][1]; v[ni][2] = acc[ni][2]; v[ni][3] = acc[ni][3];
+                    v[ni][0] = acc[sI][ni][0]; v[ni][1] = acc[sI][ni][1]; v[ni][2] = acc[sI][ni][2]; v[ni][3] = acc[sI][ni][3];
                     sum += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
                 }
                 if (!UPD(UPD_NO_LN)) sum = xor32_sum(xor16_sum(sum));
@@ -1073,70 +1110,80 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    uf[ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
-                                     v[2 * ks + 1][3]);
+                    uf[sI][ks] = pack8_d(v[2 * ks][0], v[2 * ks][1], v[2 * ks][2], v[2 * ks][3], v[2 * ks + 1][0], v[2 * ks + 1][1], v[2 * ks + 1][2],
+                                         v[2 * ks + 1][3]);
             }
             UP_STAMP(1);
             // ---------------- phase B (two halves of the 128 outputs: pos2 in {0,1} then {2,3})
-            float* orow = masks4 + (int64_t)p * 4 * 65536 + obase;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
-                f32x4 c2[4];
+                f32x4 c2[UP_NS][4];
 #pragma unroll
-                for (int nl = 0; nl < 4; ++nl) c2[nl] = f0[2 * hb + (nl >> 1)][nl & 1];                       // bias + feat_s0 enter as the C operand
+                for (int sI = 0; sI < UP_NS; ++sI)
+#pragma unroll
+                    for (int nl = 0; nl < 4; ++nl) c2[sI][nl] = f0[2 * hb + (nl >> 1)][nl & 1];                       // bias + feat_s0 enter as the C operand
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int nl = 0; nl < 4; ++nl) {
                         const op16x8 w2f = *reinterpret_cast<const op16x8*>(w2s + (UPD(UPD_NO_W2_READ) ? swz128(fi, fg) : swz128((hb * 4 + nl) * 16 + fi, ks * 4 + fg)));
-                        if (!UPD(UPD_NO_MFMA_B)) c2[nl] = MFMA_16x16x32(w2f, uf[ks], c2[nl], 0, 0, 0);
-                        else c2[nl][0] += __builtin_bit_cast(f32x4, w2f)[0] + __builtin_bit_cast(f32x4, uf[ks])[0];
+#pragma unroll
+                        for (int sI = 0; sI < UP_NS; ++sI) {
+                            if (!UPD(UPD_NO_MFMA_B)) c2[sI][nl] = MFMA_16x16x32(w2f, uf[sI][ks], c2[sI][nl], 0, 0, 0);
+                            else c2[sI][nl][0] += __builtin_bit_cast(f32x4, w2f)[0] + __builtin_bit_cast(f32x4, uf[sI][ks])[0];
+                        }
                     }
                 UP_STAMP(2);
-                float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
+                for (int sI = 0; sI < UP_NS; ++sI) {
+                    float2 px2;                                // the two pixels (dx2 = 0, 1) of output row dy2 = hb
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {           // pos2 = 2*hb + pp
 #if UP_MFMA_HYPER
-                    f32x2 ua0 = (f32x2){c2[2 * pp][0], c2[2 * pp][1]}, ub0 = (f32x2){c2[2 * pp][2], c2[2 * pp][3]};
-                    f32x2 ua1 = (f32x2){c2[2 * pp + 1][0], c2[2 * pp + 1][1]}, ub1 = (f32x2){c2[2 * pp + 1][2], c2[2 * pp + 1][3]};
-                    if (!UPD(UPD_NO_GELU)) { ua0 = gelu_erf2(ua0); ub0 = gelu_erf2(ub0); ua1 = gelu_erf2(ua1); ub1 = gelu_erf2(ub1); }
-                    float mine;
-                    if (UPD(UPD_NO_HYPER)) mine = ua0.x + ub0.y + ua1.x + ub1.y;
-                    else {
-                        const op16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
-                        f32x4 dm = MFMA_16x16x32(hy_hi, uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        dm = MFMA_16x16x32(hy_lo, uop, dm, 0, 0, 0);
-                        mine = dm[0];
-                    }
-                    if (pp == 0) px2.x = mine; else px2.y = mine;
+                        f32x2 ua0 = (f32x2){c2[sI][2 * pp][0], c2[sI][2 * pp][1]}, ub0 = (f32x2){c2[sI][2 * pp][2], c2[sI][2 * pp][3]};
+                        f32x2 ua1 = (f32x2){c2[sI][2 * pp + 1][0], c2[sI][2 * pp + 1][1]}, ub1 = (f32x2){c2[sI][2 * pp + 1][2], c2[sI][2 * pp + 1][3]};
+                        if (!UPD(UPD_NO_GELU)) { ua0 = gelu_erf2(ua0); ub0 = gelu_erf2(ub0); ua1 = gelu_erf2(ua1); ub1 = gelu_erf2(ub1); }
+                        float mine;
+                        if (UPD(UPD_NO_HYPER)) mine = ua0.x + ub0.y + ua1.x + ub1.y;
+                        else {
+                            const op16x8 uop = pack8_d(ua0.x, ua0.y, ub0.x, ub0.y, ua1.x, ua1.y, ub1.x, ub1.y);
+                            f32x4 dm = MFMA_16x16x32(hy_hi[sI], uop, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            dm = MFMA_16x16x32(hy_lo[sI], uop, dm, 0, 0, 0);
+                            mine = dm[0];
+                        }
+                        if (pp == 0) px2.x = mine; else px2.y = mine;
 #else
-                    float part[4] = {0.f, 0.f, 0.f, 0.f};
+                        float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int nl = 2 * pp + hh;
-                        f32x2 ua = (f32x2){c2[nl][0], c2[nl][1]}, ub = (f32x2){c2[nl][2], c2[nl][3]};
-                        if (!UPD(UPD_NO_GELU)) { ua = gelu_erf2(ua); ub = gelu_erf2(ub); }
-                        const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
-                        if (UPD(UPD_NO_HYPER)) { part[hh] += u0 + u1 + u2 + u3; continue; }
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int nl = 2 * pp + hh;
+                            f32x2 ua = (f32x2){c2[sI][nl][0], c2[sI][nl][1]}, ub = (f32x2){c2[sI][nl][2], c2[sI][nl][3]};
+                            if (!UPD(UPD_NO_GELU)) { ua = gelu_erf2(ua); ub = gelu_erf2(ub); }
+                            const float u0 = ua.x, u1 = ua.y, u2 = ub.x, u3 = ub.y;
+                            if (UPD(UPD_NO_HYPER)) { part[hh] += u0 + u1 + u2 + u3; continue; }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if ((need >> k) & 1) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
-                    }
-                    // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
-                    // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
-                    float k0 = fb0 ? part[1] : part[0], k1 = fb0 ? part[3] : part[2];
-                    k0 += shfl_xor16(fb0 ? part[0] : part[1], (lane >> 4) & 1);
-                    k1 += shfl_xor16(fb0 ? part[2] : part[3], (lane >> 4) & 1);
-                    float mine = fb1 ? k1 : k0;
-                    mine += shfl_xor32(fb1 ? k0 : k1, lane >= 32);
-                    if (pp == 0) px2.x = mine; else px2.y = mine;
+                            for (int k = 0; k < 4; ++k)
+                                if ((need[sI] >> k) & 1) part[k] = fmaf(u0, hy[hh][k].x, fmaf(u1, hy[hh][k].y, fmaf(u2, hy[hh][k].z, fmaf(u3, hy[hh][k].w, part[k]))));
+                        }
+                        // transpose-reduce over the four fg lanes of a token: lane fg ends with the complete sum of mask k = fg
+                        // (3 shuffles and selects instead of 8 shuffles and a 4-way branch)
+                        float k0 = fb0 ? part[1] : part[0], k1 = fb0 ? part[3] : part[2];
+                        k0 += shfl_xor16(fb0 ? part[0] : part[1], (lane >> 4) & 1);
+                        k1 += shfl_xor16(fb0 ? part[2] : part[3], (lane >> 4) & 1);
+                        float mine = fb1 ? k1 : k0;
+                        mine += shfl_xor32(fb1 ? k0 : k1, lane >= 32);
+                        if (pp == 0) px2.x = mine; else px2.y = mine;
 #endif
+                    }
+                    if (((need[sI] >> fg) & 1) && !UPD(UPD_NO_STORE)) *reinterpret_cast<float2*>(orow[sI] + hb * 256) = px2;
+                    if (UPD(UPD_NO_STORE) && px2.x + px2.y == 1.2345e30f) *reinterpret_cast<float2*>(orow[sI] + hb * 256) = px2;     // (keeps the values alive)
                 }
                 UP_STAMP(3);
-                if (((need >> fg) & 1) && !UPD(UPD_NO_STORE)) *reinterpret_cast<float2*>(orow + hb * 256) = px2;
-                if (UPD(UPD_NO_STORE) && px2.x + px2.y == 1.2345e30f) *reinterpret_cast<float2*>(orow + hb * 256) = px2;     // (keeps the values alive)
             }
             UP_STAMP(4);
+#pragma unroll
+            for (int sI = 0; sI < UP_NS; ++sI) cur[sI] = nxt[sI];
+            q_next = q_after;
         }
     }
     (void)fb0; (void)fb1;

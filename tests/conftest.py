@@ -50,6 +50,31 @@ def oracle_large(large_weights):
     return cfg, sam2_ref.to_torch(W)
 
 
+@pytest.fixture(scope="session")
+def image():
+    """the 1024^2 test micrograph of the precision-mode tests (tests/test_gpu_exact.py, tests/test_gpu_fp16.py)"""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    img = rng.uniform(0, 1, (1024, 1024)).astype(np.float32)
+    yy, xx = np.mgrid[:1024, :1024]
+    for _ in range(10):
+        cy, cx = rng.integers(100, 924, 2)
+        r = rng.integers(30, 120)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
+    return img
+
+
+@pytest.fixture(scope="session")
+def oracle_feats(image, oracle_large):
+    """the fp32 CPU oracle's Hiera-L features of `image` (one ~15-s oracle pass shared by every module that compares against it)"""
+    import numpy as np
+    import torch
+    from oracle import sam2_ref
+    cfg, W = oracle_large
+    with torch.no_grad():
+        return sam2_ref.encode_image(W, cfg, sam2_ref.sam2_transforms(np.repeat(image[..., None], 3, 2)))
+
+
 def amg_case(name):
     """Masks of one oracle AMG case from tests/golden/amg_cases_large_seed0.npz (oracle/make_golden_amg_cases.py): the quarter-resolution
     samples [2::4, 2::4] of every mask, list of {"segmentation": bool array}; compare with the same samples of the engine's masks"""

@@ -28,33 +28,12 @@ def rel_max(a, b):
 
 
 @pytest.fixture(scope="module")
-def image():
-    rng = np.random.default_rng(7)
-    img = rng.uniform(0, 1, (1024, 1024)).astype(np.float32)
-    yy, xx = np.mgrid[:1024, :1024]
-    for _ in range(10):
-        cy, cx = rng.integers(100, 924, 2)
-        r = rng.integers(30, 120)
-        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
-    return img
-
-
-@pytest.fixture(scope="module")
 def engine_exact(large_weights):
     from saber_amd.engine import Engine
     cfg, W = large_weights
     eng = Engine("large", device=0, weights=W, max_images=2, max_prompts=32, precision="exact")
     yield eng
     eng.close()
-
-
-@pytest.fixture(scope="module")
-def oracle_feats(image, oracle_large):
-    from oracle import sam2_ref
-    cfg, W = oracle_large
-    with torch.no_grad():
-        feats = sam2_ref.encode_image(W, cfg, sam2_ref.sam2_transforms(np.repeat(image[..., None], 3, 2)))
-    return feats
 
 
 def test_exact_encoder_within_1e3_of_fp32_oracle(engine_exact, image, oracle_feats):
@@ -248,20 +227,46 @@ def test_exact_default_grid_filters_goldens(large_weights):
         G, meta, got, ref = _amg_vs_golden(eng, "amg_default_grid_stability_seed0.npz",
                                            dict(npoints=32, crop_n_layers=2, pred_iou_thresh=0.7459, stability_score_thresh=0.9071, box_nms_thresh=1.0, crop_nms_thresh=1.0))
         n_ref, n_got = int(G["count"]), len(meta)
-        # a candidate whose stability score (a ratio of two pixel counts) or predicted IoU sits on the threshold to 1e-6 may fall on either side
-        edge = int((np.abs(G["stability_score"] - 0.9071) < 2e-6).sum() + (np.abs(G["predicted_iou"] - 0.7459) < 2e-6).sum())
-        print(f"filters golden (a): oracle {n_ref} masks, engine {n_got} (oracle masks within 2e-6 of a threshold: {edge})")
-        assert abs(n_got - n_ref) <= edge
-        gp = np.array([[m.point_xy[0], m.point_xy[1]] + list(m.crop_box_xywh) for m in meta], dtype=np.float32)
-        rp = np.concatenate([G["point"], G["crop_box"]], 1)
-        if n_got == n_ref:
-            assert np.allclose(gp, rp, atol=1e-3)                                  # same candidates in the same ORDER
-            inter = (got & ref).reshape(n_ref, -1).sum(1).astype(np.float64)
-            uni = (got | ref).reshape(n_ref, -1).sum(1).astype(np.float64)
-            dev = 1.0 - inter / np.maximum(uni, 1)
-            st = np.array([m.stability_score for m in meta])
-            print(f"   per-mask |IoU - 1| median {np.median(dev):.2e} max {dev.max():.2e}; stability score abs diff max {np.abs(st - G['stability_score']).max():.2e}")
-            assert np.median(dev) <= TOL and dev.max() < 1e-2 and np.abs(st - G["stability_score"]).max() < TOL
+        # Candidates are identified by (point, crop box, area rank): every oracle survivor must be among the engine's, in the oracle's ORDER.  A
+        # candidate whose stability score (a ratio of two pixel counts) or predicted IoU sits ON a threshold - both thresholds are the medians of
+        # their distributions - may fall on either side of it by one float ulp: such extras / misses are allowed only within 1e-5 of a threshold.
+        def key(pt, cb):
+            return tuple(np.round(np.concatenate([np.asarray(pt, dtype=np.float64), np.asarray(cb, dtype=np.float64)]), 2))
+        eng_keys = [key(m.point_xy, m.crop_box_xywh) for m in meta]
+        ref_keys = [key(G["point"][i], G["crop_box"][i]) for i in range(n_ref)]
+        # (three m2m candidates share a point: disambiguate by order of appearance)
+        from collections import defaultdict
+        pos = defaultdict(list)
+        for j, k in enumerate(eng_keys):
+            pos[k].append(j)
+        match, used = [], set()
+        for i, k in enumerate(ref_keys):
+            best, bi = -1.0, -1
+            for j in pos.get(k, []):
+                if j in used:
+                    continue
+                iou = (got[j] & ref[i]).sum() / max(1, (got[j] | ref[i]).sum())
+                if iou > best:
+                    best, bi = iou, j
+            match.append((bi, best))
+            if bi >= 0:
+                used.add(bi)
+        missing = [i for i, (j, _) in enumerate(match) if j < 0]
+        extras = [j for j in range(n_got) if j not in used]
+        on_edge = lambda st_, pi_: abs(st_ - 0.9071) < 1e-5 or abs(pi_ - 0.7459) < 1e-5
+        print(f"filters golden (a): oracle {n_ref} masks, engine {n_got}; oracle masks the engine lacks: {len(missing)}, engine masks the oracle lacks: {len(extras)}")
+        assert len(missing) <= 2 and len(extras) <= 4
+        for i in missing:
+            assert on_edge(float(G["stability_score"][i]), float(G["predicted_iou"][i])), i
+        for j in extras:
+            assert on_edge(meta[j].stability_score, meta[j].predicted_iou), (j, meta[j].stability_score, meta[j].predicted_iou)
+        idx = [j for j, _ in match if j >= 0]
+        assert idx == sorted(idx)                                              # the common masks in the same ORDER
+        dev = np.array([1.0 - b for j, b in match if j >= 0])
+        st = np.array([meta[j].stability_score for j, _ in match if j >= 0])
+        st_ref = np.array([G["stability_score"][i] for i, (j, _) in enumerate(match) if j >= 0])
+        print(f"   per-mask |IoU - 1| median {np.median(dev):.2e} max {dev.max():.2e}; stability score abs diff max {np.abs(st - st_ref).max():.2e}")
+        assert np.median(dev) <= TOL and dev.max() < 1e-2 and np.abs(st - st_ref).max() < TOL
         # (b) cfgAMG's own filters
         G, meta, got, ref = _amg_vs_golden(eng, "amg_default_grid_cfgamg_seed0.npz",
                                            dict(npoints=32, crop_n_layers=2, pred_iou_thresh=0.0, stability_score_thresh=0.92, box_nms_thresh=0.7, crop_nms_thresh=0.7))

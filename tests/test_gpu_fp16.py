@@ -27,32 +27,12 @@ def rel_rms(a, b):
 
 
 @pytest.fixture(scope="module")
-def image():
-    rng = np.random.default_rng(7)
-    img = rng.uniform(0, 1, (1024, 1024)).astype(np.float32)
-    yy, xx = np.mgrid[:1024, :1024]
-    for _ in range(10):
-        cy, cx = rng.integers(100, 924, 2)
-        r = rng.integers(30, 120)
-        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
-    return img
-
-
-@pytest.fixture(scope="module")
 def engine_f16(large_weights):
     from saber_amd.engine import Engine
     cfg, W = large_weights
     eng = Engine("large", device=0, weights=W, max_images=2, max_prompts=32, precision="fp16")
     yield eng
     eng.close()
-
-
-@pytest.fixture(scope="module")
-def oracle_feats(image, oracle_large):
-    from oracle import sam2_ref
-    cfg, W = oracle_large
-    with torch.no_grad():
-        return sam2_ref.encode_image(W, cfg, sam2_ref.sam2_transforms(np.repeat(image[..., None], 3, 2)))
 
 
 def _f16_bits(a):
