@@ -241,13 +241,13 @@ def test_exact_default_grid_filters_goldens(large_weights):
             pos[k].append(j)
         match, used = [], set()
         for i, k in enumerate(ref_keys):
-            best, bi = -1.0, -1
+            # the (up to three) m2m candidates of one point are told apart by their predicted IoU
+            bi, bd = -1, 1e-4
             for j in pos.get(k, []):
-                if j in used:
-                    continue
-                iou = (got[j] & ref[i]).sum() / max(1, (got[j] | ref[i]).sum())
-                if iou > best:
-                    best, bi = iou, j
+                d = abs(meta[j].predicted_iou - float(G["predicted_iou"][i]))
+                if j not in used and d < bd:
+                    bi, bd = j, d
+            best = (got[bi] & ref[i]).sum() / max(1, (got[bi] | ref[i]).sum()) if bi >= 0 else -1.0
             match.append((bi, best))
             if bi >= 0:
                 used.add(bi)
