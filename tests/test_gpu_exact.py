@@ -260,8 +260,16 @@ def test_exact_default_grid_filters_goldens(large_weights):
             assert on_edge(float(G["stability_score"][i]), float(G["predicted_iou"][i])), i
         for j in extras:
             assert on_edge(meta[j].stability_score, meta[j].predicted_iou), (j, meta[j].stability_score, meta[j].predicted_iou)
-        idx = [j for j, _ in match if j >= 0]
-        assert idx == sorted(idx)                                              # the common masks in the same ORDER
+        # the common masks in the same ORDER (a crop's survivors leave the NMS sorted by predicted IoU: two candidates whose scores agree to
+        # 1e-5 may swap between two fp32 evaluations)
+        pairs = [(i, j) for i, (j, _) in enumerate(match) if j >= 0]
+        swaps = 0
+        for (ia, ja), (ib, jb) in zip(pairs, pairs[1:]):
+            if jb < ja:
+                swaps += 1
+                assert abs(float(G["predicted_iou"][ia]) - float(G["predicted_iou"][ib])) < 1e-5, (ia, ib)
+        print(f"   order: {swaps} adjacent swaps between candidates of equal score")
+        assert swaps <= 4
         dev = np.array([1.0 - b for j, b in match if j >= 0])
         st = np.array([meta[j].stability_score for j, _ in match if j >= 0])
         st_ref = np.array([G["stability_score"][i] for i, (j, _) in enumerate(match) if j >= 0])
