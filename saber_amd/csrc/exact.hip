@@ -61,18 +61,35 @@ __global__ __launch_bounds__(256) void xg_gemm_kernel(XGemm p) {
     const bool a_ok = m0 + arow < p.M, w_ok = n0 + wrow < p.N;
     const float* ap = A + (m0 + arow) * p.lda + akh * 8;
     const float* wp = W + (int64_t)(n0 + wrow) * p.ldw + wkq * 4;
+    // 16-byte loads where the rows allow it (every GEMM of the model: K and the leading dimensions are multiples of 4), and the NEXT K step's
+    // operands are in flight while the current one is multiplied (round 4: the loop used to wait for its scalar loads at the top of every
+    // step).  The products and their order are unchanged: results are bit-identical to the unpipelined loop.
+    const bool vec = ((p.lda | p.ldw) & 3) == 0 && (p.K & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+    float av[8], wv[4];
+    auto gload = [&](int k0) {
+        if (vec) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a0 = (a_ok && k0 + akh * 8 < p.K) ? *reinterpret_cast<const float4*>(ap + k0) : z;
+            const float4 a1 = (a_ok && k0 + akh * 8 + 4 < p.K) ? *reinterpret_cast<const float4*>(ap + k0 + 4) : z;
+            const float4 w0 = (w_ok && k0 + wkq * 4 < p.K) ? *reinterpret_cast<const float4*>(wp + k0) : z;
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = (a_ok && k0 + akh * 8 + j < p.K) ? ap[k0 + j] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = (w_ok && k0 + wkq * 4 + j < p.K) ? wp[k0 + j] : 0.0f;
+        }
+    };
+    gload(0);
     for (int k0 = 0; k0 < p.K; k0 += XG_BK) {
-        float av[8], wv[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) av[j] = (a_ok && k0 + akh * 8 + j < p.K) ? ap[k0 + j] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wv[j] = (w_ok && k0 + wkq * 4 + j < p.K) ? wp[k0 + j] : 0.0f;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) As[akh * 8 + j][arow] = av[j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) Bs[wkq * 4 + j][wrow] = wv[j];
         __syncthreads();
+        if (k0 + XG_BK < p.K) gload(k0 + XG_BK);
 #pragma unroll
         for (int kk = 0; kk < XG_BK; kk += 4) {
             float a[2], bb[4];
