@@ -29,18 +29,6 @@ def rel_rms(a, b):
 
 
 @pytest.fixture(scope="module")
-def image():
-    rng = np.random.default_rng(7)
-    img = rng.uniform(0, 1, (1024, 1024)).astype(np.float32)
-    yy, xx = np.mgrid[:1024, :1024]
-    for _ in range(10):
-        cy, cx = rng.integers(100, 924, 2)
-        r = rng.integers(30, 120)
-        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.3
-    return img
-
-
-@pytest.fixture(scope="module")
 def emul_feats(image, oracle_large):
     from oracle import sam2_ref, sam2_bf16_emul as E
     cfg, W = oracle_large
@@ -49,11 +37,8 @@ def emul_feats(image, oracle_large):
 
 
 @pytest.fixture(scope="module")
-def fp32_feats(image, oracle_large):
-    from oracle import sam2_ref
-    cfg, W = oracle_large
-    with torch.no_grad():
-        return sam2_ref.encode_image(W, cfg, sam2_ref.sam2_transforms(np.repeat(image[..., None], 3, 2)))
+def fp32_feats(oracle_feats):
+    return oracle_feats          # (tests/conftest.py: the session's one oracle pass over `image`)
 
 
 # realisation spread of the emulation itself (fp32- vs fp64-accumulated GEMMs, tests/test_oracle_bf16_emul.py)
