@@ -139,9 +139,6 @@ int saber_k_dec_i2t(const uint16_t* X, int64_t x_batch_stride, const uint16_t* p
 int saber_k_dec_t2i(const uint16_t* X, int64_t x_batch_stride, const uint16_t* pek, const uint16_t* Qt, const float* tq, float qscale, float* part_ws,
                     float* ml_ws, int P, int split, const uint16_t* Wv, const float* bv, uint16_t* out, void* stream);
 
-/* gemm_w1d.hip directly: out16[M][N] = act(A[M][K] . W[N][K]^T + bias) with 16-bit operands and output (K % 64 == 0, N % 8 == 0); W is packed
- * per K-step into a scratch of the calling thread, once per (W, N, K). */
-int saber_k_gemm_w1d(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, uint16_t* out16, int M, int N, int K, int act, void* stream);
 /* Development (co-residency experiments, tools/cu_mask_bench.py): a HIP stream restricted to CUs first_cu .. first_cu + n_cus - 1
  * (hipExtStreamCreateWithCUMask), and its release. */
 int saber_k_stream_create_cu_range(int first_cu, int n_cus, void** out_stream);

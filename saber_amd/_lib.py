@@ -96,7 +96,6 @@ SIGNATURES = {
     "saber_k_init": (_i, [_i]),
     "saber_k_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "saber_k_gemm_ld": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "saber_k_gemm_w1d": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "saber_k_gemm_rowln": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "saber_k_layernorm": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
     "saber_k_hiera_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -20,7 +20,6 @@ extern "C" int saber_k_init(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return kfail("hipSetDevice failed");
     const char* m = gemm_init_device();
     if (!m) m = gemm_rowln_init_device();
-    if (!m) m = gemm_w1d_init_device();
     if (!m) m = hiera_attention_init_device();
     if (!m) m = image_ops_init_device();
     if (!m) m = decoder_fused_init_device();
@@ -64,29 +63,6 @@ extern "C" int saber_k_gemm_rowln(const uint16_t* A, int lda, const uint16_t* W,
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.w_kpad = 1; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
     p.M = M; p.N = N; p.K = K; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_out = ln_out; p.ldln = N; p.Wpk = scratch;
     return kcheck(launch_gemm_rowln(p, (hipStream_t)stream));
-}
-
-// gemm_w1d.hip directly (one wave per SIMD, direct-to-LDS operands; 16-bit output, K % 64 == 0).  The kernel reads W packed per K-step: packed
-// here into a per-thread scratch, once per (W, N, K) - repeated calls with the same weight (benchmarks) do not re-pack.
-extern "C" int saber_k_gemm_w1d(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, uint16_t* out16, int M, int N, int K, int act, void* stream) {
-    static thread_local bf16_t* scratch = nullptr;
-    static thread_local size_t scratch_elems = 0;
-    static thread_local const uint16_t* packed_w = nullptr;
-    static thread_local int packed_n = 0, packed_k = 0;
-    const size_t need = gemm_rowln_packed_elems(N, K);
-    if (need > scratch_elems) {
-        if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); scratch = nullptr; scratch_elems = 0; }
-        if (hipMalloc(reinterpret_cast<void**>(&scratch), need * sizeof(bf16_t)) != hipSuccess) return kfail("gemm_w1d: scratch allocation failed");
-        scratch_elems = need; packed_w = nullptr;
-    }
-    if (packed_w != W || packed_n != N || packed_k != K) {
-        if (const char* m = launch_pack_w_kstep(W, ldw, N, K, scratch, (hipStream_t)stream)) return kfail(m);
-        packed_w = W; packed_n = N; packed_k = K;
-    }
-    GemmParams p;
-    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.w_kpad = 1; p.bias = bias; p.Cb = out16; p.ldcb = N; p.M = M; p.N = N; p.K = K; p.act = act; p.Wpk = scratch;
-    if (!gemm_w1d_supported(p)) return kfail("gemm_w1d: unsupported problem (16-bit output, K % 64 == 0, N % 8 == 0)");
-    return kcheck(launch_gemm_w1d(p, (hipStream_t)stream));
 }
 
 extern "C" int saber_k_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* out_f32, uint16_t* out_bf16,

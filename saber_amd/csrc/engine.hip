@@ -202,7 +202,6 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     {
         const char* m = gemm_init_device();
         if (!m) m = gemm_rowln_init_device();
-        if (!m) m = gemm_w1d_init_device();
         if (!m) m = amg_device_init();
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();

@@ -1148,9 +1148,7 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const bool bf16_only = p.Cb && !p.Cf && !p.res && !p.pool4 && (p.N & 7) == 0 && (p.ldcb & 7) == 0 && grid.z == 1 && (p.act == ACT_NONE || p.act == ACT_GELU);
     const int tiles_p2 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     // (the one-wave-per-SIMD experiment of round 3, DESIGN.md section 4, is parked in tools/experiments/gemm_w1.hip: it lost its A/B)
-    // opt-in (SABER_AMD_W1D=1, read once): the one-wave-per-SIMD direct-to-LDS kernel of gemm_w1d.hip for the shapes the 256 x 256 kernel below takes
-    static const bool w1d = getenv("SABER_AMD_W1D") != nullptr;
-    if (w1d && direct_ok && bf16_only && tiles_p2 >= 256 && gemm_w1d_supported(p)) return launch_gemm_w1d(p, stream);
+    // (round 4's one-wave-per-SIMD direct-to-LDS kernel, tools/experiments/gemm_w1d.hip, matched this kernel's K-loop rate and lost on its epilogue: DESIGN.md section 8)
     if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);

@@ -173,9 +173,9 @@ namespace op_f16 {
 // one-time kernel attribute setup: both builds
 #define SABER_OP_INIT(fn)                                                                                                 \
     inline const char* fn() { const char* m = op_bf16::fn(); return m ? m : op_f16::fn(); }
-SABER_OP_INIT(gemm_init_device) SABER_OP_INIT(gemm_rowln_init_device) SABER_OP_INIT(gemm_w1d_init_device) SABER_OP_INIT(hiera_attention_init_device)
+SABER_OP_INIT(gemm_init_device) SABER_OP_INIT(gemm_rowln_init_device) SABER_OP_INIT(hiera_attention_init_device)
 SABER_OP_INIT(decoder_fused_init_device) SABER_OP_INIT(decoder_tokens_init_device)
-SABER_OP_FWD(launch_gemm) SABER_OP_FWD(gemm_w1d_supported) SABER_OP_FWD(launch_gemm_w1d) SABER_OP_FWD(gemm_rowln_supported) SABER_OP_FWD(launch_gemm_rowln) SABER_OP_FWD(gemm_rowln_packed_elems) SABER_OP_FWD(launch_pack_w_kstep)
+SABER_OP_FWD(launch_gemm) SABER_OP_FWD(gemm_rowln_supported) SABER_OP_FWD(launch_gemm_rowln) SABER_OP_FWD(gemm_rowln_packed_elems) SABER_OP_FWD(launch_pack_w_kstep)
 SABER_OP_FWD(launch_layernorm) SABER_OP_FWD(launch_gather_rows) SABER_OP_FWD(launch_add_to_bf16) SABER_OP_FWD(launch_hiera_attention)
 SABER_OP_FWD(launch_prompt_tokens) SABER_OP_FWD(launch_prompt_tokens_multi) SABER_OP_FWD(launch_mask_embed_src) SABER_OP_FWD(launch_mask_hidden) SABER_OP_FWD(launch_embb_tiles)
 SABER_OP_FWD(launch_dec_attention) SABER_OP_FWD(launch_mask_dot) SABER_OP_FWD(launch_mask_pick) SABER_OP_FWD(launch_iou_live_flags) SABER_OP_FWD(launch_mask_select)

@@ -10,10 +10,6 @@ const char* gemm_rowln_init_device();
 // W [N][ldw] (rows zero-padded) -> Wpk[ceil(K/32)][N][32] with the LDS chunk permutation of the row-owner kernel applied
 size_t gemm_rowln_packed_elems(int N, int K);
 const char* launch_pack_w_kstep(const bf16_t* W, int ldw, int N, int K, bf16_t* out, hipStream_t s);
-// one wave per SIMD, 128 x 128 wave tiles, direct-to-LDS operands (gemm_w1d.hip): 16-bit-output GEMMs with K % 64 == 0 and a K-step-packed W
-bool gemm_w1d_supported(const GemmParams& p);
-const char* launch_gemm_w1d(const GemmParams& p, hipStream_t stream);
-const char* gemm_w1d_init_device();
 const char* launch_layernorm(const LayerNormParams& p, hipStream_t s);
 // out[img][r][:] = idx[r] >= 0 ? in[img][idx[r]][:] : 0   (re-ordering between the engine's token orders; fp32 rows of C floats)
 const char* launch_gather_rows(const float* in, int64_t in_rows, float* out, int64_t out_rows, const int* idx, int C, int n_images, hipStream_t s);

@@ -31,10 +31,7 @@ for M, N, K in shapes:
     bias = rnd(N); out = torch.empty(M, N, device="cuda", dtype=DT)
     outf = torch.empty(M, N, device="cuda") if RES else None; res = torch.randn(M, N, device="cuda") if RES else None
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    if os.environ.get('KERNEL') == 'w1d':      # gemm_w1d.hip directly (16-bit output only)
-        def run(): lib.saber_k_gemm_w1d(ptr(A), K, ptr(W), Kp, ptr(bias), ptr(out), M, N, K, ACT, st)
-    else:
-      def run(): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, st)
+    def run(): lib.saber_k_gemm_ld(ptr(A), K, ptr(W), Kp, 1, ptr(bias), ptr(res) if RES else None, ptr(outf) if RES else None, None if RES else ptr(out), M, N, K, ACT, st)
     for d in dbgs:
         if d is not None: lib.saber_k_set_debug(d)
         for _ in range(3): run()
