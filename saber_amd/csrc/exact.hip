@@ -27,11 +27,17 @@ struct XGemm {
     const float* W = nullptr; int64_t ldw = 0; int64_t sW = 0;
     const float* bias = nullptr; int64_t sBias = 0;
     const float* res = nullptr; int64_t ldres = 0; int res_shift = 0; int64_t res_mod = 0;
+    // res_rows_per > 0: per-prompt rows against per-slot tables - the residual of row r is res[((r / res_rows_per + res_off) / res_div) * res_stride +
+    // (r % res_rows_per) * ldres + n] (the xg_add_slot mapping folded into the epilogue)
+    int64_t res_rows_per = 0, res_stride = 0; int res_div = 1, res_off = 0;
+    // A2: the operand is A[m][k] + A2[(m % a2_mod)][k], summed in fp32 before the product exactly as a stored sum would be (keys + dense_pe)
+    const float* A2 = nullptr; int64_t lda2 = 0; int64_t a2_mod = 1;
     float* C = nullptr; int64_t ldc = 0; int64_t sC = 0;
     int M = 0, N = 0, K = 0, act = ACT_NONE, act_last = 0, pool4 = 0, batch = 1;
 };
 
-__device__ __forceinline__ float x_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __attribute__((noinline)) float x_gelu(float x) {   // noinline: 64 epilogue values x libm erff would be 50 k instructions per GEMM kernel
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float x_act(float v, int act) {
     if (act == ACT_GELU) return x_gelu(v);
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
@@ -137,10 +143,155 @@ __global__ __launch_bounds__(256) void xg_gemm_kernel(XGemm p) {
             }
         }
 }
+// The pipelined tile (round 4): 128 x BN outputs per workgroup, 32-deep K steps, operands row-major in LDS ([row][k], rows padded to 36
+// floats: the 16-byte fragment reads of 16 rows x 4 k-quads and the staging writes are conflict-free), each lane reading the four k values
+// of its quad with one ds_read_b128 and feeding MFMA e with element e - the k index of the MFMA is a permutation of the tile's k, identical
+// for A and W.  Global loads are whole 128-byte row pieces (8 lanes per row) and the NEXT K step's loads are in flight during the MFMAs.
+// Every output is still an fp32 fmaf chain over all k; only the order within a 16-k group differs from xg_gemm_kernel (e-major instead
+// of ascending).  Needs K, lda, ldw multiples of 4 and 16-byte aligned bases (every GEMM of the model); others take xg_gemm_kernel.
+template <int BN>
+__global__ __launch_bounds__(256) void xg_gemm2_kernel(XGemm p) {
+    constexpr int LDK = 36, WM = BN == 128 ? 64 : 32, TI = WM / 16, TJ = 4, NB = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[128 * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32;
+    const int wn = BN == 128 ? (wave & 1) * 64 : 0;
+    const int64_t m0 = (int64_t)blockIdx.y * 128;
+    const int n0 = blockIdx.x * BN;
+    const int b = blockIdx.z;
+    const float* A = p.A + b * p.sA;
+    const float* W = p.W + b * p.sW;
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lr = tid >> 3, kq = (tid & 7) * 4;
+    f32x4 pa[4], pb[NB];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // row pointers once (the A2 row index is a modulo: not in the K loop)
+    const float* arow[4];
+    const float* a2row[4];
+    const float* wrow[NB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + lr + 32 * r;
+        arow[r] = row < p.M ? A + row * p.lda + kq : nullptr;
+        a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((unsigned)row % (unsigned)p.a2_mod) * p.lda2 + kq : nullptr;
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        const int n = n0 + lr + 32 * r;
+        wrow[r] = n < p.N ? W + (int64_t)n * p.ldw + kq : nullptr;
+    }
+    auto gload = [&](int k0) {
+        const bool kin = k0 + kq < p.K;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 v = z;
+            if (kin && arow[r]) {
+                v = *reinterpret_cast<const f32x4*>(arow[r] + k0);
+                if (a2row[r]) v += *reinterpret_cast<const f32x4*>(a2row[r] + k0);
+            }
+            pa[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            f32x4 v = z;
+            if (kin && wrow[r]) v = *reinterpret_cast<const f32x4*>(wrow[r] + k0);
+            pb[r] = v;
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < p.K; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * LDK + kq]) = pa[r];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * r) * LDK + kq]) = pb[r];
+        __syncthreads();
+        if (k0 + 32 < p.K) gload(k0 + 32);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[(wm + i * 16 + (lane & 15)) * LDK + h * 16 + (lane >> 4) * 4]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn + j * 16 + (lane & 15)) * LDK + h * 16 + (lane >> 4) * 4]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][2], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][3], bf[j][3], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Row-dependent addressing (the residual's row mapping has integer
+    // divisions) once per row, not per value; rows fit 32 bits (M is an int).
+    float* C = p.C + b * p.sC;
+    const float* bias = p.bias ? p.bias + b * p.sBias : nullptr;
+    float bv[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int n = n0 + wn + j * 16 + (lane & 15);
+        bv[j] = (bias && n < p.N) ? bias[n] : 0.0f;
+    }
+    const int act = p.act, act_last = p.act_last;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int64_t r0 = m0 + wm + i * 16 + (lane >> 4) * 4;
+        if (p.pool4) {   // rows 4q..4q+3 (the lane's four registers) -> output row q
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int n = n0 + wn + j * 16 + (lane & 15);
+                if (n < p.N && r0 < p.M) {
+                    const float v = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])) + bv[j];
+                    C[(r0 >> 2) * p.ldc + n] = x_act(v, act);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + r;
+            if (row >= p.M) continue;
+            const float* resrow = nullptr;
+            if (p.res) {
+                if (p.res_rows_per > 0) {
+                    const unsigned pr = (unsigned)row / (unsigned)p.res_rows_per;
+                    resrow = p.res + (int64_t)((pr + (unsigned)p.res_off) / (unsigned)p.res_div) * p.res_stride + (int64_t)((unsigned)row - pr * (unsigned)p.res_rows_per) * p.ldres;
+                } else {
+                    unsigned rr = (unsigned)row >> p.res_shift;
+                    if (p.res_mod > 0) rr %= (unsigned)p.res_mod;
+                    resrow = p.res + (int64_t)rr * p.ldres;
+                }
+            }
+            float* crow = C + row * p.ldc;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int n = n0 + wn + j * 16 + (lane & 15);
+                if (n >= p.N) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (!act_last) v = x_act(v, act);
+                if (resrow) v += resrow[n];
+                if (act_last) v = x_act(v, act);
+                crow[n] = v;
+            }
+        }
+    }
+}
 static const char* xg_gemm(const XGemm& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return nullptr;
     if (!p.A || !p.W || !p.C || p.K <= 0) return "exact gemm: bad argument";
     if (p.pool4 && (p.M % 4)) return "exact gemm: pool4 needs M % 4 == 0";
+    const bool vec = ((p.lda | p.ldw | p.sA | p.sW | (int64_t)p.K) & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0 &&
+                     (!p.A2 || (((p.lda2 & 3) == 0) && (reinterpret_cast<uintptr_t>(p.A2) & 15) == 0));
+    if (!vec && (p.A2 || p.res_rows_per > 0)) return "exact gemm: the fused operand sum / slot residual need 16-byte rows";
+    const int bn = !vec ? XG_BN : (p.N > 64 ? 128 : 64);
     const int64_t gy = ((int64_t)p.M + XG_BM - 1) / XG_BM;
     if (gy > 65535 * 32) return "exact gemm: M too large";
     // gridDim.y is limited to 65535: large M is split into row slabs
@@ -152,11 +303,15 @@ static const char* xg_gemm(const XGemm& p, hipStream_t s) {
         q.A = p.A + rows0 * p.lda;
         q.C = p.C + (p.pool4 ? rows0 / 4 : rows0) * p.ldc;
         q.M = (int)std::min<int64_t>((int64_t)p.M - rows0, ny * XG_BM);
+        if (y0 > 0 && (p.A2 || p.res_rows_per > 0)) return "exact gemm: fused operand sum / slot residual with M beyond one slab";
         if (p.res) {
             if (p.res_mod > 0 || p.res_shift) { if (y0 > 0) return "exact gemm: residual mapping with M beyond one slab"; }
-            else q.res = p.res + rows0 * p.ldres;
+            else if (p.res_rows_per <= 0) q.res = p.res + rows0 * p.ldres;
         }
-        hipLaunchKernelGGL(xg_gemm_kernel, dim3((p.N + XG_BN - 1) / XG_BN, (unsigned)ny, p.batch), dim3(256), 0, s, q);
+        const dim3 grid((p.N + bn - 1) / bn, (unsigned)ny, p.batch);
+        if (!vec) hipLaunchKernelGGL(xg_gemm_kernel, grid, dim3(256), 0, s, q);
+        else if (bn == 128) hipLaunchKernelGGL(xg_gemm2_kernel<128>, grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL(xg_gemm2_kernel<64>, grid, dim3(256), 0, s, q);
     }
     return nullptr;
 }
@@ -305,9 +460,127 @@ __global__ __launch_bounds__(128) void xg_attn_kernel(const float* __restrict__ 
         for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
     }
 }
+// Few queries against many keys (the decoder's token -> image attention: 7 + n_pts <= 16 queries, 4 096 keys per prompt and head).  The
+// one-thread-per-query kernel above puts 8 192 threads on the chip for it; here a workgroup of 256 threads owns one (prompt, head), every thread
+// takes the keys j = tid, tid + 256, ... against ALL the queries with its own online softmax (running maximum, sum, HD accumulators per
+// query), and the partial results are merged at the end (rescaled to the common maximum; wave reduction, then the 4 waves through LDS).
+// Same products and fp32 accumulation as the kernel above; only the order of the softmax sums over keys differs (~1e-7 relative).
+template <int HD, int TQ>
+__global__ __launch_bounds__(256) void xg_attn_fewq_kernel(const float* __restrict__ q, int64_t q_bs, int ldq, const float* __restrict__ k, int64_t k_bs, int ldk,
+                                                          const float* __restrict__ v, int64_t v_bs, int ldv, float* __restrict__ o, int64_t o_bs, int ldo,
+                                                          int nq, int nk, float scale) {
+    __shared__ float qs[TQ][HD];
+    __shared__ float part[4][TQ][HD + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, h = blockIdx.y;
+    const float* kb = k + b * k_bs + h * HD;
+    const float* vb = v + b * v_bs + h * HD;
+    for (int q0 = 0; q0 < nq; q0 += TQ) {
+        const int tq = min(TQ, nq - q0);
+        __syncthreads();
+        for (int idx = tid; idx < TQ * HD; idx += 256) {
+            const int t = idx / HD, d = idx - t * HD;
+            qs[t][d] = t < tq ? q[b * q_bs + (int64_t)(q0 + t) * ldq + h * HD + d] : 0.0f;
+        }
+        __syncthreads();
+        float m[TQ], l[TQ], acc[TQ][HD];
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[t][d] = 0.f;
+        }
+        for (int j0 = tid; j0 < nk; j0 += 256 * 4) {
+            float sc[4][TQ];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = j0 + 256 * c;
+                if (j < nk) {
+                    float kr[HD];
+                    const float4* kp = reinterpret_cast<const float4*>(kb + (int64_t)j * ldk);
+#pragma unroll
+                    for (int d4 = 0; d4 < HD / 4; ++d4) { const float4 x = kp[d4]; kr[4 * d4] = x.x; kr[4 * d4 + 1] = x.y; kr[4 * d4 + 2] = x.z; kr[4 * d4 + 3] = x.w; }
+#pragma unroll
+                    for (int t = 0; t < TQ; ++t) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) a = fmaf(qs[t][d], kr[d], a);
+                        sc[c][t] = a * scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TQ; ++t) sc[c][t] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) {
+                const float mt = fmaxf(fmaxf(sc[0][t], sc[1][t]), fmaxf(sc[2][t], sc[3][t]));      // finite: key j0 exists
+                const float mnew = fmaxf(m[t], mt);
+                const float corr = expf(m[t] - mnew);                                              // exp(-inf) = 0 on the first chunk
+                l[t] *= corr;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) acc[t][d] *= corr;
+                m[t] = mnew;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = j0 + 256 * c;
+                if (j >= nk) continue;
+                float vr[HD];
+                const float4* vp = reinterpret_cast<const float4*>(vb + (int64_t)j * ldv);
+#pragma unroll
+                for (int d4 = 0; d4 < HD / 4; ++d4) { const float4 x = vp[d4]; vr[4 * d4] = x.x; vr[4 * d4 + 1] = x.y; vr[4 * d4 + 2] = x.z; vr[4 * d4 + 3] = x.w; }
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) {
+                    const float pj = expf(sc[c][t] - m[t]);
+                    l[t] += pj;
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) acc[t][d] = fmaf(pj, vr[d], acc[t][d]);
+                }
+            }
+        }
+        // merge: the wave's threads to their common maximum, then the four waves
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const float M = wave_max(m[t]);
+            const float f = (m[t] == -INFINITY) ? 0.0f : expf(m[t] - M);
+            const float L = wave_sum(l[t] * f);
+            if (lane == 0) { part[wave][t][HD] = M; part[wave][t][HD + 1] = L; }
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                const float a = wave_sum(acc[t][d] * f);
+                if (lane == 0) part[wave][t][d] = a;
+            }
+        }
+        __syncthreads();
+        if (tid < TQ * HD) {
+            const int t = tid / HD, d = tid - t * HD;
+            if (t < tq) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) M = fmaxf(M, part[w][t][HD]);
+                float L = 0.f, A = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float mw = part[w][t][HD];
+                    const float f = (mw == -INFINITY) ? 0.0f : expf(mw - M);
+                    L += part[w][t][HD + 1] * f;
+                    A += part[w][t][d] * f;
+                }
+                const float inv = 1.0f / L;
+                o[b * o_bs + (int64_t)(q0 + t) * ldo + h * HD + d] = A * inv;
+            }
+        }
+    }
+}
 static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const float* k, int64_t k_bs, int ldk, const float* v, int64_t v_bs, int ldv,
                            float* o, int64_t o_bs, int ldo, int nq, int nk, int batch, int heads, int qpool, const uint8_t* kmask, float scale, hipStream_t s) {
     if (batch <= 0 || nq <= 0) return nullptr;
+    if (hd == 16 && nq <= 16 && nk >= 1024 && !qpool && !kmask && heads <= 65535 && ((ldk | ldv) & 3) == 0 && (((k_bs | v_bs) & 3) == 0) &&
+        ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(batch, heads), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
+        return nullptr;
+    }
     const dim3 grid((nq + 127) / 128, 1, heads), block(128);
     // gridDim.y <= 65535
     for (int b0 = 0; b0 < batch; b0 += 65535) {
@@ -409,7 +682,7 @@ __global__ __launch_bounds__(256) void xg_mask_dot_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ workspaces
 struct ExactWs {
-    // encoder (one image at a time)
+    // encoder (the n <= max_images crops of a pass as ONE batch of n x tokens rows)
     float *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *sb[4] = {nullptr, nullptr, nullptr, nullptr}, *lat3 = nullptr;
     // decoder (chunks of pc prompts)
     int pc = 0;
@@ -424,13 +697,13 @@ static int ensure_ws(saber_engine* e) {
     if (e->exact_ws) return SABER_OK;
     ExactWs* w = new ExactWs();
     e->exact_ws = w;
-    const size_t C0 = (size_t)e->embed_dim;
-    TRY(eng_alloc(e, &w->xn, 65536 * C0));
-    TRY(eng_alloc(e, &w->qkv, 65536 * 6 * C0));
-    TRY(eng_alloc(e, &w->att, 65536 * C0));
-    TRY(eng_alloc(e, &w->hid, 65536 * 4 * C0));
-    for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &w->sb[s], (size_t)e->tok_rows[s] * (C0 << s)));
-    TRY(eng_alloc(e, &w->lat3, (size_t)e->tok_rows[3] * 256));
+    const size_t C0 = (size_t)e->embed_dim, NI = (size_t)e->max_images;      // the whole pass of up to max_images crops at once (round 4)
+    TRY(eng_alloc(e, &w->xn, NI * 65536 * C0));
+    TRY(eng_alloc(e, &w->qkv, NI * 65536 * 6 * C0));
+    TRY(eng_alloc(e, &w->att, NI * 65536 * C0));
+    TRY(eng_alloc(e, &w->hid, NI * 65536 * 4 * C0));
+    for (int s = 0; s < 4; ++s) TRY(eng_alloc(e, &w->sb[s], NI * (size_t)e->tok_rows[s] * (C0 << s)));
+    TRY(eng_alloc(e, &w->lat3, NI * (size_t)e->tok_rows[3] * 256));
     const size_t P = w->pc = exact_chunk_prompts(e);
     TRY(eng_alloc(e, &w->keys, P * 4096 * 256));
     TRY(eng_alloc(e, &w->kpe, P * 4096 * 256));
@@ -472,15 +745,19 @@ int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s) {
     const int C0 = e->embed_dim;
     const size_t nblocks = e->blocks.size();
     const float hscale = 1.0f / sqrtf((float)e->head_dim);
-    for (int img = 0; img < n; ++img) {
-        float* x = e->xa + (size_t)img * 65536 * C0;
-        float* xalt = e->xb + (size_t)img * 65536 * C0;
-        int tokens = 65536, stage = 0;
-        XK(xg_layernorm(x, e->bw[0].n1, 1e-6f, w->xn, tokens, e->blocks[0].din, ACT_NONE, s, e->valid[0], tokens));
+    if (n > e->max_images) return eng_fail(e, SABER_ERR_INVALID, "exact encode: more images than max_images");
+    // Every image of the pass goes through each block together: the rows of the GEMMs, LayerNorms and attention batches are n x (tokens of one
+    // image).  Row r of image i computes exactly what it computed alone (no kernel mixes rows of different windows / images); round 3 looped
+    // over the images, which left the small-M GEMMs and the global attention of stages 3 / 4 with one workgroup per CU.
+    {
+        float* x = e->xa;
+        float* xalt = e->xb;
+        int tokens = 65536, stage = 0;                        // tokens of ONE image; N below = rows of the batch
+        XK(xg_layernorm(x, e->bw[0].n1, 1e-6f, w->xn, (int64_t)n * tokens, e->blocks[0].din, ACT_NONE, s, e->valid[0], tokens));
         for (size_t i = 0; i < nblocks; ++i) {
             const BlockSpec& bs = e->blocks[i];
             const BlockW& b = e->bw[i];
-            const int N = tokens;
+            const int N = n * tokens;
             float* xres = x;
             int Nq = N;
             if (bs.din != bs.dout) {     // shortcut = 2 x 2 max-pool of proj(norm1(x))
@@ -519,34 +796,33 @@ int exact_encode_blocks(saber_engine* e, int n, int slot0, hipStream_t s) {
             if ((int)i == e->stage_ends[stage])
                 ENG_HIP(e, hipMemcpyAsync(w->sb[stage], x, sizeof(float) * (size_t)Nq * bs.dout, hipMemcpyDeviceToDevice, s));
             if (e->padded && bs.din != bs.dout && stage == 2) {
-                XK(launch_gather_rows(x, 4096, xalt, e->tok_rows[2], e->pack_idx, bs.dout, 1, s));
+                XK(launch_gather_rows(x, 4096, xalt, e->tok_rows[2], e->pack_idx, bs.dout, n, s));
                 std::swap(x, xalt);
                 tokens = e->tok_rows[2];
             }
-            if (i + 1 < nblocks) XK(xg_layernorm(x, e->bw[i + 1].n1, 1e-6f, w->xn, tokens, bs.dout, ACT_NONE, s, e->valid[stage], tokens));
+            if (i + 1 < nblocks) XK(xg_layernorm(x, e->bw[i + 1].n1, 1e-6f, w->xn, (int64_t)n * tokens, bs.dout, ACT_NONE, s, e->valid[stage], tokens));
         }
-        // neck + conv_s0 / conv_s1 (composed with their lateral convs at finalize, in double)
-        const int slot = slot0 + img;
+        // neck + conv_s0 / conv_s1 (composed with their lateral convs at finalize, in double); slots slot0 .. slot0 + n - 1 are contiguous
         {
-            XGemm g = mkx(w->sb[3], e->stage_dims[3], e->tok_rows[3], e->neck3);
+            XGemm g = mkx(w->sb[3], e->stage_dims[3], n * e->tok_rows[3], e->neck3);
             g.C = w->lat3; g.ldc = 256;
             XK(xg_gemm(g, s));
         }
         {
-            float* emb_slot = e->emb + (size_t)slot * 4096 * 256;
-            XGemm g = mkx(w->sb[2], e->stage_dims[2], e->tok_rows[2], e->neck2);
-            g.C = e->padded ? w->hid : emb_slot; g.ldc = 256; g.res = w->lat3; g.ldres = 256; g.res_shift = 2;
+            float* emb_slot = e->emb + (size_t)slot0 * 4096 * 256;
+            XGemm g = mkx(w->sb[2], e->stage_dims[2], n * e->tok_rows[2], e->neck2);
+            g.C = e->padded ? w->hid : emb_slot; g.ldc = 256; g.res = w->lat3; g.ldres = 256; g.res_shift = 2;      // 4 x tok_rows[3] = tok_rows[2]: the shift holds across images
             XK(xg_gemm(g, s));
-            if (e->padded) XK(launch_gather_rows(w->hid, e->tok_rows[2], emb_slot, 4096, e->unpack_idx, 256, 1, s));
+            if (e->padded) XK(launch_gather_rows(w->hid, e->tok_rows[2], emb_slot, 4096, e->unpack_idx, 256, n, s));
         }
         {
-            XGemm g = mkx(w->sb[1], e->stage_dims[1], 16384, e->s1);
-            g.C = e->fs1 + (size_t)slot * 16384 * 64; g.ldc = 64;
+            XGemm g = mkx(w->sb[1], e->stage_dims[1], n * 16384, e->s1);
+            g.C = e->fs1 + (size_t)slot0 * 16384 * 64; g.ldc = 64;
             XK(xg_gemm(g, s));
         }
         {
-            XGemm g = mkx(w->sb[0], e->stage_dims[0], 65536, e->s0);
-            g.C = e->fs0 + (size_t)slot * 65536 * 32; g.ldc = 32;
+            XGemm g = mkx(w->sb[0], e->stage_dims[0], n * 65536, e->s0);
+            g.C = e->fs0 + (size_t)slot0 * 65536 * 32; g.ldc = 32;
             XK(xg_gemm(g, s));
         }
     }
@@ -597,8 +873,11 @@ int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, cons
     auto t2i = [&](const AttnW& a, const LnW& ln) -> int {
         xg_add(queries, tokpe, 0, w->t0, PT, 256, s);
         XK(lin(w->t0, 256, PT, a.q, w->tq, 128));
-        xg_add(w->keys, e->dense_pe, 4096, w->kpe, NI, 256, s);
-        XK(lin(w->kpe, 256, NI, a.k, w->p0, 128));
+        {   // k_proj(keys + pos): the sum is formed in the GEMM's operand load (fp32, rounded once, as the stored sum was)
+            XGemm g = mkx(w->keys, 256, (int)NI, a.k);
+            g.A2 = e->dense_pe; g.lda2 = 256; g.a2_mod = 4096; g.C = w->p0; g.ldc = 128;
+            XK(xg_gemm(g, s));
+        }
         XK(lin(w->keys, 256, NI, a.v, w->p1, 128));
         XK(xg_attn(16, w->tq, (int64_t)T * 128, 128, w->p0, (int64_t)4096 * 128, 128, w->p1, (int64_t)4096 * 128, 128, w->ta, (int64_t)T * 128, 128, T, 4096, P, 8, 0,
                    nullptr, 0.25f, s));
@@ -628,8 +907,11 @@ int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, cons
         xg_add(queries, tokpe, 0, w->t0, PT, 256, s);
         XK(lin(w->t0, 256, PT, d.i2t.k, w->tk, 128));
         XK(lin(queries, 256, PT, d.i2t.v, w->tv, 128));
-        xg_add(w->keys, e->dense_pe, 4096, w->kpe, NI, 256, s);
-        XK(lin(w->kpe, 256, NI, d.i2t.q, w->p0, 128));
+        {
+            XGemm g = mkx(w->keys, 256, (int)NI, d.i2t.q);
+            g.A2 = e->dense_pe; g.lda2 = 256; g.a2_mod = 4096; g.C = w->p0; g.ldc = 128;
+            XK(xg_gemm(g, s));
+        }
         XK(xg_attn(16, w->p0, (int64_t)4096 * 128, 128, w->tk, (int64_t)T * 128, 128, w->tv, (int64_t)T * 128, 128, w->patt, (int64_t)4096 * 128, 128, 4096, T, P, 8, 0,
                    nullptr, 0.25f, s));
         XK(lin(w->patt, 128, NI, d.i2t.o, w->kpe, 256, w->keys));
@@ -659,11 +941,21 @@ int exact_decode_core(saber_engine* e, int slot0, int per_slot, int p_base, cons
     }
     // upscaling: ConvTranspose2d(256 -> 64, k2 s2) as a GEMM whose N index is (ky*2+kx)*64 + co: row t of the 64^2 grid becomes rows
     // 4t .. 4t+3 of the 128^2 grid in the engine's token order; + feat_s1; LayerNorm2d; GELU; the same for 64 -> 32 with feat_s0; GELU
-    XK(lin(w->keys, 256, NI, e->dc1, w->up1, 256));
-    xg_add_slot(w->up1, e->fs1 + (size_t)slot0 * 16384 * 64, XMap{(int64_t)16384 * 64, per_slot, p_base}, nullptr, w->up1, 16384, 64, P, ACT_NONE, s);
+    // (+ feat_s1 / feat_s0 of the prompt's slot in the GEMM epilogues: output row t, column n of the first GEMM is element t * 256 + n of the
+    // slot's 128^2 x 64 map in the engine's token order, likewise t * 128 + n of the 256^2 x 32 map for the second)
+    {
+        XGemm g = mkx(w->keys, 256, (int)NI, e->dc1);
+        g.C = w->up1; g.ldc = 256;
+        g.res = e->fs1 + (size_t)slot0 * 16384 * 64; g.ldres = 256; g.res_rows_per = 4096; g.res_stride = (int64_t)16384 * 64; g.res_div = per_slot; g.res_off = p_base;
+        XK(xg_gemm(g, s));
+    }
     XK(xg_layernorm(w->up1, e->up_ln, 1e-6f, w->up1, (int64_t)P * 16384, 64, ACT_GELU, s));
-    XK(lin(w->up1, 64, (int64_t)P * 16384, e->dc2, w->up2, 128));
-    xg_add_slot(w->up2, e->fs0 + (size_t)slot0 * 65536 * 32, XMap{(int64_t)65536 * 32, per_slot, p_base}, nullptr, w->up2, 65536, 32, P, ACT_GELU, s);
+    {
+        XGemm g = mkx(w->up1, 64, (int)((int64_t)P * 16384), e->dc2);
+        g.C = w->up2; g.ldc = 128; g.act = ACT_GELU; g.act_last = 1;
+        g.res = e->fs0 + (size_t)slot0 * 65536 * 32; g.ldres = 128; g.res_rows_per = 16384; g.res_stride = (int64_t)65536 * 32; g.res_div = per_slot; g.res_off = p_base;
+        XK(xg_gemm(g, s));
+    }
     hipLaunchKernelGGL(xg_mask_dot_kernel, dim3((unsigned)(((int64_t)P * 65536 + 255) / 256)), dim3(256), 0, s, w->up2, e->hyper_out, P, masks4);
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;

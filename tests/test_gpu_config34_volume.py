@@ -20,10 +20,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # The GPU suite has a 900-s step limit at the driver (676 s of it were used).  By default the two tomograms are cut to a
-# quarter of their depth - every check below is written in terms of Z - and SABER_AMD_FULLSIZE=1 runs them at BASELINE's 512 / 256 slices
+# eighth of their depth - every check below is written in terms of Z - and SABER_AMD_FULLSIZE=1 runs them at BASELINE's 512 / 256 slices
 # (profiles/r03_configs34_fullsize_tests.log holds the full-size run of round 3; round 4's is profiles/r04_configs34_fullsize_tests.log).
 FULL = os.environ.get("SABER_AMD_FULLSIZE", "0") == "1"
-Z3, Z4 = (512, 256) if FULL else (128, 64)
+Z3, Z4 = (512, 256) if FULL else (64, 32)
 
 
 @pytest.fixture(scope="module")

@@ -22,6 +22,13 @@ def ck(lib, st):
 
 
 _ALIVE = []
+_ORACLE_FEATS = {}
+
+
+def _oracle_memo(W):
+    """frame content -> oracle features, shared by the oracle predictors built over the SAME weight dict (kept alive here so that its id
+    cannot be handed to another dict); every test of this module would otherwise re-encode the same 7 frames on the CPU"""
+    return _ORACLE_FEATS.setdefault(id(W), (W, {}))[1]
 
 
 def dev(t):
@@ -133,6 +140,7 @@ def _track_compare(cfg, W, vp, tomo, seed, start, bounds):
     ref_frames = V.load_tomogram_frames(tomo)
     assert np.abs(frames - ref_frames[:, 0].numpy()).max() < 1e-5
     P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.feat_memo = _oracle_memo(W)
     P.init_state(ref_frames)
     P.add_new_mask(start, 1, seed)
     ref_out = {}
@@ -203,6 +211,7 @@ def test_segment_volume_adapter_against_oracle(video_case):
     from saber_amd.adapters.sam2.predictor import SAM2Adapter
     cfg, W, vp, tomo, seed = video_case
     P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.feat_memo = _oracle_memo(W)
     P.init_state(V.load_tomogram_frames(tomo))
     ref_vol, ref_metrics, ref_scores = V.segment_volume_ref(P, 3, [seed], tomo.shape, min_presence_score=0.5)
     ad = SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0")
@@ -259,6 +268,7 @@ def test_add_new_points_single_click_against_oracle(video_case):
     cfg, W, vp, tomo, seed = video_case
     frames = load_tomogram_frames(tomo)
     P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.feat_memo = _oracle_memo(W)
     P.init_state(V.load_tomogram_frames(tomo), video_hw=(1024, 1024))
     vp.init_state(frames, video_hw=(1024, 1024))
     click, lab = np.array([[512.0, 500.0]], np.float32), np.array([1], np.int32)
@@ -307,6 +317,7 @@ def test_box_and_several_clicks_against_oracle():
         rng = np.random.default_rng(5)
         tomo = rng.uniform(-1, 1, (5, 128, 128)).astype(np.float32)
         P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+        P.feat_memo = _oracle_memo(W)
         for case in ("box+click", "two calls"):          # (a box alone: tests/test_gpu_exact.py at the decoder level)
             P.init_state(V.load_tomogram_frames(tomo), video_hw=(1024, 1024))
             vp.init_state(load_tomogram_frames(tomo), video_hw=(1024, 1024))
@@ -377,6 +388,7 @@ def test_two_objects_segment_volume_against_oracle(video_case):
     yy, xx = np.mgrid[:128, :128]
     seed2 = ((yy - 40) ** 2 + (xx - 90) ** 2 < 14 ** 2).astype(np.float32)
     P = V.VideoPredictorRef(W, cfg, num_maskmem=2)
+    P.feat_memo = _oracle_memo(W)
     P.init_state(V.load_tomogram_frames(tomo))
     ref_vol, ref_metrics, ref_scores = V.segment_volume_ref(P, 2, [seed, seed2], tomo.shape, min_presence_score=0.0)
     ad = SAM2Adapter(SAM2AdapterConfig(cfg="tiny"), device="cuda:0")
