@@ -32,6 +32,7 @@ struct XGemm {
     int64_t res_rows_per = 0, res_stride = 0; int res_div = 1, res_off = 0;
     // A2: the operand is A[m][k] + A2[(m % a2_mod)][k], summed in fp32 before the product exactly as a stored sum would be (keys + dense_pe)
     const float* A2 = nullptr; int64_t lda2 = 0; int64_t a2_mod = 1;
+    int64_t row0 = 0;      // first row of this launch within the whole GEMM (row slabs): the A2 and slot-residual mappings count from there
     float* C = nullptr; int64_t ldc = 0; int64_t sC = 0;
     int M = 0, N = 0, K = 0, act = ACT_NONE, act_last = 0, pool4 = 0, batch = 1;
 };
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void xg_gemm_kernel(XGemm p) {
 // Every output is still an fp32 fmaf chain over all k; only the order within a 16-k group differs from xg_gemm_kernel (e-major instead
 // of ascending).  Needs K, lda, ldw multiples of 4 and 16-byte aligned bases (every GEMM of the model); others take xg_gemm_kernel.
 template <int BN>
-__global__ __launch_bounds__(256) void xg_gemm2_kernel(XGemm p) {
+__global__ __launch_bounds__(256, 3) void xg_gemm2_kernel(XGemm p) {
     constexpr int LDK = 36, WM = BN == 128 ? 64 : 32, TI = WM / 16, TJ = 4, NB = BN / 32;
     __shared__ __attribute__((aligned(16))) float As[128 * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void xg_gemm2_kernel(XGemm p) {
     for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + lr + 32 * r;
         arow[r] = row < p.M ? A + row * p.lda + kq : nullptr;
-        a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((unsigned)row % (unsigned)p.a2_mod) * p.lda2 + kq : nullptr;
+        a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((uint64_t)(row + p.row0) % (uint64_t)p.a2_mod) * p.lda2 + kq : nullptr;
     }
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
@@ -262,8 +263,9 @@ __global__ __launch_bounds__(256) void xg_gemm2_kernel(XGemm p) {
             const float* resrow = nullptr;
             if (p.res) {
                 if (p.res_rows_per > 0) {
-                    const unsigned pr = (unsigned)row / (unsigned)p.res_rows_per;
-                    resrow = p.res + (int64_t)((pr + (unsigned)p.res_off) / (unsigned)p.res_div) * p.res_stride + (int64_t)((unsigned)row - pr * (unsigned)p.res_rows_per) * p.ldres;
+                    const unsigned grow = (unsigned)(row + p.row0);      // < 2^32: at most 65535 * 32 tiles of 128 rows are accepted
+                    const unsigned pr = grow / (unsigned)p.res_rows_per;
+                    resrow = p.res + (int64_t)((pr + (unsigned)p.res_off) / (unsigned)p.res_div) * p.res_stride + (int64_t)(grow - pr * (unsigned)p.res_rows_per) * p.ldres;
                 } else {
                     unsigned rr = (unsigned)row >> p.res_shift;
                     if (p.res_mod > 0) rr %= (unsigned)p.res_mod;
@@ -303,7 +305,7 @@ static const char* xg_gemm(const XGemm& p, hipStream_t s) {
         q.A = p.A + rows0 * p.lda;
         q.C = p.C + (p.pool4 ? rows0 / 4 : rows0) * p.ldc;
         q.M = (int)std::min<int64_t>((int64_t)p.M - rows0, ny * XG_BM);
-        if (y0 > 0 && (p.A2 || p.res_rows_per > 0)) return "exact gemm: fused operand sum / slot residual with M beyond one slab";
+        q.row0 = rows0;
         if (p.res) {
             if (p.res_mod > 0 || p.res_shift) { if (y0 > 0) return "exact gemm: residual mapping with M beyond one slab"; }
             else if (p.res_rows_per <= 0) q.res = p.res + rows0 * p.ldres;
@@ -339,10 +341,68 @@ __global__ __launch_bounds__(256) void xg_layernorm_kernel(const float* __restri
     const float rstd = 1.0f / sqrtf(var + eps);
     for (int c = lane; c < C; c += 64) o[c] = x_act((xr[c] - mu) * rstd * g[c] + be[c], act);
 }
+// Register-resident rows (round 4): LPR lanes share a row (64, or 16 for the 64-channel LayerNorm2d of the upscaling: 4 rows per wave), every
+// lane keeps its float4 pieces, so a row is read once (the kernel above reads it three times) with 16-byte accesses.  Two-pass statistics as
+// above; only the order of the sums differs.  C % 4 == 0, C <= 1280.
+template <int LPR>
+__global__ __launch_bounds__(256) void xg_layernorm4_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
+                                                           float eps, float* __restrict__ out, int64_t rows, int C, int act,
+                                                           const uint8_t* __restrict__ row_valid, int valid_mod) {
+    constexpr int RPW = 64 / LPR, NV = LPR == 64 ? 5 : 1;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rw = lane / LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + rw;
+    const bool live = row < rows;
+    const int C4 = C >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * C);
+    f32x4* o = reinterpret_cast<f32x4*>(out + row * C);
+    if (LPR == 64 && row_valid && live && !row_valid[row % valid_mod]) {      // wave-uniform: one row per wave
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c = sub; c < C4; c += 64) o[c] = z;
+        return;
+    }
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int c = sub + LPR * t;
+        v[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (live && c < C4) v[t] = xr[c];
+        sum += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    }
+    const float mu = (LPR == 64 ? wave_sum(sum) : row16_sum(sum)) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int c = sub + LPR * t;
+        if (c < C4) {
+            const f32x4 d = v[t] - mu;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float var = (LPR == 64 ? wave_sum(sq) : row16_sum(sq)) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int c = sub + LPR * t;
+        if (c >= C4) continue;
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[c], bb = reinterpret_cast<const f32x4*>(be)[c];
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = x_act((v[t][q] - mu) * rstd * gg[q] + bb[q], act);
+        o[c] = r;
+    }
+}
 static const char* xg_layernorm(const float* x, const LnW& w, float eps, float* out, int64_t rows, int C, int act, hipStream_t s,
                                 const uint8_t* row_valid = nullptr, int valid_mod = 0) {
     if (rows <= 0) return nullptr;
-    hipLaunchKernelGGL(xg_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+    const bool al = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w.g) | reinterpret_cast<uintptr_t>(w.b)) & 15) == 0;
+    if (al && C == 64 && !row_valid)
+        hipLaunchKernelGGL(xg_layernorm4_kernel<16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+    else if (al && C <= 1280)
+        hipLaunchKernelGGL(xg_layernorm4_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+    else
+        hipLaunchKernelGGL(xg_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
     return nullptr;
 }
 
@@ -691,7 +751,9 @@ struct ExactWs {
 };
 static ExactWs* ws_of(saber_engine* e) { return reinterpret_cast<ExactWs*>(e->exact_ws); }
 
-int exact_chunk_prompts(const saber_engine* e) { return std::min(e->max_prompts, 128); }
+// 512 prompts per pass (round 3: 128): ~14 GB of fp32 workspaces on a handle with max_prompts >= 512, a quarter of the launches, and the
+// token-side GEMMs (8 rows per prompt) get 4 096 rows instead of 1 024
+int exact_chunk_prompts(const saber_engine* e) { return std::min(e->max_prompts, 512); }
 
 static int ensure_ws(saber_engine* e) {
     if (e->exact_ws) return SABER_OK;
