@@ -49,6 +49,43 @@ def test_mrc_hand_built_big_endian_with_extended_header(tmp_path):
         read_mrc(p)
 
 
+def test_tiff_against_pillow(tmp_path):
+    """The TIFF bytes against an INDEPENDENT reader / writer that this image does have (Pillow's TIFF plugin; skimage / tifffile, which the
+    reference calls through skimage.io at saber/utils/io.py:56-57 and :151-155, are absent): files written by saber_amd.utils.tiff.imsave
+    open in Pillow with the same pixels - one page and the multi-page label volume mask3D_to_tiff writes - and files Pillow writes
+    (uncompressed, its own tag order and strip layout) are read back identically by imread."""
+    Image = pytest.importorskip("PIL.Image")
+    from saber_amd.utils import io
+    from saber_amd.utils.tiff import imread, imsave
+    rng = np.random.default_rng(3)
+    for dt, mode in ((np.uint8, "L"), (np.uint16, "I;16"), (np.float32, "F"), (np.int32, "I")):
+        a = rng.uniform(0, 200, (13, 17)).astype(dt)
+        p = str(tmp_path / f"w_{mode.replace(';', '')}.tif")
+        imsave(p, a)
+        with Image.open(p) as im:
+            assert im.mode == mode and im.size == (17, 13)
+            assert np.array_equal(np.array(im), a)
+        if mode != "I":
+            q = str(tmp_path / f"p_{mode.replace(';', '')}.tif")
+            Image.fromarray(a).save(q)
+            back = imread(q)
+            assert back.dtype == a.dtype and np.array_equal(back, a)
+    vol = (np.arange(3 * 5 * 7).reshape(3, 5, 7) % 4).astype(np.uint8)
+    p = str(tmp_path / "labels.tif")
+    io.mask3D_to_tiff(vol, p)
+    with Image.open(p) as im:
+        assert im.n_frames == 3
+        pages = []
+        for i in range(3):
+            im.seek(i)
+            pages.append(np.array(im))
+    assert np.array_equal(np.stack(pages), vol)
+    q = str(tmp_path / "pil_pages.tif")
+    ims = [Image.fromarray(vol[i]) for i in range(3)]
+    ims[0].save(q, save_all=True, append_images=ims[1:])
+    assert np.array_equal(imread(q), vol)
+
+
 def test_tiff_round_trip_and_hand_built_big_endian(tmp_path):
     from saber_amd.utils.tiff import imread, imsave
     rng = np.random.default_rng(1)
