@@ -638,6 +638,21 @@ def main():
             for e_ in engines:
                 e_.close()
             engines.clear()
+        try:        # the exact (fp32-operand) mode on the same step: ONE handle, the whole slice (21 crops, 3 072 + 9 216 prompts); a verification mode, never part of `value`
+            ex_eng = Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, precision="exact")
+            ex_eng.set_iou_pruning(False)
+            step(0, engine=ex_eng)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(2):
+                step(i, engine=ex_eng)
+            torch.cuda.synchronize()
+            dte = (time.perf_counter() - t0) / 2
+            out["alt_dtypes"]["exact"] = {"slices_per_s": 1.0 / dte, "ms_per_slice": dte * 1e3, "slices": 2, "engine_handles": 1, "vs_headline": (dt / a.steps) / dte,
+                                          "what": "csrc/exact.hip: fp32 operands end to end on v_mfma_f32_16x16x4_f32, ~1e-6 from the fp32 oracle (tests/test_gpu_exact.py)"}
+            ex_eng.close()
+        except Exception as ex:
+            out["alt_dtypes"]["exact"] = {"error": str(ex)[:300]}
         eng = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, weights, img01_cpu, a.crop_n_layers)
