@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 3) void xg_gemm2_kernel(XGemm p) {
     for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + lr + 32 * r;
         arow[r] = row < p.M ? A + row * p.lda + kq : nullptr;
-        a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((uint64_t)(row + p.row0) % (uint64_t)p.a2_mod) * p.lda2 + kq : nullptr;
+        a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((unsigned)(row + p.row0) % (unsigned)p.a2_mod) * p.lda2 + kq : nullptr;      // (rows < 2^32: 32-bit modulo)
     }
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
@@ -456,8 +456,9 @@ __global__ __launch_bounds__(128) void xg_attn_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float Ks[XA_TK][HD];
     __shared__ __attribute__((aligned(16))) float Vs[XA_TK][HD];
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, h = blockIdx.z;
-    const int i = blockIdx.x * 128 + tid;
+    // heads vary fastest over the grid: the 8 heads' 64-byte pieces of a q / k / v row share its cache lines while they are in L2
+    const int h = blockIdx.x, b = blockIdx.z;
+    const int i = blockIdx.y * 128 + tid;
     const bool live = i < nq;
     float qv[HD], acc[HD];
 #pragma unroll
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256) void xg_attn_fewq_kernel(const float* __restri
     __shared__ float qs[TQ][HD];
     __shared__ float part[4][TQ][HD + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, h = blockIdx.y;
+    const int h = blockIdx.x, b = blockIdx.y;           // heads fastest (see xg_attn_kernel)
     const float* kb = k + b * k_bs + h * HD;
     const float* vb = v + b * v_bs + h * HD;
     for (int q0 = 0; q0 < nq; q0 += TQ) {
@@ -639,16 +640,17 @@ __global__ __launch_bounds__(256) void xg_attn_fewq_kernel(const float* __restri
 static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const float* k, int64_t k_bs, int ldk, const float* v, int64_t v_bs, int ldv,
                            float* o, int64_t o_bs, int ldo, int nq, int nk, int batch, int heads, int qpool, const uint8_t* kmask, float scale, hipStream_t s) {
     if (batch <= 0 || nq <= 0) return nullptr;
-    if (hd == 16 && nq <= 16 && nk >= 1024 && !qpool && !kmask && heads <= 65535 && ((ldk | ldv) & 3) == 0 && (((k_bs | v_bs) & 3) == 0) &&
+    if (hd == 16 && nq <= 16 && nk >= 1024 && !qpool && !kmask && batch <= 65535 && ((ldk | ldv) & 3) == 0 && (((k_bs | v_bs) & 3) == 0) &&
         ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
-        hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(batch, heads), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
+        hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
         return nullptr;
     }
-    const dim3 grid((nq + 127) / 128, 1, heads), block(128);
-    // gridDim.y <= 65535
+    const dim3 block(128);
+    if ((nq + 127) / 128 > 65535) return "exact attention: too many queries";
+    // gridDim.z <= 65535
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = std::min(65535, batch - b0);
-        dim3 g2(grid.x, nb, heads);
+        dim3 g2(heads, (nq + 127) / 128, nb);
 #define XA_LAUNCH(HDIM) hipLaunchKernelGGL(xg_attn_kernel<HDIM>, g2, block, 0, s, q + b0 * q_bs, q_bs, ldq, k + b0 * k_bs, k_bs, ldk, v + b0 * v_bs, v_bs, ldv, \
                                           o + b0 * o_bs, o_bs, ldo, nq, nk, qpool, kmask, scale)
         switch (hd) {
