@@ -637,12 +637,133 @@ __global__ __launch_bounds__(256) void xg_attn_fewq_kernel(const float* __restri
         }
     }
 }
+// fp32 attention on the matrix cores (round 4) for the encoder's head dimensions (56 / 72 / 96): v_mfma_f32_16x16x4_f32 for both products, so
+// every product and sum is still fp32 (the one-thread-per-query kernel above ran the same arithmetic on the vector ALU at a third of the rate).
+// A wave owns 16 queries, a workgroup of NW waves shares 32-key K / V tiles through LDS.  Transposed formulation (as the bf16 kernels):
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]   A = K fragment (row = key, k = 4 step + g), B = Q fragment (k, col = q), 16-key tiles;
+//   the C layout leaves lane (q = lane & 15, g = lane >> 4) with keys 4 g + r, r = 0..3, of the tile: softmax per q over its 4 registers and the
+//   4 lanes q + 16 g; the same registers ARE the B operand of O^T[d][q] += sum_key V[key][d] P[key][q] when MFMA r takes key 4 g + r as its
+//   k index g, i.e. the V fragment of lane (d, g) is V[4 g + r][d]: no transposition of P anywhere.
+// qpool / kmask / scale as in xg_attn_kernel; the softmax sums differ from it only in their order.
+template <int HD>
+__global__ __launch_bounds__(512) void xg_attn_mfma_kernel(const float* __restrict__ q, int64_t q_bs, int ldq, const float* __restrict__ k, int64_t k_bs, int ldk,
+                                                          const float* __restrict__ v, int64_t v_bs, int ldv, float* __restrict__ o, int64_t o_bs, int ldo,
+                                                          int nq, int nk, int qpool, const uint8_t* __restrict__ kmask, float scale) {
+    constexpr int KT = 32, LDK = HD + 4, NS = HD / 4, NDT = (HD + 15) / 16;
+    __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.z;
+    const int i = blockIdx.y * (16 * (nthr >> 6)) + wave * 16 + fi;          // this lane's query
+    const bool live = i < nq;
+    // Q fragments: Q[i][4 step + fg]
+    float qf[NS];
+    {
+        const float* qp = q + b * q_bs + h * HD;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int d = 4 * st + fg;
+            float x = 0.f;
+            if (live) {
+                if (qpool) {
+                    const float a0 = qp[(int64_t)(4 * i) * ldq + d], a1 = qp[(int64_t)(4 * i + 1) * ldq + d];
+                    const float a2 = qp[(int64_t)(4 * i + 2) * ldq + d], a3 = qp[(int64_t)(4 * i + 3) * ldq + d];
+                    x = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                } else x = qp[(int64_t)i * ldq + d];
+            }
+            qf[st] = x;
+        }
+    }
+    f32x4 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;      // lrun: this lane's share of the row sum (its 4 g-lanes are added at the end)
+    const float* kb = k + b * k_bs + h * HD;
+    const float* vb = v + b * v_bs + h * HD;
+    for (int j0 = 0; j0 < nk; j0 += KT) {
+        __syncthreads();
+        for (int idx = tid; idx < KT * NS; idx += nthr) {
+            const int j = idx / NS, c = idx - j * NS;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + j < nk) {
+                kv = *reinterpret_cast<const f32x4*>(kb + (int64_t)(j0 + j) * ldk + 4 * c);
+                vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)(j0 + j) * ldv + 4 * c);
+            }
+            *reinterpret_cast<f32x4*>(&Ks[j * LDK + 4 * c]) = kv;
+            *reinterpret_cast<f32x4*>(&Vs[j * LDK + 4 * c]) = vv;
+        }
+        __syncthreads();
+        // scores of the two 16-key sub-tiles
+        f32x4 sc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NS; ++st) a = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(16 * sub + fi) * LDK + 4 * st + fg], qf[st], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + 16 * sub + 4 * fg + r;
+                const bool ok = j < nk && (!kmask || kmask[j]);
+                a[r] = ok ? a[r] * scale : -INFINITY;
+            }
+            sc[sub] = a;
+        }
+        float mt = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+        mt = xor32_max(xor16_max(mt));                      // over the 4 lanes of this query
+        if (__builtin_amdgcn_ballot_w64(mt != -INFINITY) == 0) continue;      // wave-uniform: every key of the tile is masked (window padding)
+        // no divergence around the MFMAs: a query that has not met a live key yet keeps the reference 0 (exp(-inf) = 0 everywhere)
+        const float mnew = fmaxf(mrun, mt);
+        const float mref = mnew == -INFINITY ? 0.f : mnew;
+        const float corr = expf(mrun - mref);
+        lrun *= corr;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) oacc[dt] *= corr;
+        mrun = mnew;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[r] = expf(sc[sub][r] - mref); lrun += pr[r]; }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int d = dt * 16 + fi;
+                const int dc = d < HD ? d : 0;             // the half tile of HD = 56 / 72: rows d >= HD multiply zeros
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float vf = Vs[(16 * sub + 4 * fg + r) * LDK + dc];
+                    if (d >= HD) vf = 0.f;
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, pr[r], oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float ltot = xor32_sum(xor16_sum(lrun));
+    if (live) {
+        const float inv = 1.0f / ltot;
+        float* op = o + b * o_bs + (int64_t)i * ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int d0 = dt * 16 + 4 * fg;              // this lane's 4 consecutive output channels of tile dt
+            if (d0 < HD) *reinterpret_cast<f32x4*>(op + d0) = oacc[dt] * inv;
+        }
+    }
+}
 static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const float* k, int64_t k_bs, int ldk, const float* v, int64_t v_bs, int ldv,
                            float* o, int64_t o_bs, int ldo, int nq, int nk, int batch, int heads, int qpool, const uint8_t* kmask, float scale, hipStream_t s) {
     if (batch <= 0 || nq <= 0) return nullptr;
     if (hd == 16 && nq <= 16 && nk >= 1024 && !qpool && !kmask && batch <= 65535 && ((ldk | ldv) & 3) == 0 && (((k_bs | v_bs) & 3) == 0) &&
         ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
+        return nullptr;
+    }
+    if ((hd == 56 || hd == 72 || hd == 96) && ((ldk | ldv | ldo) & 3) == 0 && ((k_bs | v_bs | o_bs) & 3) == 0 && batch <= 65535 &&
+        ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15) == 0) {
+        const int nw = std::min(8, (nq + 15) / 16);
+        const dim3 g3(heads, (nq + 16 * nw - 1) / (16 * nw), batch), blk(64 * nw);
+        if (hd == 56) hipLaunchKernelGGL(xg_attn_mfma_kernel<56>, g3, blk, 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, qpool, kmask, scale);
+        else if (hd == 72) hipLaunchKernelGGL(xg_attn_mfma_kernel<72>, g3, blk, 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, qpool, kmask, scale);
+        else hipLaunchKernelGGL(xg_attn_mfma_kernel<96>, g3, blk, 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, qpool, kmask, scale);
         return nullptr;
     }
     const dim3 block(128);
