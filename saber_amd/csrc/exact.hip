@@ -5,11 +5,11 @@
 // end.  This file is the mode that meets the tolerance: the same engine, the same token order, slots, weights and
 // C-ABI, but every operand, every stored activation and every statistic in fp32:
 //   * GEMMs on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bit for bit an fmaf chain, MI355X_MICROARCH.md "Matrix cores"),
-//   * attention, LayerNorm, GELU (libm erff, not the fitted form), softmax (expf) on the vector ALU,
+//   * attention products on the same fp32 MFMA (round 4), LayerNorm, GELU (libm erff, not the fitted form), softmax (expf) on the vector ALU,
 //   * the mask decoder as the UNFOLDED composition upstream executes (k/v/q projections of the image tokens per prompt, 8-head
 //     attention, out projection, residual, LayerNorm; two ConvTranspose2d as GEMMs, LayerNorm2d, GELU, hypernetwork product), so it
 //     also checks the production kernels' folded t2i / i2t algebra and their fused upscaling against an independent formulation.
-// A verification mode: a default-grid AMG slice takes 1.5 s (round 3: 3.7 s) against 0.14 s of the production arithmetic.
+// A verification mode: a default-grid AMG slice takes 1.3 s (round 3: 3.7 s) against 0.14 s of the production arithmetic.
 #include "engine.h"
 
 #include <algorithm>
@@ -749,12 +749,94 @@ __global__ __launch_bounds__(512) void xg_attn_mfma_kernel(const float* __restri
         }
     }
 }
+// The same formulation for the decoder's token -> image attention (head dimension 16, <= 16 queries, thousands of keys), one WAVE per
+// (prompt, head, key segment): S^T = K Q^T needs 4 MFMAs per 16 keys (the lane's float4 of a key row feeds MFMA e with channel 4 g + e - any
+// permutation of the contraction index serves as long as Q uses it too), the second product one MFMA per 4 keys
+// (transposed: O^T = V^T P^T, k index g <-> key 4 g + r: P's registers are the B operand as they stand, V rows are read coalesced as the A operand).  K and V go straight from global memory into operand
+// registers; NSEG waves of a workgroup split the keys and merge their (max, sum, O) through LDS.
+template <int NSEG>
+__global__ __launch_bounds__(64 * NSEG) void xg_attn_fewq_mfma_kernel(const float* __restrict__ q, int64_t q_bs, int ldq, const float* __restrict__ k, int64_t k_bs, int ldk,
+                                                                     const float* __restrict__ v, int64_t v_bs, int ldv, float* __restrict__ o, int64_t o_bs, int ldo,
+                                                                     int nq, int nk, float scale) {
+    constexpr int HD = 16;
+    __shared__ float part[NSEG][16][HD + 2];       // per wave: O[q][d], max, sum
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    // B operand of S^T: Q[q = fi][4 fg + e]
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+    if (fi < nq) qv = *reinterpret_cast<const f32x4*>(q + b * q_bs + (int64_t)fi * ldq + h * HD + 4 * fg);
+    const float* kb = k + b * k_bs + h * HD;
+    const float* vb = v + b * v_bs + h * HD;
+    f32x4 oacc = {0.f, 0.f, 0.f, 0.f};             // O^T[d = 4 fg + r][q = fi]
+    float mrun = -INFINITY, lrun = 0.f;            // of query fi (this lane's share of the sum)
+    const int per = ((nk + 16 * NSEG - 1) / (16 * NSEG)) * 16;
+    const int j_lo = wave * per, j_hi = min(nk, j_lo + per);
+    for (int j0 = j_lo; j0 < j_hi; j0 += 16) {
+        const int jk = j0 + fi;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+        if (jk < j_hi) kv = *reinterpret_cast<const f32x4*>(kb + (int64_t)jk * ldk + 4 * fg);
+        float vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jv = j0 + 4 * fg + r;
+            vv[r] = jv < j_hi ? vb[(int64_t)jv * ldv + fi] : 0.f;
+        }
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qv[e], a, 0, 0, 0);      // S^T[key 4 fg + r][q fi]
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = (j0 + 4 * fg + r < j_hi) ? a[r] * scale : -INFINITY;
+            mt = fmaxf(mt, a[r]);
+        }
+        mt = xor32_max(xor16_max(mt));
+        const float mnew = fmaxf(mrun, mt);        // finite: key j0 exists
+        const float corr = expf(mrun - mnew);
+        lrun *= corr;
+        oacc *= corr;
+        mrun = mnew;
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pr[r] = expf(a[r] - mnew); lrun += pr[r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], pr[r], oacc, 0, 0, 0);      // O^T: A = V^T[d fi][key 4 fg + r], B = P^T[key 4 fg + r][q fi]
+    }
+    const float ltot = xor32_sum(xor16_sum(lrun));
+    // merge the NSEG key segments: every wave leaves O^T (channels 4 fg + r of query fi), and per query its max / sum
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][fi][4 * fg + r] = oacc[r];
+    if (fg == 0) { part[wave][fi][HD] = mrun; part[wave][fi][HD + 1] = ltot; }
+    __syncthreads();
+    if (tid < 16 * HD) {
+        const int t = tid / HD, d = tid - t * HD;
+        if (t < nq) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NSEG; ++w) M = fmaxf(M, part[w][t][HD]);
+            float L = 0.f, A = 0.f;
+#pragma unroll
+            for (int w = 0; w < NSEG; ++w) {
+                const float mw = part[w][t][HD];
+                const float f = (mw == -INFINITY) ? 0.0f : expf(mw - M);
+                L += part[w][t][HD + 1] * f;
+                A += part[w][t][d] * f;
+            }
+            o[b * o_bs + (int64_t)t * ldo + h * HD + d] = A * (1.0f / L);
+        }
+    }
+}
 static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const float* k, int64_t k_bs, int ldk, const float* v, int64_t v_bs, int ldv,
                            float* o, int64_t o_bs, int ldo, int nq, int nk, int batch, int heads, int qpool, const uint8_t* kmask, float scale, hipStream_t s) {
     if (batch <= 0 || nq <= 0) return nullptr;
     if (hd == 16 && nq <= 16 && nk >= 1024 && !qpool && !kmask && batch <= 65535 && ((ldk | ldv) & 3) == 0 && (((k_bs | v_bs) & 3) == 0) &&
         ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
-        hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
+        static const bool fq_valu = getenv("SABER_AMD_XG_FEWQ_VALU") != nullptr;      // development A/B: the vector-ALU form
+        if (fq_valu || ((ldq | q_bs) & 3) || (reinterpret_cast<uintptr_t>(q) & 15))
+            hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
+        else
+            hipLaunchKernelGGL((xg_attn_fewq_mfma_kernel<4>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
         return nullptr;
     }
     if ((hd == 56 || hd == 72 || hd == 96) && ((ldk | ldv | ldo) & 3) == 0 && ((k_bs | v_bs | o_bs) & 3) == 0 && batch <= 65535 &&
