@@ -159,34 +159,34 @@ __global__ __launch_bounds__(256, 3) void xg_gemm2_kernel(XGemm p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32;
     const int wn = BN == 128 ? (wave & 1) * 64 : 0;
-    const int64_t m0 = (int64_t)blockIdx.y * 128;
     const int n0 = blockIdx.x * BN;
     const int b = blockIdx.z;
     const float* A = p.A + b * p.sA;
     const float* W = p.W + b * p.sW;
-    f32x4 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lr = tid >> 3, kq = (tid & 7) * 4;
     f32x4 pa[4], pb[NB];
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    // row pointers once (the A2 row index is a modulo: not in the K loop)
+    // Persistent over the row tiles blockIdx.y, blockIdx.y + gridDim.y, ...: the first K step of the NEXT tile is loaded during the last K step of
+    // this one, so its latency and the address set-up hide behind the MFMAs and the epilogue's stores (the decoder's K = 64 ... 256 GEMMs over
+    // millions of rows spend a third of their time at tile boundaries otherwise).
+    const int tiles_m = (int)(((int64_t)p.M + 127) / 128);
+    // row pointers of a tile (the A2 row index is a modulo: not in the K loop)
     const float* arow[4];
     const float* a2row[4];
     const float* wrow[NB];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + lr + 32 * r;
-        arow[r] = row < p.M ? A + row * p.lda + kq : nullptr;
-        a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((unsigned)(row + p.row0) % (unsigned)p.a2_mod) * p.lda2 + kq : nullptr;      // (rows < 2^32: 32-bit modulo)
-    }
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
         const int n = n0 + lr + 32 * r;
         wrow[r] = n < p.N ? W + (int64_t)n * p.ldw + kq : nullptr;
     }
+    auto setup = [&](int tile) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = (int64_t)tile * 128 + lr + 32 * r;
+            arow[r] = row < p.M ? A + row * p.lda + kq : nullptr;
+            a2row[r] = (p.A2 && row < p.M) ? p.A2 + (int64_t)((unsigned)(row + p.row0) % (unsigned)p.a2_mod) * p.lda2 + kq : nullptr;      // (rows < 2^32: 32-bit modulo)
+        }
+    };
     auto gload = [&](int k0) {
         const bool kin = k0 + kq < p.K;
 #pragma unroll
@@ -205,35 +205,6 @@ __global__ __launch_bounds__(256, 3) void xg_gemm2_kernel(XGemm p) {
             pb[r] = v;
         }
     };
-    gload(0);
-    for (int k0 = 0; k0 < p.K; k0 += 32) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * LDK + kq]) = pa[r];
-#pragma unroll
-        for (int r = 0; r < NB; ++r) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * r) * LDK + kq]) = pb[r];
-        __syncthreads();
-        if (k0 + 32 < p.K) gload(k0 + 32);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x4 af[TI], bf[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[(wm + i * 16 + (lane & 15)) * LDK + h * 16 + (lane >> 4) * 4]);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn + j * 16 + (lane & 15)) * LDK + h * 16 + (lane >> 4) * 4]);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][2], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][3], bf[j][3], acc[i][j], 0, 0, 0);
-                }
-        }
-    }
-    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Row-dependent addressing (the residual's row mapping has integer
-    // divisions) once per row, not per value; rows fit 32 bits (M is an int).
     float* C = p.C + b * p.sC;
     const float* bias = p.bias ? p.bias + b * p.sBias : nullptr;
     float bv[TJ];
@@ -243,46 +214,87 @@ __global__ __launch_bounds__(256, 3) void xg_gemm2_kernel(XGemm p) {
         bv[j] = (bias && n < p.N) ? bias[n] : 0.0f;
     }
     const int act = p.act, act_last = p.act_last;
+    int tile = blockIdx.y;
+    if (tile >= tiles_m) return;
+    setup(tile);
+    gload(0);
+    for (; tile < tiles_m; tile += gridDim.y) {
+        const int64_t m0 = (int64_t)tile * 128;
+        f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int64_t r0 = m0 + wm + i * 16 + (lane >> 4) * 4;
-        if (p.pool4) {   // rows 4q..4q+3 (the lane's four registers) -> output row q
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int n = n0 + wn + j * 16 + (lane & 15);
-                if (n < p.N && r0 < p.M) {
-                    const float v = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])) + bv[j];
-                    C[(r0 >> 2) * p.ldc + n] = x_act(v, act);
-                }
+            for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < p.K; k0 += 32) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * LDK + kq]) = pa[r];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * r) * LDK + kq]) = pb[r];
+            __syncthreads();
+            if (k0 + 32 < p.K) gload(k0 + 32);
+            else if (tile + (int)gridDim.y < tiles_m) { setup(tile + gridDim.y); gload(0); }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 af[TI], bf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[(wm + i * 16 + (lane & 15)) * LDK + h * 16 + (lane >> 4) * 4]);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn + j * 16 + (lane & 15)) * LDK + h * 16 + (lane >> 4) * 4]);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][2], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][3], bf[j][3], acc[i][j], 0, 0, 0);
+                    }
             }
-            continue;
         }
+        // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Row-dependent addressing (the residual's row mapping has integer
+        // divisions) once per row, not per value; rows fit 32 bits (M is an int).
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = r0 + r;
-            if (row >= p.M) continue;
-            const float* resrow = nullptr;
-            if (p.res) {
-                if (p.res_rows_per > 0) {
-                    const unsigned grow = (unsigned)(row + p.row0);      // < 2^32: at most 65535 * 32 tiles of 128 rows are accepted
-                    const unsigned pr = grow / (unsigned)p.res_rows_per;
-                    resrow = p.res + (int64_t)((pr + (unsigned)p.res_off) / (unsigned)p.res_div) * p.res_stride + (int64_t)(grow - pr * (unsigned)p.res_rows_per) * p.ldres;
-                } else {
-                    unsigned rr = (unsigned)row >> p.res_shift;
-                    if (p.res_mod > 0) rr %= (unsigned)p.res_mod;
-                    resrow = p.res + (int64_t)rr * p.ldres;
+        for (int i = 0; i < TI; ++i) {
+            const int64_t r0 = m0 + wm + i * 16 + (lane >> 4) * 4;
+            if (p.pool4) {   // rows 4q..4q+3 (the lane's four registers) -> output row q
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int n = n0 + wn + j * 16 + (lane & 15);
+                    if (n < p.N && r0 < p.M) {
+                        const float v = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])) + bv[j];
+                        C[(r0 >> 2) * p.ldc + n] = x_act(v, act);
+                    }
                 }
+                continue;
             }
-            float* crow = C + row * p.ldc;
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int n = n0 + wn + j * 16 + (lane & 15);
-                if (n >= p.N) continue;
-                float v = acc[i][j][r] + bv[j];
-                if (!act_last) v = x_act(v, act);
-                if (resrow) v += resrow[n];
-                if (act_last) v = x_act(v, act);
-                crow[n] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r0 + r;
+                if (row >= p.M) continue;
+                const float* resrow = nullptr;
+                if (p.res) {
+                    if (p.res_rows_per > 0) {
+                        const unsigned grow = (unsigned)(row + p.row0);      // < 2^32
+                        const unsigned pr = grow / (unsigned)p.res_rows_per;
+                        resrow = p.res + (int64_t)((pr + (unsigned)p.res_off) / (unsigned)p.res_div) * p.res_stride + (int64_t)(grow - pr * (unsigned)p.res_rows_per) * p.ldres;
+                    } else {
+                        unsigned rr = (unsigned)row >> p.res_shift;
+                        if (p.res_mod > 0) rr %= (unsigned)p.res_mod;
+                        resrow = p.res + (int64_t)rr * p.ldres;
+                    }
+                }
+                float* crow = C + row * p.ldc;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int n = n0 + wn + j * 16 + (lane & 15);
+                    if (n >= p.N) continue;
+                    float v = acc[i][j][r] + bv[j];
+                    if (!act_last) v = x_act(v, act);
+                    if (resrow) v += resrow[n];
+                    if (act_last) v = x_act(v, act);
+                    crow[n] = v;
+                }
             }
         }
     }
@@ -294,10 +306,24 @@ static const char* xg_gemm(const XGemm& p, hipStream_t s) {
     const bool vec = ((p.lda | p.ldw | p.sA | p.sW | (int64_t)p.K) & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0 &&
                      (!p.A2 || (((p.lda2 & 3) == 0) && (reinterpret_cast<uintptr_t>(p.A2) & 15) == 0));
     if (!vec && (p.A2 || p.res_rows_per > 0)) return "exact gemm: the fused operand sum / slot residual need 16-byte rows";
-    // short-K GEMMs (K <= 128: the 128 -> 256 out-projection of the image -> token attention, the K = 64 up-convolution) take 128 x 64 tiles:
-    // 110 registers = four workgroups per CU to hide their tile-start and store latency (1.47 -> 1.43 s per slice)
-    const int bn = !vec ? XG_BN : (p.N > 64 && !(p.K <= 128 && p.N <= 256) ? 128 : 64);
     const int64_t gy = ((int64_t)p.M + XG_BM - 1) / XG_BM;
+    if (vec) {
+        // short-K GEMMs (K <= 128: the 128 -> 256 out-projection of the image -> token attention, the K = 64 up-convolution) take 128 x 64 tiles:
+        // 110 registers = four workgroups per CU to hide their tile-start and store latency
+        const int bn = (p.N > 64 && !(p.K <= 128 && p.N <= 256)) ? 128 : 64;
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+        // persistent row tiles: as many workgroups as stay resident (3 or 4 per CU), each walking blockIdx.y, + gridDim.y, ... ; the column tiles of
+        // one row tile stay neighbours in dispatch order (they share the A tile in L2)
+        const int gx = (p.N + bn - 1) / bn;
+        const int64_t resident = (int64_t)n_cu * (bn == 128 ? 3 : 4);
+        int64_t ny = std::max<int64_t>(1, resident / ((int64_t)gx * p.batch));
+        ny = std::min<int64_t>(std::min<int64_t>(ny, gy), 65535);
+        const dim3 grid(gx, (unsigned)ny, p.batch);
+        if (bn == 128) hipLaunchKernelGGL(xg_gemm2_kernel<128>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(xg_gemm2_kernel<64>, grid, dim3(256), 0, s, p);
+        return nullptr;
+    }
     if (gy > 65535 * 32) return "exact gemm: M too large";
     // gridDim.y is limited to 65535: large M is split into row slabs
     const int64_t slab = 65535;
@@ -313,10 +339,7 @@ static const char* xg_gemm(const XGemm& p, hipStream_t s) {
             if (p.res_mod > 0 || p.res_shift) { if (y0 > 0) return "exact gemm: residual mapping with M beyond one slab"; }
             else if (p.res_rows_per <= 0) q.res = p.res + rows0 * p.ldres;
         }
-        const dim3 grid((p.N + bn - 1) / bn, (unsigned)ny, p.batch);
-        if (!vec) hipLaunchKernelGGL(xg_gemm_kernel, grid, dim3(256), 0, s, q);
-        else if (bn == 128) hipLaunchKernelGGL(xg_gemm2_kernel<128>, grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL(xg_gemm2_kernel<64>, grid, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(xg_gemm_kernel, dim3((p.N + XG_BN - 1) / XG_BN, (unsigned)ny, p.batch), dim3(256), 0, s, q);
     }
     return nullptr;
 }
