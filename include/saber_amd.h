@@ -176,7 +176,7 @@ int saber_engine_set_weight_format(saber_engine* e, int format);
  *   3-8e-3 rel-RMS from the reference's fp32 arithmetic after 48 Hiera blocks.
  * SABER_PRECISION_EXACT: every operand, stored activation and statistic in fp32 (GEMMs on the fp32-input MFMA, exact-erf GELU, the mask
  *   decoder as the unfolded composition upstream executes): the reference's own precision (saber/utils/io.py:127-132 runs fp32, autocast
- *   commented out), ~1e-6 from the fp32 CPU oracle; about ten times slower (1.3 s per cfgAMG-default slice) - a verification mode, never the default.
+ *   commented out), ~1e-6 from the fp32 CPU oracle; eight to nine times slower (1.2 s per cfgAMG-default slice) - a verification mode, never the default.
  * SABER_PRECISION_FP16 (round 4): the production kernels compiled for IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 forms' rate)
  *   - 10 mantissa bits on every GEMM / attention operand with fp32 accumulation, i.e. the operand width of the TF32 arithmetic the
  *   reference enables on its GPUs (saber/utils/io.py:127-130).  Same kernels, schedules, token order, workspaces and C-ABI as bf16; weights

@@ -9,7 +9,7 @@
 //   * the mask decoder as the UNFOLDED composition upstream executes (k/v/q projections of the image tokens per prompt, 8-head
 //     attention, out projection, residual, LayerNorm; two ConvTranspose2d as GEMMs, LayerNorm2d, GELU, hypernetwork product), so it
 //     also checks the production kernels' folded t2i / i2t algebra and their fused upscaling against an independent formulation.
-// A verification mode: a default-grid AMG slice takes 1.3 s (round 3: 3.7 s) against 0.14 s of the production arithmetic.
+// A verification mode: a default-grid AMG slice takes 1.2 s (round 3: 3.7 s) against 0.14 s of the production arithmetic.
 #include "engine.h"
 
 #include <algorithm>
@@ -370,11 +370,11 @@ __global__ __launch_bounds__(256) void xg_layernorm_kernel(const float* __restri
 // Register-resident rows (round 4): LPR lanes share a row (64, or 16 for the 64-channel LayerNorm2d of the upscaling: 4 rows per wave), every
 // lane keeps its float4 pieces, so a row is read once (the kernel above reads it three times) with 16-byte accesses.  Two-pass statistics as
 // above; only the order of the sums differs.  C % 4 == 0, C <= 1280.
-template <int LPR>
+template <int LPR, int NV>
 __global__ __launch_bounds__(256) void xg_layernorm4_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
                                                            float eps, float* __restrict__ out, int64_t rows, int C, int act,
                                                            const uint8_t* __restrict__ row_valid, int valid_mod) {
-    constexpr int RPW = 64 / LPR, NV = LPR == 64 ? 5 : 1;
+    constexpr int RPW = 64 / LPR;      // NV = float4 pieces per lane: C <= 4 * LPR * NV
     const int lane = threadIdx.x & 63, sub = lane % LPR, rw = lane / LPR;
     const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + rw;
     const bool live = row < rows;
@@ -424,9 +424,11 @@ static const char* xg_layernorm(const float* x, const LnW& w, float eps, float* 
     if (rows <= 0) return nullptr;
     const bool al = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w.g) | reinterpret_cast<uintptr_t>(w.b)) & 15) == 0;
     if (al && C == 64 && !row_valid)
-        hipLaunchKernelGGL(xg_layernorm4_kernel<16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+        hipLaunchKernelGGL((xg_layernorm4_kernel<16, 1>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+    else if (al && C <= 256)       // the decoder's 256-channel rows: one float4 per lane, a fifth of the registers of the general form
+        hipLaunchKernelGGL((xg_layernorm4_kernel<64, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
     else if (al && C <= 1280)
-        hipLaunchKernelGGL(xg_layernorm4_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
+        hipLaunchKernelGGL((xg_layernorm4_kernel<64, 5>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
     else
         hipLaunchKernelGGL(xg_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.g, w.b, eps, out, rows, C, act, row_valid, valid_mod);
     return nullptr;
@@ -461,9 +463,30 @@ __global__ __launch_bounds__(256) void xg_add_slot_kernel(const float* __restric
         out[i] = x_act(v, act);
     }
 }
+// the same on float4 pieces (C % 4 == 0, 16-byte aligned operands, slot stride a multiple of 4): one 64-bit division per 16 bytes instead of two per float
+__global__ __launch_bounds__(256) void xg_add_slot4_kernel(const f32x4* __restrict__ in, const f32x4* __restrict__ tab, XMap m, const f32x4* __restrict__ vec,
+                                                          f32x4* __restrict__ out, int64_t per4, int C4, int P, int act) {
+    const int64_t total = per4 * P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i / per4);
+        const int64_t j = i - (int64_t)p * per4;
+        f32x4 v = tab[(int64_t)((p + m.off) / m.div) * (m.stride >> 2) + j];
+        if (in) v += in[i];
+        if (vec) v += vec[(int)(j % C4)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = x_act(v[q], act);
+        out[i] = v;
+    }
+}
 static void xg_add_slot(const float* in, const float* tab, XMap m, const float* vec, float* out, int64_t rows_per, int C, int P, int act, hipStream_t s) {
     if (P <= 0) return;
     const int64_t total = rows_per * C * P;
+    if ((C & 3) == 0 && (m.stride & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(tab) | reinterpret_cast<uintptr_t>(vec) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        hipLaunchKernelGGL(xg_add_slot4_kernel, dim3((unsigned)std::min<int64_t>((total / 4 + 255) / 256, 65536 * 8)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(in),
+                           reinterpret_cast<const f32x4*>(tab), m, reinterpret_cast<const f32x4*>(vec), reinterpret_cast<f32x4*>(out), rows_per * C / 4, C / 4, P, act);
+        return;
+    }
     hipLaunchKernelGGL(xg_add_slot_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536 * 8)), dim3(256), 0, s, in, tab, m, vec, out, rows_per, C, P, act);
 }
 
@@ -850,6 +873,61 @@ __global__ __launch_bounds__(64 * NSEG) void xg_attn_fewq_mfma_kernel(const floa
         }
     }
 }
+// Many queries against a handful of keys (the decoder's image -> token attention: 4 096 queries, 7 + n_pts <= 16 keys, 8 heads of 16): the
+// eight heads of a query sit in eight neighbouring lanes, so a wave reads and writes whole 512-byte rows of q / out (the general kernel runs
+// one head per workgroup: 64-byte pieces of every row, each cache line fetched twice).  Same arithmetic, in the same order, as xg_attn_kernel
+// with its single key tile.
+__global__ __launch_bounds__(256) void xg_attn_fewk_kernel(const float* __restrict__ q, int64_t q_bs, int ldq, const float* __restrict__ k, int64_t k_bs, int ldk,
+                                                          const float* __restrict__ v, int64_t v_bs, int ldv, float* __restrict__ o, int64_t o_bs, int ldo,
+                                                          int nq, int nk, float scale) {
+    constexpr int HD = 16, NH = 8, MAXK = 16;
+    __shared__ __attribute__((aligned(16))) float Ks[MAXK][NH * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[MAXK][NH * HD];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    for (int idx = tid; idx < nk * NH * HD; idx += 256) {
+        const int j = idx / (NH * HD), c = idx - j * (NH * HD);
+        Ks[j][c] = k[b * k_bs + (int64_t)j * ldk + c];
+        Vs[j][c] = v[b * v_bs + (int64_t)j * ldv + c];
+    }
+    __syncthreads();
+    const int h = tid & 7, i = blockIdx.x * 32 + (tid >> 3);
+    if (i >= nq) return;
+    float qv[HD], acc[HD];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(q + b * q_bs + (int64_t)i * ldq + h * HD);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const f32x4 t = qp[c]; qv[4 * c] = t[0]; qv[4 * c + 1] = t[1]; qv[4 * c + 2] = t[2]; qv[4 * c + 3] = t[3]; }
+    }
+    float sc[MAXK];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        float a = 0.f;
+        if (j < nk) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a = fmaf(qv[d], Ks[j][h * HD + d], a);
+            a *= scale;
+        }
+        sc[j] = j < nk ? a : -INFINITY;
+        mt = fmaxf(mt, sc[j]);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        if (j < nk) {
+            const float pj = expf(sc[j] - mt);
+            l += pj;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(pj, Vs[j][h * HD + d], acc[d]);
+        }
+    }
+    const float inv = 1.0f / l;
+    f32x4* op = reinterpret_cast<f32x4*>(o + b * o_bs + (int64_t)i * ldo + h * HD);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) op[c] = (f32x4){acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv};
+}
 static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const float* k, int64_t k_bs, int ldk, const float* v, int64_t v_bs, int ldv,
                            float* o, int64_t o_bs, int ldo, int nq, int nk, int batch, int heads, int qpool, const uint8_t* kmask, float scale, hipStream_t s) {
     if (batch <= 0 || nq <= 0) return nullptr;
@@ -860,6 +938,11 @@ static const char* xg_attn(int hd, const float* q, int64_t q_bs, int ldq, const 
             hipLaunchKernelGGL((xg_attn_fewq_kernel<16, 8>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
         else
             hipLaunchKernelGGL((xg_attn_fewq_mfma_kernel<4>), dim3(heads, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
+        return nullptr;
+    }
+    if (hd == 16 && heads == 8 && nk <= 16 && nq >= 256 && !qpool && !kmask && batch <= 65535 && ((ldq | ldo) & 3) == 0 && ((q_bs | o_bs) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(o)) & 15) == 0) {
+        hipLaunchKernelGGL(xg_attn_fewk_kernel, dim3((nq + 31) / 32, batch), dim3(256), 0, s, q, q_bs, ldq, k, k_bs, ldk, v, v_bs, ldv, o, o_bs, ldo, nq, nk, scale);
         return nullptr;
     }
     if ((hd == 56 || hd == 72 || hd == 96) && ((ldk | ldv | ldo) & 3) == 0 && ((k_bs | v_bs | o_bs) & 3) == 0 && batch <= 65535 &&
