@@ -1036,15 +1036,30 @@ __global__ __launch_bounds__(256) void xg_mask_hidden_kernel(const float* __rest
 
 // masks[p][k][y][x] = sum_c hyper[p][k][c] * up[p][perm(y,x)][c]   (up: fp32 [P][65536][32], engine token order; hyper: [P][128])
 __global__ __launch_bounds__(256) void xg_mask_dot_kernel(const float* __restrict__ up, const float* __restrict__ hyper, int P, float* __restrict__ masks4) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)P * 65536) return;
-    const int p = (int)(idx >> 16), pix = (int)(idx & 65535);
-    const int y = pix >> 8, x = pix & 255;
-    const float* u = up + ((int64_t)p * 65536 + perm_index256(y, x)) * 32;
-    const float* hp = hyper + (int64_t)p * 128;
-    float uv[32];
+    // A workgroup takes 256 consecutive tokens = four horizontally adjacent 8 x 8 blocks of the engine's token order = an 8 x 32 pixel patch: their
+    // 32 KB of `up` are read as one contiguous stream into LDS (rows padded to 33 floats), then thread (ry, rx) of the patch reads its token's row
+    // and writes 128-byte rows of the four mask planes.  (Round 3: one thread per pixel reading its 128-byte row straight from memory.)
+    __shared__ float us[256 * 33];
+    const int64_t t0 = (int64_t)blockIdx.x * 256;              // first token of the patch, over all prompts
+    if (t0 >= (int64_t)P * 65536) return;
+    const int tid = threadIdx.x;
+    const f32x4* src = reinterpret_cast<const f32x4*>(up + t0 * 32);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) uv[c] = u[c];
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + tid;                        // float4 index in the 32-KB stream: token idx >> 3, channels 4 (idx & 7) ..
+        const f32x4 vq = src[idx];
+        float* d = &us[(idx >> 3) * 33 + 4 * (idx & 7)];
+        d[0] = vq[0]; d[1] = vq[1]; d[2] = vq[2]; d[3] = vq[3];
+    }
+    __syncthreads();
+    const int p = (int)(t0 >> 16), tl0 = (int)(t0 & 65535);
+    int y0, x0;
+    perm_coords256(tl0, &y0, &x0);                             // top-left pixel of the patch (tl0 is a multiple of 256)
+    const int ry = tid >> 5, rx = tid & 31;
+    const int tl = perm_index256(y0 + ry, x0 + rx) - tl0;      // this pixel's token within the patch
+    const float* uv = &us[tl * 33];
+    const float* hp = hyper + (int64_t)p * 128;
+    const int pix = (y0 + ry) * 256 + x0 + rx;
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
         float a = 0.f;
