@@ -318,6 +318,7 @@ static const char* xg_gemm(const XGemm& p, hipStream_t s) {
         const int gx = (p.N + bn - 1) / bn;
         const int64_t resident = (int64_t)n_cu * (bn == 128 ? 3 : 4);
         int64_t ny = std::max<int64_t>(1, resident / ((int64_t)gx * p.batch));
+        if (gy < 8 * ny && gy <= 65535) ny = gy;      // few tiles per resident workgroup (the encoder's 672-tile GEMMs: 4.4): one tile per workgroup, the dispatcher balances
         ny = std::min<int64_t>(std::min<int64_t>(ny, gy), 65535);
         const dim3 grid(gx, (unsigned)ny, p.batch);
         if (bn == 128) hipLaunchKernelGGL(xg_gemm2_kernel<128>, grid, dim3(256), 0, s, p);
