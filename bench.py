@@ -10,9 +10,13 @@ saber2D._apply_classifier (min area, duplicate removal, ascending-area sort) -> 
 automatic-mask-generator (grid prompts) on 1 MI355X").  Weights are seeded synthetic tensors of the Hiera-L
 architecture (no checkpoint is available offline).
 
-N > 1: one process per GPU (torchrun), every rank segments its own K slices (weak scaling, no data-path
-collective per slice) and the K label planes per rank are all-gathered over RCCL at the end of the timed region,
-as the tomogram driver does for a z-sharded volume.
+N > 1: one process per GPU.  Under a launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process IS one rank;
+run plainly (`python bench.py --gpus N`, WORLD_SIZE unset) it starts its N ranks itself BEFORE anything touches a GPU and relays rank 0's
+JSON line, as the reference's GPUPool starts one worker per GPU (saber/utils/parallelization.py:137-151, 339-343).  The N > 1 workload is
+the north star's: ONE 512-slice tomogram (BASELINE configs[3]) z-sharded over the ranks, value = 512 / end-to-end seconds INCLUDING the
+RCCL all-gather of the label planes and the 3-D connected-components stitch (strong scaling), the figure without the stitch beside it
+(SURVEY.md 8d "Config 4").  `--weak` keeps the K-private-slices-per-rank form of rounds 1-4 (one all-gather of the K planes per rank inside
+the timed region); it is also reported as the extra key `weak_scaling` of the N > 1 line.
 """
 import argparse
 import json
@@ -50,6 +54,9 @@ def parse():
                     "(the reference's GPUPool semantics, saber/utils/parallelization.py:137-151: task i -> GPU i %% n_gpus), each segmented and stitched on its own GPU, "
                     "no data-path collective; value = all slices / max-over-ranks seconds")
     ap.add_argument("--tomogram-slices", type=int, default=256, help="slices per tomogram of --tomograms (configs[4]: 256)")
+    ap.add_argument("--weak", action="store_true", help="N > 1 only: the weak-scaling form (every rank segments its own --steps slices) as the headline instead of the "
+                    "512-slice strong-scaling tomogram")
+    ap.add_argument("--no-volume512", action="store_true", help="N = 1: skip the extra keys `volume512` (configs[3] at full size on this GPU) and `alt_dtypes.mxfp8.tomogram256` (configs[4])")
     ap.add_argument("--cu-split", type=int, default=0, metavar="N", help="co-residency experiment (DESIGN.md section 4): every handle's decoder kernels on a stream "
                     "restricted to CUs 0..N-1, its encoder passes on a stream restricted to CUs N..255 (hipExtStreamCreateWithCUMask); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,6 +227,113 @@ def precision_check(weights, img, operands="bf16"):
         e.close()
 
 
+def full_size_keys(a, engines, pool, make_amg_params, Z=512, window=24):
+    """BASELINE configs[3] at FULL size on this one GPU, inside the default line: a 1024 x 1024 x Z tomogram resident in HBM
+    -> the z-loop on the headline's engine handles -> label planes -> 3-D connected components on the device -> uint32 labels on the host, with the
+    size-independent checks of tests/test_gpu_config34_volume.py::test_config3_512_slices_full_size asserted on the result.  The score thresholds
+    are that test's (pred_iou 0.5, stability 0.8: the seeded, untrained decoder leaves nothing at cfgAMG's own), so paint / dedup / stitch run on
+    real labels; the run at cfgAMG's own thresholds is `bench.py --volume 512`."""
+    from saber_amd.segmenters import utils
+    from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded, shard_bounds
+    params = make_amg_params(dict(npoints=a.npoints, crop_n_layers=a.crop_n_layers, pred_iou_thresh=0.5, stability_score_thresh=0.8))
+    eng = engines[0]
+    vol = torch.stack([pool[z % len(pool)] for z in range(Z)])
+    fns = [(lambda z, e_=e_: segment_slice_to_plane(e_, vol[z], params, min_mask_area=50)[0]) for e_ in engines]
+    torch.cuda.synchronize()
+    tm, keep = {}, []
+    t0 = time.perf_counter()
+    labels = segment_volume_sharded(vol, fns, stitch=True, min_mask_area=100, engine=eng, timings=tm, keep_on_device=True, planes_out=keep)
+    labels_host = labels.cpu()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    planes = keep[0]
+    K = int(tm["labels"])
+    checks = {}
+    # (1) per-slice ids are list positions: contiguous 1..n on every sampled plane (propagation.py:185-186)
+    n_fg = int((planes.view(Z, -1).max(1).values > 0).sum().item())
+    assert n_fg > Z // 2, f"only {n_fg} of {Z} planes carry masks"
+    for z in range(0, Z, 37):
+        ids = torch.unique(planes[z])
+        ids = ids[ids > 0]
+        assert torch.equal(ids.long(), torch.arange(1, ids.numel() + 1, device=ids.device)), f"plane {z}: ids not contiguous"
+    checks["planes_with_masks"] = n_fg
+    checks["max_ids_per_plane"] = int(planes.max().item())
+    # (2) slices are independent units: first + mid slice of four of the eight 8-rank z-chunks recomputed standalone = the planes of the full run
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for r in (0, 3, 5, 7):
+            z0, z1 = shard_bounds(Z, 8, r)
+            assert z1 - z0 == Z // 8
+            for z in (z0, z0 + Z // 16 - 1):
+                again, _ = segment_slice_to_plane(eng, vol[z], params, min_mask_area=50)
+                assert torch.equal(again.view(torch.int16), planes[z]), f"slice {z} recomputed standalone differs"
+        torch.cuda.current_stream().synchronize()
+    # (3) the stitched volume: K labels, every kept component >= min_mask_area * 10 voxels (utils.py:113-119), labels only on painted voxels
+    assert K >= 1 and K == int(labels.max().item())
+    counts = torch.bincount(labels.flatten(), minlength=K + 1)
+    assert bool((counts[1:] >= 1000).all())
+    assert not bool(((labels != 0) & (planes == 0)).any())
+    # (4) device stitch = host stitch (scipy) on a z-window, min_mask_area = 0 so that all of the window's components are kept
+    w0 = min(200, Z - window)
+    win = planes[w0:w0 + window].cpu().numpy().view(np.uint16)
+    host = utils.separate_masks(np.ascontiguousarray(win), min_mask_area=0)
+    devw, _ = eng.separate_masks(planes[w0:w0 + window].contiguous(), min_mask_area=0)
+    assert np.array_equal(devw.cpu().numpy().view(np.uint32), host)
+    # (5) the full stitch restricted to the window is a coarsening of the window's own components
+    lw = labels_host[w0:w0 + window].numpy().view(np.uint32)
+    sel = lw > 0
+    pairs = np.unique(np.stack([host[sel].astype(np.int64), lw[sel].astype(np.int64)], 1), axis=0)
+    assert len(np.unique(pairs[:, 0])) == len(pairs)
+    checks["asserted"] = "ids contiguous per plane; 8 slices at the 8-rank chunk bounds recomputed standalone bit-equal; every label >= 1000 voxels and inside the painted voxels; device stitch == scipy on a 24-plane window; window components map to ONE global label each"
+    return {"what": f"BASELINE configs[3] at full size on ONE GPU inside the default line: 1024x1024x{Z} uint16 tomogram (the synthetic slices cycled along z) -> z-loop on the headline's "
+                    f"{len(engines)} engine handles -> label planes -> 3-D connected components on the device -> uint32 labels on the host; AMG score thresholds of "
+                    f"tests/test_gpu_config34_volume.py (pred_iou 0.5, stability 0.8) so that the planes carry labels",
+            "slices": Z, "slices_per_s": Z / dt, "seconds": dt, "labels": K,
+            "without_stitch": {"slices_per_s": Z / tm["gathered"], "seconds": tm["gathered"]},
+            "phases_s": {"segment": tm["segmented"], "stitch_on_device": tm["stitched"] - tm["gathered"], "labels_to_host": dt - tm["stitched"]},
+            "checks": checks}
+
+
+def tomogram256_key(a, engines, pool, make_amg_params, Z=256):
+    """BASELINE configs[4], one tomogram of the batch at full depth on this GPU: Z slices on the MXFP8 handles, hipGraph replay of the per-slice
+    encode + decode sequences, stitched on the device (the checks of tests/test_gpu_config34_volume.py::test_config4_256_slices_mxfp8_hipgraph)."""
+    from saber_amd.segmenters.slice_driver import segment_slice_to_plane, segment_volume_sharded
+    params = make_amg_params(dict(npoints=a.npoints, crop_n_layers=a.crop_n_layers, pred_iou_thresh=0.5, stability_score_thresh=0.8))
+    eng = engines[0]
+    for e_ in engines:
+        e_.set_graphs(True)
+    cap0, rep0 = eng.graph_stats()
+    vol = torch.stack([pool[z % len(pool)] for z in range(Z)])
+    fns = [(lambda z, e_=e_: segment_slice_to_plane(e_, vol[z], params, min_mask_area=50)[0]) for e_ in engines]
+    torch.cuda.synchronize()
+    tm, keep = {}, []
+    t0 = time.perf_counter()
+    labels = segment_volume_sharded(vol, fns, stitch=True, min_mask_area=100, engine=eng, timings=tm, keep_on_device=True, planes_out=keep)
+    labels_host = labels.cpu()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cap, rep = eng.graph_stats()
+    planes, K = keep[0], int(tm["labels"])
+    n_fg = int((planes.view(Z, -1).max(1).values > 0).sum().item())
+    assert n_fg > Z // 2
+    assert rep - rep0 >= 7 * (Z // len(engines) - 6), f"hipGraph replays on handle 0: {rep - rep0}"
+    assert K >= 1 and K == int(labels.max().item())
+    counts = torch.bincount(labels.flatten(), minlength=K + 1)
+    assert bool((counts[1:] >= 1000).all()) and not bool(((labels != 0) & (planes == 0)).any())
+    # eager run of a z-subsample on the same handle: planes identical to the replayed run's
+    eng.set_graphs(False)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for z in (0, Z // 3, Z - 1):
+            p, _ = segment_slice_to_plane(eng, vol[z], params, min_mask_area=50)
+            assert torch.equal(p.view(torch.int16), planes[z]), z
+        torch.cuda.current_stream().synchronize()
+    eng.set_graphs(os.environ.get("SABER_AMD_GRAPHS", "1") != "0")
+    return {"what": f"BASELINE configs[4], ONE tomogram of the batch at full depth: 1024x1024x{Z}, MXFP8 operands on the fp8 MFMA, hipGraph replay of encode + decode "
+                    f"({len(engines)} handles), stitched on the device, labels to the host; thresholds as `volume512`",
+            "slices": Z, "slices_per_s": Z / dt, "seconds": dt, "labels": K, "without_stitch": {"slices_per_s": Z / tm["gathered"], "seconds": tm["gathered"]},
+            "graph_sequences_captured_handle0": cap, "graph_replays_handle0": rep - rep0,
+            "checks": "planes with masks > Z/2; >= 7 replays per slice from the third slice on; labels >= 1000 voxels inside painted voxels; eager planes of 3 slices bit-equal to replayed"}
+
+
 def volume_modes(a, rank, world, rehearsal, engines, pool, params, dist):
     """--volume Z: ONE tomogram z-sharded over the ranks (strong scaling, gather + stitch inside the timed region);
     --tomograms T: T tomograms dealt round-robin to the ranks, each stitched where it was segmented.  Slices are the synthetic pool slices
@@ -246,27 +360,29 @@ def volume_modes(a, rank, world, rehearsal, engines, pool, params, dist):
     if a.volume > 0:
         Z = a.volume
         vol = torch.stack([pool[z % len(pool)] for z in range(Z)])            # (Z, 1024, 1024) uint16 in HBM
-        z0, z1 = shard_bounds(Z, world, rank)
         sync_all()
+        # ONE timed pass: this rank's z-chunk -> all-gather of the uint16 planes -> 3-D connected components on the device -> uint32 labels on the
+        # host.  `timings` holds the seconds at which the chunk was segmented, the gather had finished and the stitch had finished (each behind a
+        # device synchronisation), so the figure without the stitch comes from the same run (rounds 1-4 ran the volume twice for it).
+        tm = {}
         t0 = time.perf_counter()
-        planes = segment_volume_sharded(vol, fns_for(vol), stitch=False, engine=eng)      # local chunk + all-gather; host planes (Z, H, W) uint16
-        t_seg = time.perf_counter() - t0
-        sync_all()
-        # the timed form: segment + gather + device stitch, labels left on the device of every rank (the D2H copy of the uint32 volume is reported beside it)
-        t0 = time.perf_counter()
-        labels = segment_volume_sharded(vol, fns_for(vol), stitch=True, min_mask_area=100, engine=eng)
+        labels = segment_volume_sharded(vol, fns_for(vol), stitch=True, min_mask_area=100, engine=eng, timings=tm)
         sync_all()
         dt = time.perf_counter() - t0
+        t_seg, t_gath, t_st = tm["segmented"], tm["gathered"], tm["stitched"]
         if world > 1:
-            t = torch.tensor([dt, t_seg], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            t = torch.tensor([dt, t_seg, t_gath, t_st], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, t_seg = float(t[0].item()), float(t[1].item())
-        return dict(base, metric="EM slices/sec (1024^2, Hiera-L), one tomogram z-sharded", value=Z / dt, ms_per_step=dt * 1e3, scaling="strong",
+            dt, t_seg, t_gath, t_st = (float(x) for x in t.tolist())
+        return dict(base, metric="EM slices/sec (1024^2, Hiera-L)" if Z == 512 else "EM slices/sec (1024^2, Hiera-L), one tomogram z-sharded", value=Z / dt, ms_per_step=dt * 1e3, scaling="strong",
                     config={"workload": f"ONE 1024x1024x{Z} uint16 tomogram (BASELINE configs[{2 if Z <= 64 else 3}]): per slice prep.prepare -> SAM2 AMG (Hiera-L, cfgAMG defaults) -> dedup/sort -> label plane; "
                                         f"contiguous z-chunks over {world} rank(s) x {len(engines)} engine handles, ONE all-gather of the uint16 planes, 3-D connected components "
                                         f"(saber_separate_masks) on the device, uint32 labels back on the host: all inside the timed region" + note,
-                            "slices": Z, "labels": int(labels.max()) if labels.size else 0, "parallelism": f"STRONG scaling: total work fixed at {Z} slices"},
-                    without_stitch={"slices_per_s": Z / t_seg, "seconds": t_seg, "what": "the same run up to and including the all-gather and the D2H of the planes, no 3-D connected components"},
+                            "slices": Z, "labels": int(labels.max()) if labels.size else 0, "parallelism": f"STRONG scaling: total work fixed at {Z} slices, {-(-Z // world)} per rank",
+                            "engine_handles_per_gpu": len(engines), "weights": "seeded synthetic Hiera-L (no checkpoint offline)"},
+                    without_stitch={"slices_per_s": Z / t_gath, "seconds": t_gath, "what": "the same run up to and including the all-gather of the label planes (max over ranks), no 3-D connected components"},
+                    phases_s={"segment_own_chunk": t_seg, "all_gather": t_gath - t_seg, "stitch_on_device": t_st - t_gath, "labels_to_host": dt - t_st,
+                              "what": "max over ranks of the seconds since the start of the timed region at which each phase ended, differenced"},
                     seconds=dt)
     T, Zt = a.tomograms, a.tomogram_slices
     mine = [t for t in range(T) if t % world == rank]             # GPUPool: task i -> GPU i % n_gpus
@@ -313,13 +429,62 @@ def volume_modes(a, rank, world, rehearsal, engines, pool, params, dist):
                 seconds=dt)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, rendezvous on 127.0.0.1), relay rank 0's JSON line and exit with the worst child status.  The parent
+    makes no HIP call and never asks torch for a device (a process that has initialised the GPU must not be the one that forks the ranks),
+    which is the reference's multiprocessing mode: one spawned worker per GPU (saber/utils/parallelization.py:339-343)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's peer buffers need it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0 = procs[0].communicate()[0]
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 10)
+        except subprocess.TimeoutExpired:
+            p.kill()                     # the exact PID this function started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    sys.exit(1 if rc else 0)
+
+
+def spawn_selftest(rank, world):
+    """SABER_AMD_BENCH_SPAWN_ONLY=1 (tests/test_bench_launch.py, no GPU): the ranks only rendezvous over gloo and count themselves, so the CPU
+    suite covers the launcher of `--gpus N`."""
+    import torch.distributed as dist
+    if os.environ.get("SABER_AMD_BENCH_SPAWN_FAIL_RANK", "") == str(rank):
+        raise SystemExit(3)              # (the launcher must surface a rank's failure: tests/test_bench_launch.py)
+    dist.init_process_group("gloo", timeout=__import__("datetime").timedelta(seconds=20))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "rank_sum": float(t.item()), "argv": sys.argv[1:]}))
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("SABER_AMD_BENCH_SPAWN_ONLY", "0") == "1" and world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return spawn_selftest(rank, world)
     import torch.distributed as dist
     # SABER_AMD_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL, the
     # gather staged through host memory).  Never set by the driver; the number it prints is not a multi-GPU measurement.
@@ -403,7 +568,10 @@ def main():
         return sum(totals)
 
     img01_cpu = eng.prepare(pool[0]).cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None      # (input of the CPU baseline leg)
-    if a.volume > 0 or a.tomograms > 0:
+    # N > 1 without an explicit workload: the north star's 512-slice strong-scaling tomogram is the line's `value`; the weak-scaling K steps of
+    # rounds 1-4 run first (they also warm every handle) and ride along as the extra key `weak_scaling`.
+    north_star = world > 1 and not a.weak and a.volume == 0 and a.tomograms == 0
+    if (a.volume > 0 or a.tomograms > 0) and not north_star:
         out = volume_modes(a, rank, world, rehearsal, engines, pool, params, dist)
         if rank == 0:
             print(json.dumps(out))
@@ -474,6 +642,21 @@ def main():
         if world > 1:
             out["n_ranks_seen"] = n_seen
             out["per_rank_slices_per_s"] = [round(v, 4) for v in per_rank]
+    if north_star:
+        a.volume = int(os.environ.get("SABER_AMD_BENCH_NORTH_STAR_SLICES", "512"))       # (the one-GPU rehearsal may shorten it; the driver never sets this)
+        vout = volume_modes(a, rank, world, rehearsal, engines, pool, params, dist)
+        if rank == 0:
+            vout["weak_scaling"] = {"value": out["value"], "unit": "slices/s", "steps": a.steps, "warmup": a.warmup, "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                                    "n_ranks_seen": out["n_ranks_seen"], "per_rank_slices_per_s": out["per_rank_slices_per_s"],
+                                    "what": out["config"]["parallelism"]}
+            vout["steps"], vout["warmup"] = 1, a.warmup
+            vout["steps_note"] = (f"one step = the whole {a.volume}-slice tomogram (total work fixed: strong scaling); --steps {a.steps} / --warmup {a.warmup} "
+                                  f"are the per-rank slice counts of `weak_scaling`, which ran first on the same handles")
+            print(json.dumps(vout))
+        for e_ in engines:
+            e_.close()
+        dist.destroy_process_group()
+        return
     if rank == 0:
         # the stitch that follows the gather (utils.separate_masks, propagation.py:189) on the device; reported beside the metric, not in it
         vol = (gathered if world > 1 else planes).view(torch.int16)
@@ -597,6 +780,11 @@ def main():
             out["precision"] = precision_check(weights, eng.prepare(pool[0]), a.dtype)
         except Exception as ex:
             out["precision"] = {"error": str(ex)[:300]}
+    if rank == 0 and world == 1 and not a.no_profile and not a.no_tail and not a.no_volume512:
+        try:        # configs[3] at full size on the headline's handles (about 75 s); never part of `value`
+            out["volume512"] = full_size_keys(a, engines, pool, make_amg_params)
+        except Exception as ex:
+            out["volume512"] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
     if rank == 0 and world == 1 and not a.no_profile and not a.no_tail and not a.no_alt_dtypes and a.dtype == "bf16":
         # The other arithmetic modes as extra keys of the default line, each on fresh handles after the headline's were closed
         # (a Hiera-L handle with its AMG scratch is ~58 GB): the same step, the same slices, `--workers` handles; never part of `value`.
@@ -632,6 +820,11 @@ def main():
                                        "avg_launch_us": g["ms"] * 1e3 / max(1, g["launches"]), "launches_per_slice": g["launches"]}
                 if dt_name == "fp16":
                     rec["precision"] = precision_check(weights, img_prec, "fp16")
+                if dt_name == "mxfp8" and not a.no_volume512:
+                    try:        # configs[4] at full depth (about 35 s)
+                        rec["tomogram256"] = tomogram256_key(a, engines, pool, make_amg_params)
+                    except Exception as ex:
+                        rec["tomogram256"] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
                 out["alt_dtypes"][dt_name] = rec
             except Exception as ex:
                 out["alt_dtypes"][dt_name] = {"error": str(ex)[:300]}

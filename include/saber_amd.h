@@ -50,7 +50,8 @@ enum saber_status {
     SABER_ERR_INVALID = -1,   /* bad argument / unsupported configuration (ValueError in the reference) */
     SABER_ERR_STATE = -2,     /* call order violated (RuntimeError in the reference)                    */
     SABER_ERR_HIP = -3,       /* HIP runtime failure                                                     */
-    SABER_ERR_CAPACITY = -4   /* caller-provided output capacity exceeded                                */
+    SABER_ERR_CAPACITY = -4,  /* caller-provided output capacity exceeded                                */
+    SABER_ERR_RANGE = -5      /* overflow sentinel: NaN / inf in the 16-bit arithmetic (saber_engine_check_finite) */
 };
 
 enum saber_dtype { SABER_U16 = 0, SABER_F32 = 1 };
@@ -181,7 +182,9 @@ int saber_engine_set_weight_format(saber_engine* e, int format);
  *   - 10 mantissa bits on every GEMM / attention operand with fp32 accumulation, i.e. the operand width of the TF32 arithmetic the
  *   reference enables on its GPUs (saber/utils/io.py:127-130).  Same kernels, schedules, token order, workspaces and C-ABI as bf16; weights
  *   and stored activations are fp16.  What fp16 gives up is RANGE (largest finite value 65 504): saber_engine_finalize fails loudly when a
- *   weight, or a LayerNorm output bound |gamma| sqrt(C) + |beta|, cannot be represented.  The choice is made ONCE, before
+ *   weight, or a LayerNorm output bound |gamma| sqrt(C) + |beta|, cannot be represented, and at RUN time the overflow sentinel below
+ *   (saber_engine_check_finite; built into saber_amg_generate) turns an activation that left the range into SABER_ERR_RANGE instead of
+ *   NaN masks.  Conversions do NOT saturate: a clamped activation would be a silently wrong result.  The choice is made ONCE, before
  *   saber_engine_finalize (the weights are converted there); a handle finalized in one 16-bit type cannot be switched to the other.
  *   Not available together with the fp8 weight formats.
  * Call it with EXACT once BEFORE saber_engine_finalize (the fp32 weight copies are kept only then: +0.9 GB for Hiera-L); afterwards the
@@ -191,6 +194,17 @@ int saber_engine_set_weight_format(saber_engine* e, int format);
 #define SABER_PRECISION_EXACT 1
 #define SABER_PRECISION_FP16 2
 int saber_engine_set_precision(saber_engine* e, int precision);
+
+/* Overflow sentinel of the 16-bit modes (round 5).  A stored fp16 activation beyond 65 504 is an inf from there on: fp32
+ * accumulators, the fp32 residual stream and every LayerNorm / softmax statistic carry it (as inf or NaN) into (a) the three feature maps of
+ * the encoder pass, (b) the decoder batch's predicted IoUs / hypernetwork outputs and (c) the low-res logits.  The engine counts non-finite
+ * values there on the device, on the caller's stream: one HBM-bound scan of the feature maps per encoder pass (16 MB per crop), two tiny
+ * scans per decoder batch, one fma per stored pixel inside dec_upscale.  saber_amg_generate reads the counters with the records at its one
+ * synchronisation and returns SABER_ERR_RANGE (nothing of that call's output may be used).  After saber_encode / saber_decode_points /
+ * saber_decode_prompts (asynchronous, no synchronisation inside) call saber_engine_check_finite where the host synchronises anyway: it
+ * waits for `stream`, returns SABER_ERR_RANGE with a message naming the stage when any counter is non-zero, and clears the counters.
+ * bf16 handles run the same checks (their range is fp32's: a hit means NaN / inf in the input or the weights); the exact mode does not. */
+int saber_engine_check_finite(saber_engine* e, void* stream);
 
 /* hipGraph replay of saber_amg_generate's launch sequences (BASELINE configs[4]: "hipGraph-captured per-slice encode+decode"): the batched
  * encoder pass and each decoder batch are run eagerly the first time their shapes are seen on a handle, captured the second time and

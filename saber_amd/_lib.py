@@ -14,8 +14,13 @@ class SaberAmdError(RuntimeError):
     pass
 
 
+class SaberRangeError(SaberAmdError):
+    """SABER_ERR_RANGE: the engine's overflow sentinel found NaN / inf in the 16-bit arithmetic (include/saber_amd.h:
+    saber_engine_check_finite) - with fp16 operands, an activation beyond 65 504.  The call's results are invalid."""
+
+
 # status codes of include/saber_amd.h
-SABER_OK, SABER_ERR_INVALID, SABER_ERR_STATE, SABER_ERR_HIP, SABER_ERR_CAPACITY = 0, -1, -2, -3, -4
+SABER_OK, SABER_ERR_INVALID, SABER_ERR_STATE, SABER_ERR_HIP, SABER_ERR_CAPACITY, SABER_ERR_RANGE = 0, -1, -2, -3, -4, -5
 
 
 def build(verbose: bool = False) -> str:
@@ -75,6 +80,7 @@ SIGNATURES = {
     "saber_engine_set_encoder_stream": (_i, [_vp, _vp]),
     "saber_engine_set_weight_format": (_i, [_vp, _i]),
     "saber_engine_set_precision": (_i, [_vp, _i]),
+    "saber_engine_check_finite": (_i, [_vp, _vp]),
     "saber_engine_graph_stats": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "saber_label_plane": (_i, [_vp, _vp, C.POINTER(_i), _i, _i, _i, _vp, _vp]),
     "saber_mask_pair_intersections": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

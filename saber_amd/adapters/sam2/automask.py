@@ -15,7 +15,21 @@ from saber_amd.adapters.sam2 import amg as fmask
 _ENGINES: Dict[Any, Any] = {}
 
 
-def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 21, max_prompts: int = 1024, replica: int = 0):
+def default_precision() -> str:
+    """The adapter's production arithmetic.  Default (round 5): "fp16" - the production kernels on IEEE half operands with fp32 accumulation
+    (10 mantissa bits = the TF32 arithmetic the reference enables on its GPUs, saber/utils/io.py:127-130; include/saber_amd.h:
+    SABER_PRECISION_FP16): ~1e-3 from the fp32 oracle end to end against bf16's 5-7e-3, at the same speed, with the engine's run-time overflow
+    sentinel (SaberRangeError instead of NaN masks if an activation leaves the range of half).  SABER_AMD_PRECISION=bf16 selects the arithmetic
+    of BASELINE configs[1] (bench.py's headline); read ONCE per model, when its first handle is built."""
+    import os
+    precision = os.environ.get("SABER_AMD_PRECISION", "fp16")
+    if precision not in ("bf16", "fp16"):
+        raise ValueError(f"SABER_AMD_PRECISION must be 'bf16' or 'fp16', got '{precision}'")
+    return precision
+
+
+def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_images: int = 21, max_prompts: int = 1024, replica: int = 0,
+               precision: Optional[str] = None):
     """One engine per (device, trunk, weights): the reference builds a second SAM2 copy for AMG (SURVEY 3.4);
     here adapter and generator share one handle.  replica > 0: further handles of the same model on the same device (the z-loop keeps
     two slices in flight per GPU, one handle per thread)."""
@@ -25,12 +39,10 @@ def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_imag
         raise RuntimeError(f"the MI355X engine needs a ROCm device, got '{dev}' (there is no CPU fallback)")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     src = pretrained_weights.resolve_weights(sam2_cfg, checkpoint)
-    # SABER_AMD_PRECISION=fp16: the production kernels on IEEE half operands (10 mantissa bits = the TF32 arithmetic the reference enables on
-    # its GPUs, saber/utils/io.py:127-130; include/saber_amd.h: SABER_PRECISION_FP16).  Default: bf16, the arithmetic of BASELINE configs[1].
-    import os
-    precision = os.environ.get("SABER_AMD_PRECISION", "bf16")
+    if precision is None:
+        precision = default_precision()
     if precision not in ("bf16", "fp16"):
-        raise ValueError(f"SABER_AMD_PRECISION must be 'bf16' or 'fp16', got '{precision}'")
+        raise ValueError(f"precision must be 'bf16' or 'fp16', got '{precision}'")
     key = (idx, sam2_cfg, tuple(sorted(src.items())), replica, precision)
     if key not in _ENGINES:
         eng = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, precision=precision, **src)
@@ -44,7 +56,9 @@ def get_replica(engine, replica: int):
     flight per GPU; every handle must segment with the model slice 0 was segmented with, whatever the adapter's `cfg` field says
     (the AMG model is chosen by amg_cfg.sam2_cfg, reference automask.py:61)."""
     sam2_cfg, checkpoint = getattr(engine, "_build", (engine.cfg.name, None))
-    return get_engine(sam2_cfg, engine.device, checkpoint, max_images=engine.max_images, max_prompts=engine.max_prompts, replica=replica)
+    # the replica takes the 16-bit operand type OF THE HANDLE IT REPLICATES, not whatever the environment says by now (ADVICE r04)
+    return get_engine(sam2_cfg, engine.device, checkpoint, max_images=engine.max_images, max_prompts=engine.max_prompts, replica=replica,
+                      precision=engine.operands)
 
 
 def get_default() -> Dict[str, Any]:

@@ -179,7 +179,9 @@ class VideoPredictor:
         # 8f-1 sized the exchange that way; every rank, the encoding one included, then decodes from the ROUNDED features, so the ranks agree
         # bit for bit with each other but not with an unsharded run: +4e-3 (bf16) / +5e-4 (fp16) on the features).  Over xGMI the fp32 gather
         # of a 16-frame window is ~2 ms against ~55 ms of work per window, so precision is the default and bytes are the option.
-        self.gather_dtype = os.environ.get("SABER_AMD_VIDEO_GATHER", "fp32")
+        # Round 5: on an fp16 handle (the adapter's default) the 16-bit gather is the default - its +5e-4 is inside that mode's 1e-3 budget and the
+        # window then moves 8 instead of 16 MiB per frame; bf16 handles keep fp32 (+4e-3 would double that mode's error).
+        self.gather_dtype = os.environ.get("SABER_AMD_VIDEO_GATHER", "op16" if getattr(engine, "operands", "bf16") == "fp16" else "fp32")
         if self.gather_dtype not in ("fp32", "op16"):
             raise ValueError("SABER_AMD_VIDEO_GATHER must be 'fp32' or 'op16'")
         self._keep: List[torch.Tensor] = []
@@ -388,6 +390,7 @@ class VideoPredictor:
         toks = self._new(8, 256)
         self.eng._check(self.lib.saber_get_decoder_tokens(self.eng.h, 1, self._p(toks), self._s()))
         host = torch.cat([obj.reshape(-1)[:1], iou[0].reshape(-1)]).cpu()       # the one synchronisation of a tracked frame: object score + IoUs
+        self.eng.check_finite()          # overflow sentinel of the 16-bit modes (the stream has just drained: a 16-byte copy); SaberRangeError, never NaN masks
         obj_v = float(host[0])
         if self.hook is not None:
             self.hook(obj_v)

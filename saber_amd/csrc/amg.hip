@@ -99,7 +99,7 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
     hipStream_t s = (hipStream_t)stream;
     *out_count = 0;
     e->amg_last_syncs = 0;
-    ENG_HIP(e, hipMemsetAsync(e->prune_counters, 0, 16, (hipStream_t)stream));
+    ENG_HIP(e, hipMemsetAsync(e->prune_counters, 0, 32, (hipStream_t)stream));       // pruning statistics + the overflow sentinel's counters
     const int W32 = (W + 31) >> 5;
     const size_t mask_words = (size_t)H * W32;
     const int M = prm->multimask_output ? 3 : 1;
@@ -442,12 +442,13 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         ENG_KP(e, PC_MASK_POST, 0.0, 0.0, launch_amg_final(e->amg_surv, e->amg_nsurv, (int)total_cand, nc > 1 ? 1 : 0, prm->crop_nms_thresh, max_masks, e->amg_final_slots, e->amg_meta_dev,
                                                         e->amg_count_dev, e->amg_crop_bits, out_bits_dev, (int64_t)mask_words, s));
         int nf = 0;
-        unsigned long long h_pr[2] = {0, 0};
+        unsigned long long h_pr[4] = {0, 0, 0, 0};
         ENG_HIP(e, hipMemcpyAsync(&nf, e->amg_count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
         ENG_HIP(e, hipMemcpyAsync(out_meta, e->amg_meta_dev, sizeof(saber_mask_meta) * max_masks, hipMemcpyDeviceToHost, s));
-        ENG_HIP(e, hipMemcpyAsync(h_pr, e->prune_counters, 16, hipMemcpyDeviceToHost, s));
+        ENG_HIP(e, hipMemcpyAsync(h_pr, e->prune_counters, 32, hipMemcpyDeviceToHost, s));
         { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
         e->amg_last_pruned = (int64_t)h_pr[0]; e->amg_last_m2m = (int64_t)h_pr[1];
+        TRY(eng_check_finite_counts(e, reinterpret_cast<const unsigned int*>(h_pr + 2)));      // overflow sentinel: rides on the slice's one synchronisation
         if (nf < 0) return eng_fail(e, SABER_ERR_HIP, "amg_generate: device post-processing overflow (internal)");
         if (nf > max_masks) {
             *out_count = nf;
@@ -489,10 +490,11 @@ extern "C" int saber_amg_generate(saber_engine* e, const float* img_dev, int H, 
         m.crop_box_xywh[0] = (float)cd.crop[0]; m.crop_box_xywh[1] = (float)cd.crop[1];
         m.crop_box_xywh[2] = (float)(cd.crop[2] - cd.crop[0]); m.crop_box_xywh[3] = (float)(cd.crop[3] - cd.crop[1]);
     }
-    unsigned long long h_pr[2] = {0, 0};
-    ENG_HIP(e, hipMemcpyAsync(h_pr, e->prune_counters, 16, hipMemcpyDeviceToHost, s));
+    unsigned long long h_pr[4] = {0, 0, 0, 0};
+    ENG_HIP(e, hipMemcpyAsync(h_pr, e->prune_counters, 32, hipMemcpyDeviceToHost, s));
     { ENG_HIP(e, hipStreamSynchronize(s)); ++e->amg_last_syncs; }
     e->amg_last_pruned = (int64_t)h_pr[0]; e->amg_last_m2m = (int64_t)h_pr[1];
+    TRY(eng_check_finite_counts(e, reinterpret_cast<const unsigned int*>(h_pr + 2)));
     *out_count = nf;
     return SABER_OK;
 }

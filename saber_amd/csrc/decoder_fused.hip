@@ -900,7 +900,7 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
                                                                  const float* __restrict__ fs1, const float* __restrict__ fs0, int s_div, int s_off,
                                                                  const float* __restrict__ hyper, float* __restrict__ masks4, int P,
                                                                  const uint8_t* __restrict__ live, const float* __restrict__ iou4, int multimask, int dbg,
-                                                                 unsigned long long* __restrict__ stamps) {
+                                                                 unsigned long long* __restrict__ stamps, unsigned int* __restrict__ sentinel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
     char* w2s = w1s + UP_W1S;
@@ -933,6 +933,9 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
     // live (optional): prompts whose flag is 0 are skipped altogether (their masks are never read: engine.hip decode_chunk, IoU pruning)
     auto next_live = [&](int q, int qe) { while (live && q < qe && !live[q]) ++q; return q; };     // block-uniform
 
+    // overflow sentinel (engine.hip "sentinel"): x * 0 is NaN for a NaN / inf logit and 0 otherwise, so one fma per stored pixel keeps a
+    // sticky flag in `chk`; one atomic per wave at the end, and only when something was seen
+    float chk = 0.f;
     for (long long u = u0; u < u1;) {
         const int tile = (int)(u / P);
         const int p_begin = (int)(u - (long long)tile * P);
@@ -1175,7 +1178,10 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
                         if (pp == 0) px2.x = mine; else px2.y = mine;
 #endif
                     }
-                    if (((need[sI] >> fg) & 1) && !UPD(UPD_NO_STORE)) *reinterpret_cast<float2*>(orow[sI] + hb * 256) = px2;
+                    if (((need[sI] >> fg) & 1) && !UPD(UPD_NO_STORE)) {
+                        *reinterpret_cast<float2*>(orow[sI] + hb * 256) = px2;
+                        chk = fmaf(px2.x, 0.f, fmaf(px2.y, 0.f, chk));
+                    }
                     if (UPD(UPD_NO_STORE) && px2.x + px2.y == 1.2345e30f) *reinterpret_cast<float2*>(orow[sI] + hb * 256) = px2;     // (keeps the values alive)
                 }
                 UP_STAMP(3);
@@ -1187,6 +1193,10 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
         }
     }
     (void)fb0; (void)fb1;
+    if (sentinel) {
+        const unsigned long long bad = __ballot(chk != chk);
+        if (bad && lane == __ffsll((long long)bad) - 1) atomicAdd(sentinel, (unsigned int)__popcll(bad));
+    }
     if (UP_DEV && stamps && lane == 0)
         for (int k = 0; k < 5; ++k) stamps[((int64_t)blockIdx.x * (4 * UP_NTG) + wave) * 5 + k] = ts[k];
 #undef UP_STAMP
@@ -1194,7 +1204,7 @@ __global__ __launch_bounds__(UP_THREADS) void dec_upscale_kernel(const bf16_t* _
 
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap sm, const float* hyper, float* masks4, int P,
-                               hipStream_t s, const uint8_t* live, const float* iou4, int multimask) {
+                               hipStream_t s, const uint8_t* live, const float* iou4, int multimask, unsigned int* sentinel) {
     if (P <= 0) return nullptr;
     if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
     // one resident workgroup per CU; each takes an equal contiguous share of the UP_TILES x P (tile, prompt) units
@@ -1203,7 +1213,7 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
     const long long units = (long long)UP_TILES * P;
     const int grid = (int)(units < n_cu ? units : n_cu);
     hipLaunchKernelGGL(dec_upscale_kernel, dim3(grid), dim3(UP_THREADS), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, live, iou4, multimask,
-                       UP_DEV ? (g_saber_debug_flags >> 8) & 0x1ff : 0, UP_DEV ? g_saber_stamp_buf : nullptr);
+                       UP_DEV ? (g_saber_debug_flags >> 8) & 0x1ff : 0, UP_DEV ? g_saber_stamp_buf : nullptr, sentinel);
     return nullptr;
 }
 

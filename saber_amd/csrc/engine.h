@@ -87,6 +87,7 @@ struct saber_engine {
     bool iou_prune = true;          // AMG m2m pass: skip the mask upscaling of candidates whose predicted IoUs cannot pass pred_iou_thresh (identical results)
     uint8_t* live = nullptr;        // per-prompt flags of the decode chunk in progress
     unsigned long long* prune_counters = nullptr;   // device: [0] pruned, [1] seen (accumulated by iou_live_flags_kernel)
+    unsigned int* nonfinite = nullptr;              // device: overflow-sentinel counters (engine.hip "sentinel"); the 16 bytes behind prune_counters[0..1]
     int64_t amg_last_pruned = 0, amg_last_m2m = 0;    // statistics of the last saber_amg_generate call (bench.py)
     int decode_n_pts = 1;           // points per prompt of the decode call in progress (saber_decode_prompts; exact precision only when > 1)
     uint8_t *xn8_s = nullptr, *hid8_s = nullptr; int64_t mx_rows = 0;   // MXFP8 weight format: scale panels of the MX activations (their e4m3 bytes reuse xn / hid); mx_rows = panel rows
@@ -164,6 +165,8 @@ void prof_end(saber_engine* e, hipStream_t s);
     } while (0)
 
 int eng_fail(saber_engine* e, int code, const std::string& msg);
+// h[0..2]: the sentinel counters as read from the device; SABER_OK or SABER_ERR_RANGE with a message that names the stage
+int eng_check_finite_counts(saber_engine* e, const unsigned int* h);
 // Binds the calling thread to the engine's device for the duration of one C-ABI call and restores the caller's current device on
 // return (a caller whose torch current device is M must not find it switched to the engine's device N afterwards).
 // It also selects the kernels' 16-bit operand type for the call (kernels.h: the launchers dispatch on the calling thread's setting).

@@ -752,8 +752,9 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     e->slot_embb_valid.assign(B, 0);
 
     TRY(eng_alloc(e, &e->live, P));
-    TRY(eng_alloc(e, &e->prune_counters, 2));
-    ENG_HIP(e, hipMemset(e->prune_counters, 0, 16));
+    TRY(eng_alloc(e, &e->prune_counters, 4));                   // [0] pruned, [1] seen, [2..3] = the four 32-bit sentinel counters (engine.h: nonfinite)
+    ENG_HIP(e, hipMemset(e->prune_counters, 0, 32));
+    e->nonfinite = reinterpret_cast<unsigned int*>(e->prune_counters + 2);
     TRY(eng_alloc(e, &e->tok_pe, P * 8 * 256));
     TRY(eng_alloc(e, &e->queries, P * 8 * 256));
     TRY(eng_alloc(e, &e->tq, P * 8 * 256));
@@ -1065,8 +1066,34 @@ int eng_encode(saber_engine* e, const float* img_dev, int H, int W, int channels
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, gemm_bytes(g), launch_gemm(g, s));
     }
     for (int i = 0; i < n; ++i) { e->slot_valid[slot0 + i] = 1; e->slot_shared_valid[slot0 + i] = 0; e->slot_embb_valid[slot0 + i] = 0; }
+    // sentinel: a 16-bit activation that left its type's range (fp16: 65 504) is an inf from there on - through the fp32 accumulators, the
+    // fp32 residual stream and every LayerNorm / softmax statistic - so it ends in the pass's three feature maps: one HBM-bound scan (16 MB per crop)
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)n * 4096 * 256 * 4, launch_nonfinite_scan(e->emb + (size_t)slot0 * 4096 * 256, (int64_t)n * 4096 * 256, e->nonfinite + 0, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)n * 16384 * 64 * 4, launch_nonfinite_scan(e->fs1 + (size_t)slot0 * 16384 * 64, (int64_t)n * 16384 * 64, e->nonfinite + 0, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, (double)n * 65536 * 32 * 4, launch_nonfinite_scan(e->fs0 + (size_t)slot0 * 65536 * 32, (int64_t)n * 65536 * 32, e->nonfinite + 0, s));
     ENG_HIP(e, hipGetLastError());
     return SABER_OK;
+}
+
+// Overflow sentinel of the 16-bit arithmetic modes (include/saber_amd.h: saber_engine_check_finite).  Three device counters, written by
+// launches on the caller's stream: [0] non-finite values in the feature maps of an encoder pass, [1] in a decoder batch's predicted IoUs /
+// hypernetwork outputs (every token-side quantity feeds them), [2] low-res logits stored by dec_upscale.  Sticky until read.
+int eng_check_finite_counts(saber_engine* e, const unsigned int* h) {
+    if (!(h[0] | h[1] | h[2])) return SABER_OK;
+    return eng_fail(e, SABER_ERR_RANGE, std::string("non-finite values in the ") + (e->op_f16 ? "fp16" : "bf16") + " arithmetic: " + std::to_string(h[0]) +
+                    " in encoder features, " + std::to_string(h[1]) + " in decoder IoU / hypernetwork heads, " + std::to_string(h[2]) + " in low-res mask logits" +
+                    (e->op_f16 ? " - an activation left the range of IEEE half (65 504); results of this call are invalid: use precision bf16 (or exact) for this model / input"
+                               : " - the input image or the weights hold NaN / inf; results of this call are invalid"));
+}
+extern "C" int saber_engine_check_finite(saber_engine* e, void* stream) {
+    if (!e) return SABER_ERR_INVALID;
+    if (!e->finalized || !e->nonfinite) return SABER_OK;
+    ENG_DEVICE(e);
+    unsigned int h[4] = {0, 0, 0, 0};
+    ENG_HIP(e, hipMemcpyAsync(h, e->nonfinite, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ENG_HIP(e, hipStreamSynchronize((hipStream_t)stream));
+    if (h[0] | h[1] | h[2]) ENG_HIP(e, hipMemsetAsync(e->nonfinite, 0, 16, (hipStream_t)stream));
+    return eng_check_finite_counts(e, h);
 }
 
 extern "C" int saber_encode(saber_engine* e, const float* img_dev, int H, int W, int channels, const int* crop_boxes_host, int n,
@@ -1366,6 +1393,10 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         ENG_KP(e, PC_GEMM, 2.0 * g.M * (double)g.N * g.K * 4, gemm_bytes(g), launch_gemm(g, s));
     }
     }   // (separate token-side launches)
+    // sentinel: every token-side quantity of the batch ends in the predicted IoUs and the hypernetwork outputs (a NaN / inf row of the image-token
+    // state reaches them through the tokens -> image attentions: its score is NaN, so is the softmax sum); the logits are checked where they are stored
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_nonfinite_scan(e->iou4, (int64_t)P * 4, e->nonfinite + 1, s));
+    ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_nonfinite_scan(e->hyper_out, (int64_t)P * 128, e->nonfinite + 1, s));
     // IoU pruning (the AMG m2m pass): a single-mask candidate reports iou[0] or max(iou[1..3]) (dynamic multimask selection); when all four are
     // <= the caller's pred_iou_thresh it fails that filter whatever its masks look like, so its 1 MB of planes is neither computed nor read
     const uint8_t* live = nullptr;
@@ -1377,7 +1408,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     ENG_KP(e, PC_DEC_UPSCALE, (double)P * 2.0 * (4096.0 * 256 * 256 + 16384.0 * 64 * 128 + 65536.0 * 32 * 4), (double)P * (4096.0 * 256 * 2 + 4 * 65536.0 * 4),
            launch_dec_upscale(X, e->dc1.w, e->dc1.b, e->up_ln.g, e->up_ln.b, e->dc2p, e->dc2.b, e->fs1 + (size_t)slot0 * 16384 * 64,
                               e->fs0 + (size_t)slot0 * 65536 * 32, XMap{0, per_slot, p_base}, e->hyper_out, raw4_out ? raw4_out : e->masks4, P, s, live,
-                              getenv("SABER_AMD_ALL_PLANES") ? nullptr : e->iou4, multimask));      // (development A/B: all four planes)
+                              getenv("SABER_AMD_ALL_PLANES") ? nullptr : e->iou4, multimask, e->nonfinite + 2));      // (development A/B: all four planes)
     float* oi = out_iou ? out_iou : e->dec_out_iou;
     if (raw4_out) {
         ENG_KP(e, PC_ELEMENTWISE, 0.0, 0.0, launch_mask_pick(raw4_out, e->iou4, P, multimask, oi, out_sel, s, live));

@@ -319,3 +319,32 @@ const char* launch_patch_embed(const float* pix, const float* wt, const float* b
     else return "patch_embed: unsupported embed dim";
     return nullptr;
 }
+
+// ------------------------------------------------------------------------------------------------ non-finite sentinel
+// Counts the values of an fp32 array that are NaN or +-inf into one device counter (the engine's overflow sentinel: with fp16 operands a
+// stored activation beyond 65 504 becomes inf, and every consumer downstream of it - fp32 accumulators, the fp32 residual stream,
+// LayerNorm and softmax statistics - carries the inf / NaN on to the tensors scanned here; engine.hip "sentinel").  HBM-bound, one pass.
+__global__ __launch_bounds__(256) void nonfinite_scan_kernel(const float* __restrict__ p, int64_t n4, int64_t n, unsigned int* __restrict__ counter) {
+    unsigned int bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p) + i);
+        // x * 0 is 0 for every finite x and NaN for NaN / inf: one fma chain per vector, one compare
+        const float z = fmaf(v[0], 0.f, fmaf(v[1], 0.f, fmaf(v[2], 0.f, v[3] * 0.f)));
+        bad += (z != z) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) { const float x = p[4 * n4 + threadIdx.x] * 0.f; bad += (x != x) ? 1u : 0u; }
+    const unsigned long long m = __ballot(bad != 0);
+    if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(counter, (unsigned int)__popcll(m));
+}
+
+const char* launch_nonfinite_scan(const float* p, int64_t n, unsigned int* counter, hipStream_t s) {
+    if (n <= 0) return nullptr;
+    if (!p || !counter || (reinterpret_cast<uintptr_t>(p) & 15)) return "nonfinite_scan: null or unaligned pointer";
+    const int64_t n4 = n / 4;
+    const int64_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+    const int grid = (int)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(nonfinite_scan_kernel, dim3(grid), dim3(256), 0, s, p, n4, n, counter);
+    return nullptr;
+}

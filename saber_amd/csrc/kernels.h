@@ -89,6 +89,8 @@ const char* launch_resize_normalize(const float* img, int H, int W, int channels
 const char* launch_patch_embed(const float* pix, const float* wt, const float* bias, const float* pos, float* out, int n_images,
                                int C, int res, hipStream_t s);
 const char* image_ops_init_device();
+// overflow sentinel: adds the number of 4-value groups of p[0..n) that hold a NaN / inf to *counter
+const char* launch_nonfinite_scan(const float* p, int64_t n, unsigned int* counter, hipStream_t s);
 
 // ------------------------------------------------------------------ decoder_ops.hip
 struct PromptWeights {

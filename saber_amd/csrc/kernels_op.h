@@ -59,7 +59,8 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s, const XBuild* build = nullptr);
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap slot_map, const float* hyper, float* masks4, int P,
-                               hipStream_t s, const uint8_t* live = nullptr, const float* iou4 = nullptr, int multimask = 0);
+                               hipStream_t s, const uint8_t* live = nullptr, const float* iou4 = nullptr, int multimask = 0, unsigned int* sentinel = nullptr);
+// sentinel (optional): += number of lanes that stored a NaN / inf logit
 // live: optional per-prompt flags, prompts with 0 are skipped; iou4 ([P][4], optional): only the planes a multimask / single-mask selection can return are computed
 const char* decoder_fused_init_device();
 const char* launch_dec_tokens(const TokSeg& s, hipStream_t st);

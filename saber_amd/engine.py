@@ -96,7 +96,13 @@ class Engine:
     def _check(self, st: int):
         if st != 0:
             msg = self.lib.saber_last_error(self.h).decode()
-            raise (ValueError if st == -1 else RuntimeError)(f"saber_amd: {msg}")
+            raise (ValueError if st == -1 else _lib.SaberRangeError if st == _lib.SABER_ERR_RANGE else RuntimeError)(f"saber_amd: {msg}")
+
+    def check_finite(self):
+        """Overflow sentinel (include/saber_amd.h: saber_engine_check_finite): waits for the current stream and raises SaberRangeError when an
+        encode / decode since the last check produced NaN / inf (fp16 operands: an activation beyond 65 504).  amg_generate checks by itself;
+        call this after encode / decode_points where the host synchronises anyway."""
+        self._check(self.lib.saber_engine_check_finite(self.h, _stream()))
 
     def close(self):
         if getattr(self, "h", None):

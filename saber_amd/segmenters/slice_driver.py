@@ -57,7 +57,8 @@ def shard_bounds(Z: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area: int = 100,
-                           group=None, engine=None, smooth_scale: Optional[float] = None) -> Optional[np.ndarray]:
+                           group=None, engine=None, smooth_scale: Optional[float] = None, timings: Optional[dict] = None,
+                           keep_on_device: bool = False, planes_out: Optional[list] = None) -> Optional[np.ndarray]:
     """Slice-parallel slice_by_slice.  `volume` only supplies the shape (Z,H,W); `slice_fn(z)` returns the uint16
     label plane of slice z as a tensor on this rank's device.  All ranks receive every plane (all_gather of equal,
     zero-padded chunks); the (Z,H,W) uint32 stitched labels are returned (reference: utils.separate_masks).  With `engine`
@@ -65,8 +66,20 @@ def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area:
     `slice_fn` may be a LIST of callables, one per engine handle of this rank: its slices are then dealt round-robin to one thread
     per handle, each on its own HIP stream (two slices in flight per GPU fill each other's idle issue slots: +6 % measured).
     `smooth_scale` (device stitch only) also applies the post step of segment_tomogram_core (inference_core.py:68-74, scale 0.05):
-    fast_3d_gaussian_smoothing on the stitched labels without leaving the device; the result is then the uint8 volume it returns."""
+    fast_3d_gaussian_smoothing on the stitched labels without leaving the device; the result is then the uint8 volume it returns.
+    `timings` (a dict, bench.py): filled with the seconds since entry at which this rank's chunk was segmented (`segmented`), every rank's
+    planes had arrived (`gathered`) and the stitch had finished on the device (`stitched`), each behind a device synchronisation.
+    `keep_on_device` (device stitch only): return the (Z,H,W) int32 device tensor that holds the uint32 labels instead of a host array;
+    `planes_out` (device stitch only): a list that receives the gathered (Z,H,W) int16 device tensor of label planes the stitch ran on."""
+    import time
     import torch.distributed as dist
+    t_entry = time.perf_counter()
+
+    def stamp(key, dev_):
+        if timings is not None:
+            if dev_ is not None and dev_.type == "cuda":
+                torch.cuda.synchronize(dev_)
+            timings[key] = time.perf_counter() - t_entry
     Z, H, W = volume.shape
     dist_on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if dist_on else 1
@@ -113,6 +126,7 @@ def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area:
     if local is None:  # rank without slices
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and dist_on and dist.get_backend(group) == "nccl" else torch.device("cpu")
         local = torch.zeros((chunk, H, W), dtype=torch.int16, device=dev)
+    stamp("segmented", dev)
     if world > 1:
         full = torch.empty((world * chunk, H, W), dtype=torch.int16, device=dev)
         # byte view: gloo (CPU tests) has no int16 collectives; RCCL moves the same bytes
@@ -126,13 +140,22 @@ def segment_volume_sharded(volume, slice_fn, stitch: bool = True, min_mask_area:
             dist.all_gather_into_tensor(full.view(torch.uint8), local.view(torch.uint8), group=group)
     else:
         full = local
+    stamp("gathered", dev)
     if stitch and engine is not None and full.is_cuda:
         parts = []
         for r in range(world):
             a, b = shard_bounds(Z, world, r)
             parts.append(full[r * chunk: r * chunk + (b - a)])
         planes_dev = parts[0] if world == 1 and parts[0].shape[0] == Z else torch.cat(parts, 0)
-        labels, _ = engine.separate_masks(planes_dev.contiguous(), min_mask_area=min_mask_area)
+        planes_dev = planes_dev.contiguous()
+        if planes_out is not None:
+            planes_out.append(planes_dev)
+        labels, n_labels = engine.separate_masks(planes_dev, min_mask_area=min_mask_area)
+        stamp("stitched", dev)
+        if timings is not None:
+            timings["labels"] = n_labels
+        if keep_on_device and smooth_scale is None:
+            return labels
         if smooth_scale is not None:
             smoothed, _ = engine.smooth_labels(labels, smooth_scale)
             return smoothed.cpu().numpy()
