@@ -43,6 +43,20 @@ extern "C" int saber_k_gemm_ld(const uint16_t* A, int lda, const uint16_t* W, in
     GemmParams p;
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.res = res; p.ldres = N; p.Cf = out_f32; p.ldcf = N; p.Cb = out_bf16; p.ldcb = N;
     p.M = M; p.N = N; p.K = K; p.act = act; p.w_kpad = w_kpad;
+    // the widest 16-bit-output GEMMs read W packed per K-step (the engine packs qkv / mlp.layers.0 once at finalize: engine.hip); here: into a
+    // scratch kept per thread, so that the kernel-level tests and tools/gemm_bench.py reach the kernels the engine runs
+    if (w_kpad && out_bf16 && !out_f32 && !res && (K % 64) == 0 && (N & 7) == 0 && ((int64_t)M * N >= (int64_t)1024 * 65536 || (g_saber_debug_flags & 128))) {
+        static thread_local bf16_t* scratch = nullptr;
+        static thread_local size_t scratch_elems = 0;
+        const size_t need = gemm_rowln_packed_elems(N, K);
+        if (need > scratch_elems) {
+            if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); scratch = nullptr; scratch_elems = 0; }
+            if (hipMalloc(reinterpret_cast<void**>(&scratch), need * sizeof(bf16_t)) != hipSuccess) return kfail("gemm: scratch allocation failed");
+            scratch_elems = need;
+        }
+        if (const char* m = launch_pack_w_kstep(W, ldw, N, K, scratch, (hipStream_t)stream)) return kfail(m);
+        p.Wpk = scratch;
+    }
     return kcheck(launch_gemm(p, (hipStream_t)stream));
 }
 

@@ -25,9 +25,13 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_bits_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float f16_bits_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 // round-to-nearest-even f32 -> 16-bit pair (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+// (a vector conversion: ONE v_cvt_pk_bf16_f32.  Through hip_bf16.h's __float22bfloat162_rn the same pair came out, inside the big kernels,
+// as two single conversions + a shift + an SDWA or - four VALU instructions per packed register in every bf16 epilogue; found in round 5
+// in the instruction stream of gemm_w1e.hip)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16_rn(float lo, float hi) {
-    __hip_bfloat162 v = __float22bfloat162_rn(make_float2(lo, hi));
-    return *reinterpret_cast<uint32_t*>(&v);
+    const f32x2 x = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
 }
 __device__ __forceinline__ uint32_t pack_f16_rn(float lo, float hi) {
     const f16x2_t v = {(_Float16)lo, (_Float16)hi};

@@ -201,7 +201,7 @@ extern "C" int saber_engine_create(int device_id, const char* trunk, int max_ima
     if (const char* m = hiera_spec(e, *spec)) { delete e; return eng_fail(nullptr, SABER_ERR_INVALID, m); }
     {
         const char* m = gemm_init_device();
-        if (!m) m = gemm_rowln_init_device();
+            if (!m) m = gemm_rowln_init_device();
         if (!m) m = amg_device_init();
         if (!m) m = hiera_attention_init_device();
         if (!m) m = image_ops_init_device();

@@ -1151,6 +1151,8 @@ const char* launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     // (round 4's one-wave-per-SIMD direct-to-LDS kernel, tools/experiments/gemm_w1d.hip, matched this kernel's K-loop rate and lost on its epilogue: DESIGN.md section 8)
     if (direct_ok && bf16_only && ((tiles_p2 >= 1024 && (p.N >= 1024 || (p.act == ACT_NONE && p.N >= 384)) && !(p.dbg & 64)) || (p.dbg & 128))) {
         // widest bf16-output GEMMs (qkv, fc1 of stages 2-3): persistent 256x256 tiles, one workgroup per CU
+        // (round 5's one-wave-per-SIMD kernel whose epilogue runs under the NEXT tile's K loop, tools/experiments/gemm_w1e.hip: parity-green and
+        // bit-identical to this kernel, 5-27 % ahead of it in tools/gemm_bench.py, 5-10 % BEHIND it inside the engine - DESIGN.md section 8)
         const int slots = padded((p.M + 255) / 256, (p.N + 255) / 256);
         // opt-in experiment (SABER_AMD_P256X=1): the 32x32x16 kernel without staggered groups.  2-4 % faster than the staggered kernel in
         // isolation, level with it inside the slice (same-box A/B: 145.8 vs 145.5 ms), and its fp32 summation order differs from the

@@ -14,7 +14,7 @@ Two sources:
 """
 import zlib
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 
@@ -208,6 +208,28 @@ def seeded_weights(cfg: HieraConfig, seed: int = 0, video: bool = False) -> Dict
     if video:
         specs = OrderedDict(list(specs.items()) + list(video_param_specs().items()))
     return OrderedDict((n, _gen(n, s, k, g, seed)) for n, (s, k, g) in specs.items())
+
+
+def fitted_decoder_weights(cfg: HieraConfig, seed: int = 0, video: bool = False, path: Optional[str] = None) -> Dict[str, np.ndarray]:
+    """seeded_weights(cfg, seed) with the mask decoder (and the prompt encoder's mask-input branch) replaced by the tensors that
+    oracle/fit_decoder_heads.py fitted on the synthetic slices (tests/golden/decoder_fit_large_seed0.npz, float16): the seeded Hiera-L
+    encoder with a decoder whose masks are compact objects with a spread of predicted IoU / stability, so that cfgAMG's OWN thresholds and
+    both NMS stages (saber/adapters/sam2/amg.py:7-17) leave a non-trivial set of masks on BASELINE configs[1]'s slice.  Not a checkpoint:
+    a fixture that gives the generator's filters, the duplicate removal and the paint order something to do (no weights ship offline)."""
+    import os
+    if cfg.name != "large" or seed != 0:
+        raise ValueError("the fitted decoder exists for the seeded Hiera-L model (seed 0) only")
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "decoder_fit_large_seed0.npz")
+    W = seeded_weights(cfg, seed, video)
+    with np.load(path) as Z:
+        for k in Z.files:
+            if k.startswith("__"):
+                continue
+            if k not in W or W[k].shape != Z[k].shape:
+                raise ValueError(f"fitted decoder tensor '{k}' does not match the model")
+            W[k] = np.ascontiguousarray(Z[k], dtype=np.float32)
+    return W
 
 
 def stress_weights(cfg: HieraConfig, seed: int = 0, gamma_outlier: float = 30.0, massive: float = 200.0) -> Dict[str, np.ndarray]:
