@@ -252,7 +252,7 @@ def full_size_keys(a, engines, pool, make_amg_params, Z=512, window=24):
     # (1) per-slice ids are list positions: contiguous 1..n on every sampled plane (propagation.py:185-186)
     n_fg = int((planes.view(Z, -1).max(1).values > 0).sum().item())
     assert n_fg > Z // 2, f"only {n_fg} of {Z} planes carry masks"
-    for z in range(0, Z, 37):
+    for z in range(0, Z, 37):       # (contiguous as long as no mask is painted over completely: true for the seeded decoder's masks, not in general)
         ids = torch.unique(planes[z])
         ids = ids[ids > 0]
         assert torch.equal(ids.long(), torch.arange(1, ids.numel() + 1, device=ids.device)), f"plane {z}: ids not contiguous"
@@ -831,6 +831,37 @@ def main():
             for e_ in engines:
                 e_.close()
             engines.clear()
+        try:        # the same step on the seeded encoder + the FITTED mask decoder (tests/golden/decoder_fit_large_seed0.npz): compact masks
+            #           with a spread of predicted IoU / stability, so cfgAMG's own thresholds and both NMS stages leave real masks and the post-filter
+            #           tail (per-crop / cross-crop NMS, survivors' copies, pair intersections, dedup, sort, paint) runs on them; never part of `value`
+            from saber_amd.weights import fitted_decoder_weights
+            Wf = fitted_decoder_weights(cfg, 0)
+            alt = [Engine("large", device=local_rank, weights=Wf, max_images=a.max_images, max_prompts=a.max_prompts) for _ in range(a.workers)]
+            engines.extend(alt)
+            eng = engines[0]
+            rec = {}
+            for prune in (False, True):
+                for e_ in engines:
+                    e_.set_iou_pruning(prune)
+                run_steps(0, 2 * len(engines))
+                torch.cuda.synchronize()
+                n_alt = max(8, a.steps // 2)
+                t0 = time.perf_counter()
+                nm = run_steps(0, n_alt)
+                torch.cuda.synchronize()
+                dta = (time.perf_counter() - t0) / n_alt
+                rec["iou_pruning_on" if prune else "iou_pruning_off"] = {"slices_per_s": 1.0 / dta, "ms_per_slice": dta * 1e3, "slices": n_alt, "masks_per_slice": nm / n_alt, "vs_headline": (dt / a.steps) / dta}
+            pruned, seen = eng.last_pruning()
+            rec["iou_pruning_on"].update(m2m_candidates=seen, pruned=pruned)
+            rec["what"] = ("the headline's step (bf16, cfgAMG defaults, two handles) on the seeded Hiera-L encoder with the fitted mask decoder (oracle/fit_decoder_heads.py): the filters, "
+                           "both NMS stages and the paint tail work on real masks; `iou_pruning_on` is the engine's default (m2m candidates that cannot pass pred_iou_thresh skip the upscaling), "
+                           "whose saving depends on the IoU head - here a fitted one")
+            out["fitted_decoder"] = rec
+        except Exception as ex:
+            out["fitted_decoder"] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
+        for e_ in engines:
+            e_.close()
+        engines.clear()
         try:        # the exact (fp32-operand) mode on the same step: ONE handle, the whole slice (21 crops, 3 072 + 9 216 prompts); a verification mode, never part of `value`
             ex_eng = Engine("large", device=local_rank, weights=weights, max_images=a.max_images, max_prompts=a.max_prompts, precision="exact")
             ex_eng.set_iou_pruning(False)

@@ -69,6 +69,11 @@ def main():
     W = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in Wnp.items()}
     train_keys = [k for k in W if k.startswith("sam_mask_decoder.") and not k.startswith(("sam_mask_decoder.conv_s0", "sam_mask_decoder.conv_s1"))]
     train_keys += [k for k in W if k.startswith("sam_prompt_encoder.mask_downscaling.")]
+    if os.environ.get("FIT_INIT"):                      # continue from an earlier result (a GPU-box call is limited to 20 minutes)
+        with np.load(os.environ["FIT_INIT"]) as Z:
+            for k in train_keys:
+                W[k] = torch.from_numpy(np.ascontiguousarray(Z[k], dtype=np.float32)).to(dev)
+        print("continuing from", os.environ["FIT_INIT"], flush=True)
     n_par = sum(W[k].numel() for k in train_keys)
     print(f"device {dev}; fitting {len(train_keys)} tensors, {n_par / 1e6:.2f} M parameters; {steps} steps of {P} prompts", flush=True)
 

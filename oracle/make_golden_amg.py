@@ -35,19 +35,25 @@ if VARIANT == "stability":
 elif VARIANT == "cfgamg":
     AMG = dict(AMG, pred_iou_thresh=0.0, stability_score_thresh=0.92, box_nms_thresh=0.7, crop_nms_thresh=0.7)
     OUT = os.path.join(GOLDEN, "amg_default_grid_cfgamg_seed0.npz")
+elif VARIANT == "fitted":
+    # Round 5: the seeded Hiera-L encoder with the FITTED mask decoder (oracle/fit_decoder_heads.py ->
+    # tests/golden/decoder_fit_large_seed0.npz, saber_amd.weights.fitted_decoder_weights): compact masks with a spread of predicted IoU and
+    # stability, so the generator runs at cfgAMG's OWN thresholds (saber/adapters/sam2/amg.py:7-17) with both NMS stages ON
+    AMG = dict(AMG, pred_iou_thresh=0.7, stability_score_thresh=0.92, box_nms_thresh=0.7, crop_nms_thresh=0.7)
+    OUT = os.path.join(GOLDEN, "amg_default_grid_fitted_seed0.npz")
 elif VARIANT:
-    raise SystemExit("VARIANT must be '', 'stability' or 'cfgamg'")
+    raise SystemExit("VARIANT must be '', 'stability', 'cfgamg' or 'fitted'")
 
 
 def main():
     from saber_amd.model_config import get_config
-    from saber_amd.weights import seeded_weights
+    from saber_amd.weights import fitted_decoder_weights, seeded_weights
     from oracle import saber_ref
     from oracle.sam2_ref import ImagePredictorRef
     from oracle.amg_ref import AutomaticMaskGeneratorRef
     torch.set_num_threads(int(os.environ.get("THREADS", "6")))
     cfg = get_config("large")
-    W = seeded_weights(cfg, 0)
+    W = fitted_decoder_weights(cfg, 0) if VARIANT == "fitted" else seeded_weights(cfg, 0)
     img = saber_ref.prepare(saber_ref.synthetic_slice(seed=0).astype(np.float32), to_rgb=True)
     t0 = time.time()
     anns = AutomaticMaskGeneratorRef(ImagePredictorRef(W, cfg), **AMG).generate(img)

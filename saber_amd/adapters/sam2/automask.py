@@ -45,6 +45,10 @@ def get_engine(sam2_cfg: str, device, checkpoint: Optional[str] = None, max_imag
         raise ValueError(f"precision must be 'bf16' or 'fp16', got '{precision}'")
     key = (idx, sam2_cfg, tuple(sorted(src.items())), replica, precision)
     if key not in _ENGINES:
+        if src.pop("fitted_decoder", None):               # SABER_AMD_SEEDED_WEIGHTS=fitted (tests / bench): seeded encoder + fitted mask decoder
+            from saber_amd.model_config import get_config
+            from saber_amd.weights import fitted_decoder_weights
+            src = {"weights": fitted_decoder_weights(get_config(sam2_cfg), src.get("seed", 0))}
         eng = Engine(sam2_cfg, device=idx, max_images=max_images, max_prompts=max_prompts, precision=precision, **src)
         eng._build = (sam2_cfg, checkpoint)       # what get_replica() needs to build an identical handle
         _ENGINES[key] = eng

@@ -5,6 +5,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <atomic>
+
 static thread_local std::string g_kerr;
 static int kfail(const char* m) { g_kerr = m ? m : "unknown"; return -1; }
 static int kcheck(const char* m) {
@@ -151,6 +153,18 @@ extern "C" int saber_k_stream_create_cu_range(int first_cu, int n_cus, void** ou
     return 0;
 }
 extern "C" int saber_k_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : kfail("hipStreamDestroy failed"); }
+int saber_cu_count() {
+    static std::atomic<int> table[64];                      // zero-initialised; 0 = not queried yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = table[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t pr;
+    n = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    table[dev].store(n, std::memory_order_relaxed);         // (every thread that races here computes the same value)
+    return n;
+}
+
 extern "C" int saber_k_set_operand_type(int f16) { const int prev = g_saber_op_f16; g_saber_op_f16 = f16 ? 1 : 0; return prev; }
 
 // ------------------------------------------------------------------------------------------------ video (memory) path kernels

@@ -1208,8 +1208,7 @@ const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b
     if (P <= 0) return nullptr;
     if (sm.div <= 0) return "dec_upscale: XMap.div must be positive";
     // one resident workgroup per CU; each takes an equal contiguous share of the UP_TILES x P (tile, prompt) units
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = saber_cu_count();
     const long long units = (long long)UP_TILES * P;
     const int grid = (int)(units < n_cu ? units : n_cu);
     hipLaunchKernelGGL(dec_upscale_kernel, dim3(grid), dim3(UP_THREADS), UP_LDS, s, X, W1, b1, ln_g, ln_b, W2p, b2, fs1, fs0, sm.div, sm.off, hyper, masks4, P, live, iou4, multimask,

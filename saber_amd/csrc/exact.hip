@@ -311,8 +311,7 @@ static const char* xg_gemm(const XGemm& p, hipStream_t s) {
         // short-K GEMMs (K <= 128: the 128 -> 256 out-projection of the image -> token attention, the K = 64 up-convolution) take 128 x 64 tiles:
         // 110 registers = four workgroups per CU to hide their tile-start and store latency
         const int bn = (p.N > 64 && !(p.K <= 128 && p.N <= 256)) ? 128 : 64;
-        static int n_cu = 0;
-        if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+        const int n_cu = saber_cu_count();
         // persistent row tiles: as many workgroups as stay resident (3 or 4 per CU), each walking blockIdx.y, + gridDim.y, ... ; the column tiles of
         // one row tile stay neighbours in dispatch order (they share the A tile in L2)
         const int gx = (p.N + bn - 1) / bn;
@@ -1085,10 +1084,25 @@ static ExactWs* ws_of(saber_engine* e) { return reinterpret_cast<ExactWs*>(e->ex
 // token-side GEMMs (8 rows per prompt) get 4 096 rows instead of 1 024
 int exact_chunk_prompts(const saber_engine* e) { return std::min(e->max_prompts, 512); }
 
+static int ensure_ws_alloc(saber_engine* e, ExactWs* w);
+//  the handle learns about the workspaces only when EVERY allocation has succeeded: these are ~14 GB next to a 58-GB production
+// handle, so a hipMalloc failure half way is plausible, and a non-null exact_ws with null members would send the next exact call into
+// kernels on nullptr buffers.  On failure what was allocated is released again.
 static int ensure_ws(saber_engine* e) {
     if (e->exact_ws) return SABER_OK;
     ExactWs* w = new ExactWs();
+    const int st = ensure_ws_alloc(e, w);
+    if (st != SABER_OK) {
+        void* bufs[] = {w->xn, w->qkv, w->att, w->hid, w->sb[0], w->sb[1], w->sb[2], w->sb[3], w->lat3, w->keys, w->kpe, w->p0, w->p1, w->patt, w->up1, w->up2, w->h2,
+                        w->t0, w->t1, w->tq, w->tk, w->tv, w->ta, w->thid, w->hd0, w->hd1};
+        for (void* b : bufs) if (b) eng_free(e, b);
+        delete w;
+        return st;
+    }
     e->exact_ws = w;
+    return SABER_OK;
+}
+static int ensure_ws_alloc(saber_engine* e, ExactWs* w) {
     const size_t C0 = (size_t)e->embed_dim, NI = (size_t)e->max_images;      // the whole pass of up to max_images crops at once (round 4)
     TRY(eng_alloc(e, &w->xn, NI * 65536 * C0));
     TRY(eng_alloc(e, &w->qkv, NI * 65536 * 6 * C0));

@@ -457,13 +457,7 @@ const char* launch_gemm_rowln(const GemmParams& p_in, hipStream_t stream) {
         ((uintptr_t)p.ln_gamma & 15) || ((uintptr_t)p.ln_beta & 15))
         return "gemm_rowln: operand alignment";
     constexpr int lds24 = RowLnCfg<2, 4>::LDS, lds42 = RowLnCfg<4, 2>::LDS, lds81 = RowLnCfg<8, 1>::LDS;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return "gemm_rowln: device query failed";
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = saber_cu_count();
     if (p.N == 576) {
         const int tiles = (p.M + 127) / 128;
         hipLaunchKernelGGL((gemm_rowln_kernel<2, 4>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), lds24, stream, p);

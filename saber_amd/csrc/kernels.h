@@ -15,6 +15,9 @@
 // development switches shared by all kernel files (capi_kernels.hip: saber_k_set_debug, saber_k_set_stamp_buffer)
 extern int g_saber_debug_flags;
 extern unsigned long long* g_saber_stamp_buf;
+// compute units of the calling thread's CURRENT device (capi_kernels.hip): queried once per device, thread-safe (the launchers kept
+// function-local `static int n_cu`s - a data race between worker threads, and the first caller's device for everybody)
+int saber_cu_count();
 // operand type of the calling thread: 0 = bf16, 1 = fp16 (capi_kernels.hip)
 extern thread_local int g_saber_op_f16;
 inline bool saber_op_is_f16() { return g_saber_op_f16 != 0; }

@@ -33,6 +33,8 @@ def resolve_weights(sam2_cfg: str, checkpoint: str = None):
         return {"checkpoint": path}
     if os.environ.get("SABER_AMD_SEEDED_WEIGHTS", "0") == "1":
         return {"seed": int(os.environ.get("SABER_AMD_SEED", "0"))}
+    if os.environ.get("SABER_AMD_SEEDED_WEIGHTS", "0") == "fitted":      # the seeded encoder with the fitted mask decoder (saber_amd.weights.fitted_decoder_weights; tests / bench only)
+        return {"seed": 0, "fitted_decoder": 1}
     raise FileNotFoundError(f"SAM2.1 checkpoint '{path}' not found (no network: nothing is downloaded). Place the file there, "
                             f"or set SABER_AMD_SEEDED_WEIGHTS=1 to run with deterministic synthetic weights.")
 
@@ -46,4 +48,7 @@ def load_weights(sam2_cfg: str, checkpoint: str = None, video: bool = False):
     cfg = get_config(sam2_cfg)
     if "checkpoint" in src:
         return load_checkpoint(src["checkpoint"], cfg, video=video)
+    if src.get("fitted_decoder"):
+        from saber_amd.weights import fitted_decoder_weights
+        return fitted_decoder_weights(cfg, src["seed"], video=video)
     return seeded_weights(cfg, src["seed"], video=video)

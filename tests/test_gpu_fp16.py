@@ -13,12 +13,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3        # north star: "float logits within 1e-3 rel": asserted on every encoder feature map and on the decoder alone (identical features)
-# The composition of the two halves, each under 1e-3, is NOT under it: measured 1.05e-3 (8 random prompts) ... 1.3e-3 (64 grid prompts of the bench
-# slice) on Hiera-L, 1.6e-3 on the tiny golden = sqrt(encoder^2 + decoder^2) with 7.4e-4 and 8.0e-4.  No single tensor carries the excess
-# (switching any ONE rounding point of the emulated decoder off moves the result by the same ~10 %: the error is the sum of ~25 roundings of
-# 2^-11 each), so there is no cheap tensor to widen; TF32 itself (10 mantissa bits at every product, what the reference runs) sits at the
-# same level.  Bound for end-to-end quantities: 2x the measured 1e-3 level, reported by every test.
-TOL_E2E = 2e-3
+# The composition of the two halves, each under 1e-3, is NOT under it: sqrt(encoder^2 + decoder^2) with 7.4e-4 and 8.0e-4.  No single tensor carries
+# the excess (switching any ONE rounding point of the emulated decoder off moves the result by the same ~10 %: the error is the sum of ~25
+# roundings of 2^-11 each), so there is no cheap tensor to widen; TF32 itself (10 mantissa bits at every product, what the reference runs) sits
+# at the same level.  Round 5: the bounds of the end-to-end quantities are what this suite MEASURES + 15 %
+# (gpurun_out/r05g/gpu_suite2.log, copied to profiles/r05_full_gpu_suite.log), per quantity instead of one loose 2e-3:
+TOL_E2E = 1.25e-3        # Hiera-L, first pass: low-res logits 1.05-1.07e-3, predicted IoU 9.1e-4 abs (8 random prompts / stress weights / one handle)
+TOL_E2E_M2M = 1.75e-3    # Hiera-L, mask-prompted refinement (the second decode reads 256 x 256 rounded logits as its prompt): 1.52e-3
+TOL_E2E_TINY = 1.85e-3   # BASELINE configs[0], Hiera-tiny golden: 1.59e-3
+TOL_E2E_TINY_M2M = 2.45e-3   # ... its m2m refinement, two decodes in series from the engine's own first pass: 2.10e-3
 
 
 def rel_rms(a, b):
@@ -110,7 +113,7 @@ def test_fp16_decoder_and_m2m_within_1e3(engine_f16, image, oracle_large, oracle
         r_low2, r_iou2, _, _, _ = sam2_ref.mask_decoder(W, oracle_feats, sp, de, False)
     e2 = rel_rms(low2.cpu(), r_low2)
     print(f"FP16 m2m vs fp32 oracle: low-res rel-rms {e2:.2e}, iou abs {(iou2.cpu() - r_iou2).abs().max().item():.2e}")
-    assert e2 < TOL_E2E and (iou2.cpu() - r_iou2).abs().max().item() < TOL_E2E
+    assert e2 < TOL_E2E_M2M and (iou2.cpu() - r_iou2).abs().max().item() < TOL_E2E
 
 
 def test_fp16_engine_matches_its_rounding_model(engine_f16, image, oracle_large, oracle_feats):
@@ -150,12 +153,12 @@ def test_fp16_config1_tiny_golden():
         e_low = rel_rms(low[0, :, ::4, ::4].cpu(), torch.from_numpy(M["low_res_sub"]))
         e_iou = float(np.abs(iou.cpu().numpy() - M["iou"]).max())
         print("FP16 config 1 (tiny) vs golden:", errs, "low-res", e_low, "iou", e_iou)
-        assert max(errs.values()) < TOL and e_low < TOL_E2E and e_iou < TOL
+        assert max(errs.values()) < TOL and e_low < TOL_E2E_TINY and e_iou < TOL
         mi = torch.clamp(low[:, 0], -32, 32).contiguous()
         low2, iou2, _ = eng.decode_points(pts.cuda(), slot=0, multimask=False, mask_input=mi)
         e2 = rel_rms(low2[0, :, ::4, ::4].cpu(), torch.from_numpy(M["m2m_low_res_sub"]))
         print("FP16 config 1 m2m low-res", e2)
-        assert e2 < 2 * TOL_E2E    # (its mask prompt is the engine's own first-pass output, not the golden's: two decodes in series)
+        assert e2 < TOL_E2E_TINY_M2M    # (its mask prompt is the engine's own first-pass output, not the golden's: two decodes in series)
         eng.check_finite()         # the overflow sentinel stays silent on a healthy model
     finally:
         eng.close()
