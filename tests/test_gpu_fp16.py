@@ -311,7 +311,8 @@ def test_fp16_default_grid_amg_golden(large_weights):
         # paired with a different, similar candidate)
         matched = dev < 1e-2
         assert matched.mean() > 0.95
-        assert np.abs(piou - G["predicted_iou"])[matched].max() < TOL_E2E
+        print("predicted_iou abs diff of the matched masks (|IoU - 1| < 1e-2): max", np.abs(piou - G["predicted_iou"])[matched].max())
+        assert np.abs(piou - G["predicted_iou"])[matched].max() < TOL_E2E_M2M          # (the golden's masks are m2m refinements)
     finally:
         eng.close()
 
