@@ -18,6 +18,7 @@
 // O^T = V^T.P^T, V^T fragments via ds_read_b64_tr_b16).
 #include "common.h"
 #include "kernels.h"
+#include <utility>
 
 // cache policy of dec_i2t's read of a prompt's image-token state, its LAST use (2 = nontemporal: same-box A/B 20.55 -> 19.86 ms per slice;
 // the same hint on dec_upscale's reads cost it 0.5 ms)
@@ -484,6 +485,325 @@ __global__ __launch_bounds__(256) void dec_t2i_finish_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ tokens -> image, one wave per SIMD (round 5)
+// dec_t2i_kernel reads every key fragment once per QUERY TILE (its waves are 4 query tiles x 2 key halves): 272 KB of LDS reads and 100
+// LDS instructions per 64-key block for 272 MFMAs, and the chain read -> wait -> MFMA of each wave is short (34 MFMAs per step).  Here a
+// wave owns a key QUARTER and all FOUR query tiles: a key / value fragment is read once and feeds four MFMAs (136 per 32-key step), the
+// partial sums of the whole 64 x 256 output (256 registers) live in the wave, and the query fragments are re-read from a 32-KB LDS image
+// (they would be another 128 registers).  That needs ~400 registers: ONE wave per SIMD, so the latencies are hidden inside the wave
+// (fragments of the next k-step / value group are requested before the MFMAs of the current one).
+//  * wave w streams keys 128 kb + 32 w .. + 31 of every 128-key block through a PRIVATE two-stage ring (2 x 16 KB, global -> LDS directly):
+//    no workgroup barrier in the key loop, counted vmcnt waits only;
+//  * the positional operand rows (PEK, 1 MB for all prompts: L2) come through registers, requested one step ahead;
+//  * the four key quarters are merged pairwise through the (then dead) rings, then v_proj as in dec_t2i_kernel's tail.
+// grid = P (whole key range per workgroup; the engine's split > 1 cases - fewer than 512 prompts - stay on dec_t2i_kernel).
+#ifdef SABER_OP_F16
+#define T4_MFMA_OP "v_mfma_f32_16x16x32_f16"
+#else
+#define T4_MFMA_OP "v_mfma_f32_16x16x32_bf16"
+#endif
+// The 64 x 256 partial sums of a wave are PHYSICAL AccVGPRs named in the instruction strings: tile (q, dt) = a[(16 q + dt) * 4 .. + 3].  As
+// compiler-allocated values they were moved through VGPRs and scratch every iteration (332 spilled registers: the conditional rescale is VALU
+// work on them, so the allocator wants them in VGPRs and then splits their live ranges) - the lesson of tools/experiments/gemm_w1e.hip.
+#define T4_ACC(q, dt) (((q) * 16 + (dt)) * 4)
+#define T4_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+template <int N> __device__ __forceinline__ void t4_acc_mfma(const op16x8& a, const op16x8& b) {
+    asm volatile(T4_MFMA_OP " a[%0:%1], %2, %3, a[%0:%1]" : : "n"(N), "n"(N + 3), "v"(a), "v"(b));
+}
+template <int N> __device__ __forceinline__ f32x4 t4_acc_get() {
+    float x0, x1, x2, x3;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "n"(N), "n"(N + 1), "n"(N + 2), "n"(N + 3));
+    return (f32x4){x0, x1, x2, x3};
+}
+template <int N> __device__ __forceinline__ void t4_acc_set(const f32x4& v) {
+    asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\tv_accvgpr_write_b32 a[%6], %2\n\tv_accvgpr_write_b32 a[%7], %3"
+                 : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(N), "n"(N + 1), "n"(N + 2), "n"(N + 3));
+}
+template <int... I, class F> __device__ __forceinline__ void t4_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+#define T4_SEQ(n) std::make_integer_sequence<int, n>{}
+#define T4_LAZY 8.0f                              // log2 units
+#define T4_STAGE (32 * ROW_B)                    // 32 keys
+#define T4_RING (2 * T4_STAGE)
+#define T4_QOFF (4 * T4_RING)                    // the prompt's 64 folded query rows, dec_t2i's tile format
+#define T4_LDS (T4_QOFF + 64 * ROW_B)            // 160 KB
+// SHARED: the image tokens belong to the crop, not to the prompt (x_div > 1: first pass, layer 0) - re-read from L2 by its prompts, no streaming hint
+// MFMAs on compiler-allocated VGPR accumulators, as asm too: the compiler must not emit an MFMA of its own in this kernel, or it would place
+// that MFMA's result in the AccVGPRs the kernel has taken (seen: the score tiles in a[0:3], a[20:23]).  It cannot see these are MFMAs, so
+// the wait states between them and the VALU that reads their results are the kernel's business (s_nop below).
+#define T4_MFMA_V0(acc, a, b) asm volatile(T4_MFMA_OP " %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
+#define T4_MFMA_V(acc, a, b) asm volatile(T4_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+template <bool STAMPS, bool SHARED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void dec_t2i_w1_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ pek, const bf16_t* __restrict__ Qt,
+                       const float* __restrict__ tq, float qscale, const bf16_t* __restrict__ Wv, const float* __restrict__ bv, bf16_t* __restrict__ out,
+                       unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[4] = {0, 0, 0, 0}, tprev = 0;
+#define T4_STAMP(k) do { if (STAMPS) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.x;
+    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs;
+    constexpr int NKB = 4096 / 128;
+
+    // the query rows -> LDS (512-B rows, 16-byte chunks XOR-swizzled by row & 15)
+    for (int idx = tid; idx < 64 * 32; idx += 256) {
+        const int row = idx >> 5, ch = idx & 31;
+        *reinterpret_cast<u32x4*>(smem + T4_QOFF + row * ROW_B + ((ch ^ (row & 15)) << 4)) = *reinterpret_cast<const u32x4*>(Qt + ((int64_t)p * 64 + row) * DC + ch * 8);
+    }
+    op16x8 pq[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int hsel = fg >> 1;
+        const float* qp = tq + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qt + hsel) + 8 * (fg & 1);
+        const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+        const float z = ((fi >> 3) == hsel) ? qscale : 0.f;
+        pq[qt] = pack8_d(a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z);
+    }
+    float m[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { m[q] = -3.0e38f; l[q] = 0.f; }
+    // the AccVGPR file is taken (see above)
+    asm volatile("" ::: T4_ALL_AGPRS);
+    t4_for(T4_SEQ(64), [&](auto I) { t4_acc_set<decltype(I)::value * 4>((f32x4){0.f, 0.f, 0.f, 0.f}); });
+
+    // LDS-DMA: a stage = 16 pieces of 2 rows; lanes 0..31 fill row 2 i, lanes 32..63 row 2 i + 1; source-side swizzle
+    const int hrow = lane >> 5, lsw = (lane & 31) ^ hrow;         // (2 i + h) & 15 = ((2 i) & 15) ^ h
+    char* ring = smem + wave * T4_RING;
+    auto issue = [&](int kb) {
+        const bf16_t* src = Xp + (int64_t)(kb * 128 + 32 * wave + hrow) * DC;
+        char* dst = ring + (kb & 1) * T4_STAGE;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bf16_t* g = src + (2 * i) * DC + ((lsw ^ ((2 * i) & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_d)g, (lptr_d)(dst + i * 1024), 16, 0, SHARED ? 0 : T2I_X_AUX);
+        }
+    };
+    // PEK fragments of a step: [kt][q tile]: row = key 16 kt + fi, chunk 4 qt + fg.  Requested by asm and awaited by the counted wait at the
+    // top of the step that uses them (tied to that wait through "+v"): as compiler-visible loads their first use got s_waitcnt vmcnt(0) - with
+    // the 16 LDS-DMA pieces of the refill and the next step's PEK loads in flight behind them.
+    auto load_kp = [&](int kb, op16x8 (&kp)[2][4]) {
+        const bf16_t* pr = pek + (int64_t)(kb * 128 + 32 * wave + fi) * 128 + fg * 8;
+        const bf16_t* pr1 = pr + 16 * 128;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\tglobal_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                     : "=&v"(kp[0][0]), "=&v"(kp[0][1]), "=&v"(kp[0][2]), "=&v"(kp[0][3]) : "v"(pr) : "memory");
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\tglobal_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                     : "=&v"(kp[1][0]), "=&v"(kp[1][1]), "=&v"(kp[1][2]), "=&v"(kp[1][3]) : "v"(pr1) : "memory");
+    };
+    const uint32_t ring_a = (uint32_t)(uintptr_t)(lptr_d)ring;
+    const uint32_t q_a = (uint32_t)(uintptr_t)(lptr_d)(smem + T4_QOFF);
+    uint32_t koff[4];                 // fragment (row fi, chunk 4 ks + fg): ks and ks + 4 differ by 256 bytes
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = fi * ROW_B + (((4 * ks + fg) ^ fi) << 4);
+    const int vrow = 4 * fg + (fi >> 2);
+    const uint32_t vbase = vrow * ROW_B + (fi & 1) * 8;
+    const uint32_t vx = (((fi & 3) >> 1) ^ (vrow & 15)) << 4;          // chunk (2 d + vsel) ^ (vrow & 15) = (vsel ^ (vrow & 15)) ^ 2 d
+
+    op16x8 kpa[2][4], kpb[2][4];
+    issue(0); issue(1);
+    load_kp(0, kpa);
+    __syncthreads();                  // the query image
+    if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
+    // AHEAD: another step follows (its PEK rows are requested, its stage is in flight); REFILL: the step after that exists too.  Compile-time so
+    // that the number of vector-memory operations in flight is the same on every path (the compiler's own waits for the PEK registers
+    // become vmcnt(0) otherwise).
+    auto step = [&](int kb, op16x8 (&kp)[2][4], op16x8 (&kpn)[2][4], auto AHEAD_, auto REFILL_) {
+        constexpr bool AHEAD = decltype(AHEAD_)::value, REFILL = decltype(REFILL_)::value;
+        if constexpr (AHEAD) load_kp(kb + 1, kpn);
+        // this step's stage has landed: behind it in the queue are the next stage's 16 pieces and the 8 PEK loads just requested
+#define T4_KP_TIED "+v"(kp[0][0]), "+v"(kp[0][1]), "+v"(kp[0][2]), "+v"(kp[0][3]), "+v"(kp[1][0]), "+v"(kp[1][1]), "+v"(kp[1][2]), "+v"(kp[1][3])
+        if constexpr (AHEAD) asm volatile("s_waitcnt vmcnt(24)" : T4_KP_TIED : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : T4_KP_TIED : : "memory");
+#undef T4_KP_TIED
+        const uint32_t xs = ring_a + (kb & 1) * T4_STAGE;
+        // ---- scores: s[q][kt] = PEK part + sum over 8 k-steps; fragments of k-step ks + 1 are requested before the MFMAs of ks
+        f32x4 s[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) T4_MFMA_V0(s[q][kt], kp[kt][q], pq[q]);
+        op16x8 fr[2][6];              // [buffer][K kt 0, K kt 1, Q 0..3]
+        auto request = [&](int ks, op16x8 (&f)[6]) {
+            const uint32_t ka = xs + koff[ks & 3] + (ks >> 2) * 256, qa = q_a + koff[ks & 3] + (ks >> 2) * 256;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192" : "=&v"(f[0]), "=&v"(f[1]) : "v"(ka) : "memory");
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:8192\n\tds_read_b128 %2, %4 offset:16384\n\tds_read_b128 %3, %4 offset:24576"
+                         : "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(qa) : "memory");
+        };
+        request(0, fr[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            op16x8 (&f)[6] = fr[ks & 1];
+            if (ks + 1 < 8) {
+                request(ks + 1, fr[(ks + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                T4_MFMA_V(s[q][0], f[0], f[2 + q]);
+                T4_MFMA_V(s[q][1], f[1], f[2 + q]);
+            }
+        }
+        T4_STAMP(0);
+        // ---- value fragments of the first group are requested before the softmax arithmetic
+        u32x2_d vl[2][4], vh[2][4];
+        auto request_v = [&](int d4, u32x2_d (&lo)[4], u32x2_d (&hi)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t va = xs + vbase + (vx ^ ((2 * (d4 + j)) << 4));
+                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:8192" : "=&v"(lo[j]), "=&v"(hi[j]) : "v"(va) : "memory");
+            }
+        };
+        request_v(0, vl[0], vh[0]);
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // the last score MFMAs -> the VALU that reads them
+        op16x8 pf[4];
+        t4_for(T4_SEQ(4), [&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            float mx = fmaxf(fmaxf(fmaxf(s[q][0][0], s[q][0][1]), fmaxf(s[q][0][2], s[q][0][3])), fmaxf(fmaxf(s[q][1][0], s[q][1][1]), fmaxf(s[q][1][2], s[q][1][3])));
+            mx = xor32_max(xor16_max(mx));
+            // The partial sums are rescaled only when a row's maximum has grown by more than 2^T4_LAZY since its reference m was set (the
+            // rescale is 64 AccVGPR reads, multiplies and writes per query tile here; with a test per step it ran in ~60 % of the steps on
+            // random data and was half of the kernel's time - stamped).  Until then the weights are exp2(s - m) <= 2^T4_LAZY: exact
+            // arithmetic all the same (the reference cancels in O / l), and far inside the 16-bit operand's and fp32's range.
+            if (__any(mx > m[q] + T4_LAZY)) {
+                const float mn = fmaxf(m[q], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m[q] - mn);
+                m[q] = mn;
+                l[q] *= alpha;
+                t4_for(T4_SEQ(16), [&](auto D) {
+                    constexpr int n = T4_ACC(q, decltype(D)::value);
+                    const f32x4 v = t4_acc_get<n>();
+                    t4_acc_set<n>(v * alpha);
+                });
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[q][kt][r] - m[q]);
+                    s[q][kt][r] = e;
+                    sum += e;
+                }
+            sum = xor32_sum(xor16_sum(sum));
+            l[q] += sum;
+            pf[q] = pack8_d(s[q][0][0], s[q][0][1], s[q][0][2], s[q][0][3], s[q][1][0], s[q][1][1], s[q][1][2], s[q][1][3]);
+        });
+        T4_STAMP(1);
+        // ---- O += V^T P: 4 groups of 4 channel tiles, each value fragment feeds the four query tiles
+        asm volatile("s_nop 3" ::: "memory");          // (v_accvgpr_write of a rescale -> MFMA SrcC)
+        t4_for(T4_SEQ(4), [&](auto G) {
+            constexpr int g = decltype(G)::value;
+            u32x2_d (&lo)[4] = vl[g & 1];
+            u32x2_d (&hi)[4] = vh[g & 1];
+            if constexpr (g + 1 < 4) {
+                request_v(4 * (g + 1), vl[(g + 1) & 1], vh[(g + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+            }
+            t4_for(T4_SEQ(4), [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const op16x8 vfr = cat4_d(__builtin_bit_cast(op16x4, lo[j]), __builtin_bit_cast(op16x4, hi[j]));
+                t4_acc_mfma<T4_ACC(0, 4 * g + j)>(vfr, pf[0]);
+                t4_acc_mfma<T4_ACC(1, 4 * g + j)>(vfr, pf[1]);
+                t4_acc_mfma<T4_ACC(2, 4 * g + j)>(vfr, pf[2]);
+                t4_acc_mfma<T4_ACC(3, 4 * g + j)>(vfr, pf[3]);
+            });
+        });
+        T4_STAMP(2);
+        // every read of this stage has returned (the last wait above): refill it
+        if constexpr (REFILL) issue(kb + 2);
+        T4_STAMP(3);
+    };
+    // two steps per trip: the PEK registers alternate between two sets (a copy would make the compiler wait for everything in flight)
+    for (int kb = 0; kb < NKB - 2; kb += 2) {
+        step(kb, kpa, kpb, std::true_type{}, std::true_type{});
+        step(kb + 1, kpb, kpa, std::true_type{}, std::true_type{});
+    }
+    step(NKB - 2, kpa, kpb, std::true_type{}, std::false_type{});
+    step(NKB - 1, kpb, kpa, std::false_type{}, std::false_type{});
+    if (STAMPS && stamps && lane == 0)
+        for (int k = 0; k < 4; ++k) stamps[((int64_t)blockIdx.x * 4 + wave) * 4 + k] = ts[k];
+
+    // ---- merge the four key quarters pairwise through the LDS (two regions of [64 q][260] floats), then v_proj per query tile
+    float* reg0 = reinterpret_cast<float*>(smem);
+    float* reg1 = reg0 + 64 * 260;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results -> v_accvgpr_read
+    auto park = [&](float* r, auto Q) {
+        constexpr int q = decltype(Q)::value;
+        t4_for(T4_SEQ(16), [&](auto D) {
+            constexpr int dt = decltype(D)::value;
+            const f32x4 v = t4_acc_get<T4_ACC(q, dt)>();
+            *reinterpret_cast<float4*>(r + (16 * q + fi) * 260 + 16 * dt + 4 * fg) = make_float4(v[0], v[1], v[2], v[3]);
+        });
+        if (fg == 0) { r[(16 * q + fi) * 260 + 256] = m[q]; r[(16 * q + fi) * 260 + 257] = l[q]; }
+    };
+    auto merge = [&](const float* r, auto Q) {
+        constexpr int q = decltype(Q)::value;
+        const float m2 = r[(16 * q + fi) * 260 + 256], l2 = r[(16 * q + fi) * 260 + 257];
+        const float mn = fmaxf(m[q], m2);
+        const float a1 = exp2f(m[q] - mn), a2 = exp2f(m2 - mn);
+        t4_for(T4_SEQ(16), [&](auto D) {
+            constexpr int dt = decltype(D)::value;
+            const float4 t = *reinterpret_cast<const float4*>(r + (16 * q + fi) * 260 + 16 * dt + 4 * fg);
+            const f32x4 v = t4_acc_get<T4_ACC(q, dt)>();
+            t4_acc_set<T4_ACC(q, dt)>((f32x4){v[0] * a1 + t.x * a2, v[1] * a1 + t.y * a2, v[2] * a1 + t.z * a2, v[3] * a1 + t.w * a2});
+        });
+        m[q] = mn;
+        l[q] = l[q] * a1 + l2 * a2;
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>; using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    __syncthreads();                          // every wave has left its ring
+    if (wave & 1) { float* r = (wave >> 1) ? reg1 : reg0; park(r, Q0{}); park(r, Q1{}); park(r, Q2{}); park(r, Q3{}); }
+    __syncthreads();
+    if (!(wave & 1)) { const float* r = (wave >> 1) ? reg1 : reg0; merge(r, Q0{}); merge(r, Q1{}); merge(r, Q2{}); merge(r, Q3{}); }
+    __syncthreads();
+    // waves 0 and 2 hold the two halves: wave 0 keeps query tiles 0, 1 and hands 2, 3 over; wave 2 the other way round (region 0)
+    if (wave == 0) { park(reg0, Q2{}); park(reg0, Q3{}); }
+    if (wave == 2) { park(reg0, Q0{}); park(reg0, Q1{}); }
+    __syncthreads();
+    if (wave == 0) { merge(reg0, Q0{}); merge(reg0, Q1{}); }
+    if (wave == 2) { merge(reg0, Q2{}); merge(reg0, Q3{}); }
+    // normalised rows -> region 1
+    t4_for(T4_SEQ(4), [&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        if (wave == 2 * (q >> 1)) {
+            const float inv = __builtin_amdgcn_rcpf(l[q]);
+            t4_for(T4_SEQ(16), [&](auto D) {
+                constexpr int dt = decltype(D)::value;
+                const f32x4 v = t4_acc_get<T4_ACC(q, dt)>();
+                *reinterpret_cast<float4*>(reg1 + (16 * q + fi) * 260 + 16 * dt + 4 * fg) = make_float4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+            });
+        }
+    });
+    __syncthreads();
+    {   // dec_t2i_kernel's v_proj tail, query tile = wave
+        const int qt = wave;
+        const float* mo = reg1 + (size_t)qt * 16 * 260;
+        f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 z0 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg), z1 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg + 4);
+            const op16x8 zf = pack8_d(z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w);
+            const op16x8 w0 = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + fi) * DC + 32 * ks + 8 * fg));
+            const op16x8 w1 = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(Wv + (int64_t)(32 * qt + 16 + fi) * DC + 32 * ks + 8 * fg));
+            T4_MFMA_V(r0, w0, zf);
+            T4_MFMA_V(r1, w1, zf);
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(r0), "+v"(r1));
+        const int hsel = fi >> 3, hh = 2 * qt + hsel, t = fi & 7;
+        const float4 b4 = *reinterpret_cast<const float4*>(bv + 16 * hh + 4 * fg);
+        const f32x4 r = hsel ? r1 : r0;
+        *reinterpret_cast<uint2*>(out + (int64_t)p * 1024 + t * 128 + 16 * hh + 4 * fg) =
+            make_uint2(pack_op16(r[0] + b4.x, r[1] + b4.y), pack_op16(r[2] + b4.z, r[3] + b4.w));
+    }
+#undef T4_STAMP
+}
+
 const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, float* Opart, float* ML,
                            int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s, const XBuild* build) {
     if (P <= 0) return nullptr;
@@ -494,6 +814,11 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
         if (!build->embb || !build->h2 || !build->w3 || build->map.div <= 0) return "dec_t2i: incomplete XBuild";
         hipLaunchKernelGGL((dec_t2i_kernel<8, false, true>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, (const bf16_t*)nullptr, build->map.stride, build->map.div, build->map.off,
                            pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, (unsigned long long*)nullptr, build->embb, build->h2, build->w3);
+    } else if (split == 1 && ((g_saber_debug_flags & 0x200) || getenv("SABER_AMD_T2I_W1") != nullptr)) {      // opt-in (round 5): one wave per SIMD, four query tiles per wave
+#define T4_LAUNCH(ST, SH) hipLaunchKernelGGL((dec_t2i_w1_kernel<ST, SH>), dim3(P), dim3(256), T4_LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Wv, bv, out, g_saber_stamp_buf)
+        if (g_saber_stamp_buf) { if (xm.div > 1) T4_LAUNCH(true, true); else T4_LAUNCH(true, false); }
+        else { if (xm.div > 1) T4_LAUNCH(false, true); else T4_LAUNCH(false, false); }
+#undef T4_LAUNCH
     } else if (!(g_saber_debug_flags & 4)) {  // 4-wave workgroups (two per CU, no key-half merge) measure the same as one 8-wave workgroup: kept as an option
         if (g_saber_stamp_buf)
             hipLaunchKernelGGL((dec_t2i_kernel<8, true, false>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, g_saber_stamp_buf, nf, nb, nf);
@@ -834,6 +1159,367 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
             hipLaunchKernelGGL((dec_i2t_kernel<1, true, false>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
         else
             hipLaunchKernelGGL((dec_i2t_kernel<1, false, false>), dim3(P * nsplit), dim3(256), I2TCfg<1>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
+    return nullptr;
+}
+
+
+// ------------------------------------------------------------------------------------------------ image -> tokens of layer l FUSED with the
+// tokens -> image attention that follows it (round 5; VERDICT r01-r04 "i2t + next-t2i")
+// X' = LN(X + softmax((X + pe).Kt).Vt + b_o) is written to HBM as before, and every pair of finished 16-row tiles is at once the next
+// attention's key / value block: the 2 MB of X' per prompt are NOT read back by a separate dec_t2i launch.  The queries of that
+// attention depend on the tokens only (dec_tokens_kernel has produced fold_q / tq before this kernel runs).
+// Structure: dec_i2t_kernel<1>'s tile loop unchanged (4 waves = the four 16-column quarters of the score matrix, one barrier per tile),
+// plus, per wave, ONE 16-row query tile of the next attention (wave = q tile): finish_tile also drops the normalised rows into `xbuf`
+// (dec_t2i's tile format: 512-B rows, 16-byte chunks XOR-swizzled by row & 15), four tiles deep, and every second iteration the wave
+// runs dec_t2i's block step on the 32 keys of the pair finished two iterations earlier (18 + 16 MFMAs, online softmax).  The PEK rows of
+// a pair come global -> LDS directly, two wave-instructions per wave and pair, two stages.
+// Registers: dec_i2t's ~200 + 32 (Q fragments) + 64 (partial sums) + ~16: ONE workgroup of four waves per CU (one wave per SIMD) - the
+// price of the fusion, see DESIGN.md section 8.2.
+#define FZ_XBUF (4 * 16 * ROW_B)                 // 32 KB: four X' tiles
+#define FZ_PEK_STAGE (32 * T2I_PEK_ROWB)         // 8 KB: the PEK rows of one pair of tiles
+struct I2TFuse {
+    const bf16_t* pek; const bf16_t* Qt; const float* tq; float qscale; const bf16_t* Wv; const float* bv; bf16_t* out;
+};
+template <bool STAMPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void dec_i2t_t2i_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
+                        const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
+                        const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                        bf16_t* __restrict__ Xout, I2TFuse f, unsigned long long* __restrict__ stamps) {
+    using CF = I2TCfg<1>;
+    constexpr int I2T_ROWS = CF::ROWS, I2T_STAGE = CF::STAGE, I2T_PBUF_B = CF::PBUF_B, I2T_STAT_B = CF::STAT_B;
+    constexpr int NT = 4096 / I2T_ROWS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[4] = {0, 0, 0, 0}, tprev = 0;
+#define FZ_STAMP(k) do { if (STAMPS) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); ts[k] += _n - tprev; tprev = _n; } } while (0)
+    char* pbuf = smem + I2T_NSTAGE * I2T_STAGE;
+    float* stat = reinterpret_cast<float*>(pbuf + 2 * I2T_PBUF_B);
+    char* xbuf = smem + CF::LDS;
+    char* pkbuf = xbuf + FZ_XBUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = wave;                  // i2t: score quarter;  t2i: query tile
+    const int fi = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.x;
+    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs;
+    bf16_t* Xo = Xout + (int64_t)p * 4096 * DC;
+
+    // ---- i2t operands (dec_i2t_kernel)
+    op16x8 kf[8], vf[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        kf[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(Kt + ((int64_t)p * 64 + 16 * qr + fi) * DC + 32 * ks + 8 * fg));
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            vf[t][ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(VtT + ((int64_t)p * 256 + 64 * qr + 16 * t + fi) * 64 + 32 * ks + 8 * fg));
+    op16x8 kq;
+    {
+        const int hsel = fg >> 1;
+        const float* kp = tk + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qr + hsel) + 8 * (fg & 1);
+        const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
+        const float z = ((fi >> 3) == hsel) ? kscale : 0.f;
+        kq = pack8_d(a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z);
+    }
+    const float4 cb4 = *reinterpret_cast<const float4*>(cb + (int64_t)p * 64 + 16 * qr + 4 * fg);
+    f32x2 g2[8], be2[8], bo2[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bo + 64 * qr + 16 * t + 4 * fg);
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + 64 * qr + 16 * t + 4 * fg);
+        const float4 e4 = *reinterpret_cast<const float4*>(beta + 64 * qr + 16 * t + 4 * fg);
+        g2[2 * t] = (f32x2){g4.x, g4.y}; g2[2 * t + 1] = (f32x2){g4.z, g4.w};
+        be2[2 * t] = (f32x2){e4.x, e4.y}; be2[2 * t + 1] = (f32x2){e4.z, e4.w};
+        bo2[2 * t] = (f32x2){b4.x, b4.y}; bo2[2 * t + 1] = (f32x2){b4.z, b4.w};
+    }
+    // ---- t2i operands of this wave's query tile (dec_t2i_kernel, qt = wave)
+    op16x8 qf[8], pq;
+    {
+        const bf16_t* qrow = f.Qt + ((int64_t)p * 64 + qr * 16 + fi) * DC;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(qrow + 32 * ks + 8 * fg));
+        const int hsel = fg >> 1;
+        const float* qp = f.tq + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * qr + hsel) + 8 * (fg & 1);
+        const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+        const float z = ((fi >> 3) == hsel) ? f.qscale : 0.f;
+        pq = pack8_d(a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z);
+    }
+    float m = -3.0e38f, l = 0.f;
+    f32x4 o[16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- LDS-DMA: per tile 2 X pieces + 1 PEQ piece per wave (dec_i2t_kernel), per PAIR of tiles 2 PEK pieces per wave
+    int srow[2], schunk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        srow[i] = 2 * (wave * 2 + i) + (lane >> 5);
+        schunk[i] = (lane & 31) ^ (srow[i] & 15);
+    }
+    const int prow = 4 * wave + (lane >> 4), pchunk = (lane & 15) ^ (prow & 15);
+    auto issue = [&](int t) {
+        char* sx = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t off = (int64_t)(t * I2T_ROWS + srow[i]) * DC + schunk[i] * 8;
+            if (x_div > 1) __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 2 + i) * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_d)(Xp + off), (lptr_d)(sx + (wave * 2 + i) * 1024), 16, 0, I2T_X_AUX);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_d)(peq + (int64_t)(t * I2T_ROWS + prow) * 128 + pchunk * 8), (lptr_d)(sx + I2T_ROWS * ROW_B + wave * 1024), 16, 0, 0);
+    };
+    int krow[2], kchunk[2];          // PEK: 32 rows x 256 B = 8 pieces of 4 rows; wave w issues pieces 2w, 2w + 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        krow[i] = 4 * (wave * 2 + i) + (lane >> 4);
+        kchunk[i] = (lane & 15) ^ (krow[i] & 15);
+    }
+    auto issue_pek = [&](int pair) {             // the PEK rows of tiles 2 pair, 2 pair + 1
+        char* sk = pkbuf + (pair & 1) * FZ_PEK_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_d)(f.pek + (int64_t)(pair * 32 + krow[i]) * 128 + kchunk[i] * 8), (lptr_d)(sk + (wave * 2 + i) * 1024), 16, 0, 0);
+    };
+    const int poff = fi * I2T_PEQ_ROWB + (((4 * qr + fg) ^ fi) << 4);
+    int xoff[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xoff[ks] = fi * ROW_B + (((4 * ks + fg) ^ fi) << 4);
+    int roff[4];      // this lane's 8-byte pieces of row fi: channels 64 qr + 16 t + 4 fg .. + 3, in the swizzled tile format
+#pragma unroll
+    for (int t = 0; t < 4; ++t) roff[t] = fi * ROW_B + (((8 * qr + 2 * t + (fg >> 1)) ^ fi) << 4) + (fg & 1) * 8;
+    const uint32_t prow_a = (uint32_t)(uintptr_t)(lptr_d)(pbuf + fi * I2T_PSTRIDE);
+    const uint32_t stat_a = (uint32_t)(uintptr_t)(lptr_d)(stat + (fi * 4) * 2);
+    const uint32_t smem_a = (uint32_t)(uintptr_t)(lptr_d)smem;
+    const uint32_t oscr_a = smem_a + I2T_NSTAGE * I2T_STAGE + 2 * I2T_PBUF_B + 2 * I2T_STAT_B + wave * 2048;
+    const uint32_t xbuf_a = (uint32_t)(uintptr_t)(lptr_d)xbuf;
+    f32x2 y2[8];
+    auto finish_tile = [&](int tp) {
+        f32x4 a, b;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(stat_a + (tp & 1) * I2T_STAT_B) : "memory");
+        const float tot = (a.x + a.z) + (b.x + b.z), tsq = (a.y + a.w) + (b.y + b.w);
+        const float mean = tot * (1.0f / DC);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(tsq * (1.0f / DC) - mean * mean, 0.f) + eps);
+        const f32x2 mean2 = (f32x2){mean, mean}, rstd2 = (f32x2){rstd, rstd};
+        const uint32_t tb = oscr_a + fi * 128 + (fg & 1) * 8;
+        const uint32_t xb = xbuf_a + (tp & 3) * (16 * ROW_B);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const f32x2 v0 = ((y2[2 * tt] - mean2) * rstd2) * g2[2 * tt] + be2[2 * tt];
+            const f32x2 v1 = ((y2[2 * tt + 1] - mean2) * rstd2) * g2[2 * tt + 1] + be2[2 * tt + 1];
+            const uint32_t lo = pack_op16(v0.x, v0.y), hi = pack_op16(v1.x, v1.y);
+            lds_write_b64(tb + (((2 * tt + (fg >> 1)) ^ (fi & 7)) << 4), lo, hi);
+            lds_write_b64(xb + roff[tt], lo, hi);            // the next attention's key / value tile
+        }
+        u32x4 o0, o1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(o0), "=&v"(o1) : "v"(oscr_a + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4)) : "memory");
+        bf16_t* orow = Xo + (int64_t)(tp * I2T_ROWS + (lane >> 3)) * DC + 64 * qr + 8 * (lane & 7);
+        __builtin_nontemporal_store(o0, reinterpret_cast<u32x4*>(orow));
+        __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(orow + 8 * DC));
+    };
+    // dec_t2i_kernel's block step on the 32 keys of tiles 2 pair, 2 pair + 1 (this wave's 16 query rows)
+    int koff[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = fi * ROW_B + (((4 * ks + fg) ^ fi) << 4);
+    const int vrow = 4 * fg + (fi >> 2);
+    const int vsel = (fi & 3) >> 1, vlow = (fi & 1) * 8;
+    auto t2i_step = [&](int pair) {
+        const uint32_t xs = xbuf_a + (pair & 1) * (32 * ROW_B);
+        const uint32_t ps = (uint32_t)(uintptr_t)(lptr_d)pkbuf + (pair & 1) * FZ_PEK_STAGE;
+        f32x4 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            op16x8 kp, kx[8];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kp) : "v"(ps + (kt * 16 + fi) * T2I_PEK_ROWB + (((4 * qr + fg) ^ fi) << 4)) : "memory");
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(kx[ks]) : "v"(xs + kt * 16 * ROW_B + koff[ks]) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kp), "+v"(kx[0]), "+v"(kx[1]), "+v"(kx[2]), "+v"(kx[3]), "+v"(kx[4]), "+v"(kx[5]), "+v"(kx[6]), "+v"(kx[7]));
+            s[kt] = MFMA_16x16x32(kp, pq, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) s[kt] = MFMA_16x16x32(kx[ks], qf[ks], s[kt], 0, 0, 0);
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mx = xor32_max(xor16_max(mx));
+        if (__any(mx > m)) {
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum = xor32_sum(xor16_sum(sum));
+        l += sum;
+        const op16x8 pf = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
+        const uint32_t va = xs + vrow * ROW_B + vlow;
+#pragma unroll
+        for (int d4 = 0; d4 < 16; d4 += 4) {
+            u32x2_d lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sw = ((2 * (d4 + j) + vsel) ^ (vrow & 15)) << 4;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[j]) : "v"(va + sw) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(hi[j]) : "v"(va + sw) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const op16x8 vfr = cat4_d(__builtin_bit_cast(op16x4, lo[j]), __builtin_bit_cast(op16x4, hi[j]));
+                o[d4 + j] = MFMA_16x16x32(vfr, pf, o[d4 + j], 0, 0, 0);
+            }
+        }
+    };
+
+    issue(0); issue(1); issue(2);
+    issue_pek(0);
+    // queue of this wave: L(0) L(1) L(2) K(0); tile 0 must have landed
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < NT; ++t) {
+        const char* xs = smem + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+        const char* ps = xs + I2T_ROWS * ROW_B;
+        f32x4 s = (f32x4){cb4.x, cb4.y, cb4.z, cb4.w}, s1;
+        {
+            const op16x8 pf = *reinterpret_cast<const op16x8*>(ps + poff);
+            s1 = MFMA_16x16x32(kq, pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+            const op16x8 xf0 = *reinterpret_cast<const op16x8*>(xs + xoff[ks]);
+            const op16x8 xf1 = *reinterpret_cast<const op16x8*>(xs + xoff[ks + 1]);
+            s = MFMA_16x16x32(kf[ks], xf0, s, 0, 0, 0);
+            s1 = MFMA_16x16x32(kf[ks + 1], xf1, s1, 0, 0, 0);
+        }
+        s += s1;
+        {
+            float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            mx = xor16_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mx); sum += s[r]; }
+            sum = xor16_sum(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            lds_write_b64(prow_a + (t & 1) * I2T_PBUF_B + (16 * qr + 4 * fg) * 2, pack_op16(s[0] * inv, s[1] * inv), pack_op16(s[2] * inv, s[3] * inv));
+        }
+        FZ_STAMP(0);
+        // Tile t + 1 must have landed before the barrier publishes it.  After its barrier iteration i issues L(i + 3) [3 operations],
+        // S(i - 1) [2 stores] and, when i is even and >= 2, K(i / 2) [2] - the PEK rows of the pair that is consumed in iteration i + 3, into
+        // the stage that the step of iteration i - 1 has read (every wave is past that step: this iteration's barrier).  Behind L(t + 1) in
+        // this wave's queue: S(t - 3), L(t + 2), S(t - 2) and exactly one K: 9 operations may stay in flight.  The PEK rows an odd
+        // iteration consumes were issued BEFORE L(t + 1) (iteration t - 3), so the same wait covers them.
+        if (t + 3 >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (t < 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");            // t = 0: L(2) K(0);  t = 1: K(0) L(3);  t = 2: L(4) S(0)
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FZ_STAMP(1);
+        if (t + 3 < NT) issue(t + 3);
+        if (t > 0) finish_tile(t - 1);
+        // the pair (t - 3, t - 2): both tiles were dropped into xbuf before this iteration's barrier
+        if ((t & 1) && t >= 3) t2i_step((t - 3) >> 1);
+        else if (!(t & 1) && t >= 2) issue_pek(t >> 1);
+        FZ_STAMP(2);
+        f32x4 y[4];
+        {
+            op16x8 p0, p1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(p0), "=&v"(p1) : "v"(prow_a + (t & 1) * I2T_PBUF_B + 16 * fg) : "memory");
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                y[tt] = MFMA_16x16x32(vf[tt][0], p0, y[tt], 0, 0, 0);
+                y[tt] = MFMA_16x16x32(vf[tt][1], p1, y[tt], 0, 0, 0);
+            }
+        }
+        uint64_t xr0, xr1, xr2, xr3;
+        {
+            const uint32_t xa = smem_a + (t & (I2T_NSTAGE - 1)) * I2T_STAGE;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(xr0), "=&v"(xr1), "=&v"(xr2), "=&v"(xr3)
+                         : "v"(xa + roff[0]), "v"(xa + roff[1]), "v"(xa + roff[2]), "v"(xa + roff[3])
+                         : "memory");
+        }
+        const uint64_t xrs[4] = {xr0, xr1, xr2, xr3};
+        f32x2 sum2 = (f32x2){0.f, 0.f}, sq2 = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const uint32_t xlo = (uint32_t)xrs[tt], xhi = (uint32_t)(xrs[tt] >> 32);
+            const f32x2 r0 = (f32x2){op16_lo(xlo), op16_hi(xlo)};
+            const f32x2 r1 = (f32x2){op16_lo(xhi), op16_hi(xhi)};
+            y2[2 * tt] = ((f32x2){y[tt][0], y[tt][1]} + bo2[2 * tt]) + r0;
+            y2[2 * tt + 1] = ((f32x2){y[tt][2], y[tt][3]} + bo2[2 * tt + 1]) + r1;
+            sum2 += y2[2 * tt]; sum2 += y2[2 * tt + 1];
+            sq2 = __builtin_elementwise_fma(y2[2 * tt], y2[2 * tt], sq2);
+            sq2 = __builtin_elementwise_fma(y2[2 * tt + 1], y2[2 * tt + 1], sq2);
+        }
+        float sum = sum2.x + sum2.y, sq = sq2.x + sq2.y;
+        sum = xor16_sum(sum); sq = xor16_sum(sq);
+        sum = xor32_sum(sum); sq = xor32_sum(sq);
+        if (fg == 0) lds_write_b64(stat_a + (t & 1) * I2T_STAT_B + qr * 8, __float_as_uint(sum), __float_as_uint(sq));
+        FZ_STAMP(3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    finish_tile(NT - 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the loop's last step (t = NT - 1) took the pair (NT - 4, NT - 3); the last pair is left
+    t2i_step(NT / 2 - 1);
+    if (STAMPS && stamps && lane == 0)
+        for (int k = 0; k < 4; ++k) stamps[((int64_t)blockIdx.x * 4 + wave) * 4 + k] = ts[k];
+    // ---- normalise and apply v_proj (dec_t2i_kernel's tail for a whole key range in one workgroup): out[p][t][16 h + i]
+    __syncthreads();
+    float* mo = reinterpret_cast<float*>(smem) + (size_t)qr * 16 * 260;
+    {
+        const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+            *reinterpret_cast<float4*>(mo + fi * 260 + 16 * dt + 4 * fg) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 z0 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg), z1 = *reinterpret_cast<const float4*>(mo + fi * 260 + 32 * ks + 8 * fg + 4);
+            const op16x8 zf = pack8_d(z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w);
+            const op16x8 w0 = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(f.Wv + (int64_t)(32 * qr + fi) * DC + 32 * ks + 8 * fg));
+            const op16x8 w1 = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(f.Wv + (int64_t)(32 * qr + 16 + fi) * DC + 32 * ks + 8 * fg));
+            r0 = MFMA_16x16x32(w0, zf, r0, 0, 0, 0);
+            r1 = MFMA_16x16x32(w1, zf, r1, 0, 0, 0);
+        }
+        const int hsel = fi >> 3, hh = 2 * qr + hsel, tt = fi & 7;
+        const float4 b4 = *reinterpret_cast<const float4*>(f.bv + 16 * hh + 4 * fg);
+        const f32x4 r = hsel ? r1 : r0;
+        *reinterpret_cast<uint2*>(f.out + (int64_t)p * 1024 + tt * 128 + 16 * hh + 4 * fg) =
+            make_uint2(pack_op16(r[0] + b4.x, r[1] + b4.y), pack_op16(r[2] + b4.z, r[3] + b4.w));
+    }
+#undef FZ_STAMP
+}
+
+const char* launch_dec_i2t_t2i(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* VtT,
+                               const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P,
+                               const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s) {
+    if (P <= 0) return nullptr;
+    if (xm.div <= 0) return "dec_i2t_t2i: XMap.div must be positive";
+    const I2TFuse f{pek, Qt, tq, qscale, Wv, bv, out};
+    constexpr int lds = I2TCfg<1>::LDS + FZ_XBUF + 2 * FZ_PEK_STAGE;
+    static_assert(lds >= 4 * 16 * 260 * 4, "the v_proj tail re-uses the front of the LDS");
+    if (g_saber_stamp_buf)
+        hipLaunchKernelGGL((dec_i2t_t2i_kernel<true>), dim3(P), dim3(256), lds, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, f, g_saber_stamp_buf);
+    else
+        hipLaunchKernelGGL((dec_i2t_t2i_kernel<false>), dim3(P), dim3(256), lds, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, f, (unsigned long long*)nullptr);
     return nullptr;
 }
 
@@ -1226,5 +1912,11 @@ const char* decoder_fused_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS + I2TCfg<1>::W3_B);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_t2i_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS + FZ_XBUF + 2 * FZ_PEK_STAGE);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_t2i_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS + FZ_XBUF + 2 * FZ_PEK_STAGE);
     return st == hipSuccess ? nullptr : hipGetErrorString(st);
 }

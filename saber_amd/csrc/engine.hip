@@ -1294,6 +1294,18 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
             X = e->keys_bf; xm = per_prompt; build = nullptr;
             return SABER_OK;
         };
+        // Opt-in (round 5, SABER_AMD_FUSE_I2T_T2I=1, read per call): image -> tokens of a layer and the tokens -> image attention that follows
+        // it in ONE kernel (dec_i2t_t2i_kernel: X' is the next attention's key / value block while it is still in LDS).  Same results as the
+        // two launches up to the order of the online softmax; measured slower (one wave per SIMD): DESIGN.md section 8.2.
+        const bool fuse = getenv("SABER_AMD_FUSE_I2T_T2I") != nullptr && P >= 128;
+        auto run_i2t_t2i = [&](const DecLayerW& w, const AttnW& a) -> int {
+            if (!fuse || build != nullptr) { TRY(run_i2t(w)); return run_t2i(a); }
+            ENG_KP(e, PC_DEC_I2T, 8.0 * 64 * 4096.0 * 256 * P, (double)P * 4096 * 256 * 4,
+                   launch_dec_i2t_t2i(X, xm, w.i2t.pe_proj, e->fold_k, e->tk, kScale, e->fold_cb, e->fold_v, w.i2t.o.b, w.n4.g, w.n4.b, 1e-5f, e->keys_bf, P,
+                                      a.pe_proj, e->fold_q, e->tq, kScale, a.v.w, a.v.b, e->t_att, s));
+            X = e->keys_bf; xm = per_prompt; build = nullptr;
+            return SABER_OK;
+        };
         {   // S0: self attention of layer 0, operands of its tokens -> image attention
             TokSeg g = base(); with_self(g, e->dl[0], 1); with_t2i(g, e->dl[0].t2i);
             ENG_KP(e, PC_DEC_ATTN, tflops * (4 * 256 + 128 + 128), 0.0, launch_dec_tokens(g, s));
@@ -1303,14 +1315,12 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
             TokSeg g = base(); with_att_out(g, e->dl[0].t2i, e->dl[0].n2); with_mlp_i2t(g, e->dl[0]); with_self(g, e->dl[1], 0); with_t2i(g, e->dl[1].t2i);
             ENG_KP(e, PC_DEC_ATTN, tflops * (128 + 4096 + 4 * 128 + 4 * 256 + 256), 0.0, launch_dec_tokens(g, s));
         }
-        TRY(run_i2t(e->dl[0]));
-        TRY(run_t2i(e->dl[1].t2i));
+        TRY(run_i2t_t2i(e->dl[0], e->dl[1].t2i));
         {   // S2: rest of layer 1, operands of the final tokens -> image attention
             TokSeg g = base(); with_att_out(g, e->dl[1].t2i, e->dl[1].n2); with_mlp_i2t(g, e->dl[1]); with_t2i(g, e->final_attn);
             ENG_KP(e, PC_DEC_ATTN, tflops * (128 + 4096 + 4 * 128 + 256), 0.0, launch_dec_tokens(g, s));
         }
-        TRY(run_i2t(e->dl[1]));
-        TRY(run_t2i(e->final_attn));
+        TRY(run_i2t_t2i(e->dl[1], e->final_attn));
         {   // S3: final output projection + LayerNorm, IoU / object-score / hypernetwork heads
             TokSeg g = base(); with_att_out(g, e->final_attn, e->final_ln);
             g.do_heads = 1;

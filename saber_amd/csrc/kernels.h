@@ -184,7 +184,7 @@ SABER_OP_FWD(launch_gemm) SABER_OP_FWD(gemm_rowln_supported) SABER_OP_FWD(launch
 SABER_OP_FWD(launch_layernorm) SABER_OP_FWD(launch_gather_rows) SABER_OP_FWD(launch_add_to_bf16) SABER_OP_FWD(launch_hiera_attention)
 SABER_OP_FWD(launch_prompt_tokens) SABER_OP_FWD(launch_prompt_tokens_multi) SABER_OP_FWD(launch_mask_embed_src) SABER_OP_FWD(launch_mask_hidden) SABER_OP_FWD(launch_embb_tiles)
 SABER_OP_FWD(launch_dec_attention) SABER_OP_FWD(launch_mask_dot) SABER_OP_FWD(launch_mask_pick) SABER_OP_FWD(launch_iou_live_flags) SABER_OP_FWD(launch_mask_select)
-SABER_OP_FWD(launch_dec_fold) SABER_OP_FWD(launch_dec_t2i) SABER_OP_FWD(launch_dec_i2t) SABER_OP_FWD(launch_dec_upscale) SABER_OP_FWD(launch_dec_tokens)
+SABER_OP_FWD(launch_dec_fold) SABER_OP_FWD(launch_dec_t2i) SABER_OP_FWD(launch_dec_i2t) SABER_OP_FWD(launch_dec_i2t_t2i) SABER_OP_FWD(launch_dec_upscale) SABER_OP_FWD(launch_dec_tokens)
 SABER_OP_FWD(launch_mask_post) SABER_OP_FWD(launch_gather_masks) SABER_OP_FWD(launch_label_plane) SABER_OP_FWD(launch_pair_intersections) SABER_OP_FWD(launch_unpermute_nchw)
 SABER_OP_FWD(launch_rope) SABER_OP_FWD(launch_softmax_rows) SABER_OP_FWD(launch_conv3x3s2) SABER_OP_FWD(launch_unpack_masks) SABER_OP_FWD(launch_paint_nearest)
 SABER_OP_FWD(launch_conv3x3s2_t) SABER_OP_FWD(launch_dwconv7_t) SABER_OP_FWD(launch_dwconv7) SABER_OP_FWD(launch_conv4x4s4) SABER_OP_FWD(launch_resize_plane)

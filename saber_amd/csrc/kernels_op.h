@@ -57,6 +57,11 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
                            int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s, const XBuild* build = nullptr);
 const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* Vt,
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s, const XBuild* build = nullptr);
+// dec_i2t of layer l fused with the tokens -> image attention that follows it (round 5): X' is written as before and consumed as the next
+// attention's keys / values from LDS; `out` = that attention's output after v_proj (what launch_dec_t2i writes).  P workgroups of four waves.
+const char* launch_dec_i2t_t2i(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* VtT,
+                               const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P,
+                               const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s);
 const char* launch_dec_upscale(const bf16_t* X, const bf16_t* W1, const float* b1, const float* ln_g, const float* ln_b, const bf16_t* W2p,
                                const float* b2, const float* fs1, const float* fs0, XMap slot_map, const float* hyper, float* masks4, int P,
                                hipStream_t s, const uint8_t* live = nullptr, const float* iou4 = nullptr, int multimask = 0, unsigned int* sentinel = nullptr);
