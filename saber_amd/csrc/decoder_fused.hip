@@ -804,6 +804,14 @@ void dec_t2i_w1_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, in
 #undef T4_STAMP
 }
 
+// dec_t2i_w1_kernel is the route for split == 1 (-16 % against dec_t2i_kernel<8> in the engine, profiles/r05_t2i_w1_*); SABER_AMD_T2I_W1=0 (read per
+// call) or debug flag 0x200000 selects the 8-wave kernel for A/Bs, debug flag 0x100000 forces the new one.
+static bool t2i_w1_route() {
+    if (g_saber_debug_flags & 0x100000) return true;
+    if (g_saber_debug_flags & 0x200000) return false;
+    const char* e = getenv("SABER_AMD_T2I_W1");
+    return !(e && e[0] == '0');
+}
 const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf16_t* Qt, const float* tq, float qscale, float* Opart, float* ML,
                            int P, int split, const bf16_t* Wv, const float* bv, bf16_t* out, hipStream_t s, const XBuild* build) {
     if (P <= 0) return nullptr;
@@ -814,7 +822,7 @@ const char* launch_dec_t2i(const bf16_t* X, XMap xm, const bf16_t* pek, const bf
         if (!build->embb || !build->h2 || !build->w3 || build->map.div <= 0) return "dec_t2i: incomplete XBuild";
         hipLaunchKernelGGL((dec_t2i_kernel<8, false, true>), dim3(P * split), dim3(512), T2ICfg<8>::LDS, s, (const bf16_t*)nullptr, build->map.stride, build->map.div, build->map.off,
                            pek, Qt, tq, qscale, Opart, ML, split, Wv, bv, out, (unsigned long long*)nullptr, build->embb, build->h2, build->w3);
-    } else if (split == 1 && ((g_saber_debug_flags & 0x200) || getenv("SABER_AMD_T2I_W1") != nullptr)) {      // opt-in (round 5): one wave per SIMD, four query tiles per wave
+    } else if (split == 1 && t2i_w1_route()) {      // round 5: one wave per SIMD, four query tiles per wave (whole key range per workgroup: P >= 512 in the engine)
 #define T4_LAUNCH(ST, SH) hipLaunchKernelGGL((dec_t2i_w1_kernel<ST, SH>), dim3(P), dim3(256), T4_LDS, s, X, xm.stride, xm.div, xm.off, pek, Qt, tq, qscale, Wv, bv, out, g_saber_stamp_buf)
         if (g_saber_stamp_buf) { if (xm.div > 1) T4_LAUNCH(true, true); else T4_LAUNCH(true, false); }
         else { if (xm.div > 1) T4_LAUNCH(false, true); else T4_LAUNCH(false, false); }

@@ -50,7 +50,7 @@ def test_fused_equals_separate_launches(precision):
 
 @pytest.mark.parametrize("shared", [False, True])
 def test_t2i_one_wave_per_simd_kernel_against_fp64(shared):
-    """`dec_t2i_w1_kernel` (opt-in, debug flag 0x200 / SABER_AMD_T2I_W1): the tokens -> image attention with a wave per key quarter and all
+    """`dec_t2i_w1_kernel` (the route for whole-key-range launches; debug flag 0x200000 / SABER_AMD_T2I_W1=0 select the 8-wave kernel): the tokens -> image attention with a wave per key quarter and all
     four query tiles per wave - against the same fp64 restatement tests/test_gpu_kernels.py::test_dec_t2i uses, and run-to-run identical
     (it orders its LDS-DMA ring by counted waits alone)."""
     import ctypes as C
@@ -69,7 +69,7 @@ def test_t2i_one_wave_per_simd_kernel_against_fp64(shared):
     part = torch.zeros(P * 64 * 256, device="cuda")
     ml = torch.zeros(P * 64 * 2, device="cuda")
     outs = []
-    lib.saber_k_set_debug(0x200)
+    lib.saber_k_set_debug(0x100000)
     try:
         for _ in range(3):
             out = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
@@ -79,7 +79,10 @@ def test_t2i_one_wave_per_simd_kernel_against_fp64(shared):
     finally:
         lib.saber_k_set_debug(0)
     ref8 = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
+    lib.saber_k_set_debug(0x200000)
     kcall(lib, lib.saber_k_dec_t2i(ptr(X), 0 if shared else 4096 * 256, ptr(pek), ptr(Qt), ptr(tq), qscale, ptr(part), ptr(ml), P, 1, ptr(Wv), ptr(bv), ptr(ref8), None))
+    torch.cuda.synchronize()
+    lib.saber_k_set_debug(0)
     Xd = X.double().expand(P, -1, -1)
     tqb = (tq * qscale).to(torch.bfloat16).view(P, 8, 128)
     S = Qt.double() @ Xd.transpose(1, 2) + _blockdiag_pe_scores(tqb, pek, 1.0)
@@ -103,9 +106,9 @@ def test_decode_with_t2i_w1_equals_default():
         outs = {}
         for w1 in (False, True):
             if w1:
-                os.environ["SABER_AMD_T2I_W1"] = "1"
+                os.environ.pop("SABER_AMD_T2I_W1", None)       # the default route
             else:
-                os.environ.pop("SABER_AMD_T2I_W1", None)
+                os.environ["SABER_AMD_T2I_W1"] = "0"
             low, iou, _ = eng.decode_points(pts, slot=0, multimask=True)
             mi = torch.clamp(low[:, 0], -32, 32).contiguous()
             low2, iou2, _ = eng.decode_points(pts, slot=0, multimask=False, mask_input=mi)

@@ -12,7 +12,10 @@ pts = torch.rand(P, 2, device="cuda") * 1024
 low, iou, _ = eng.decode_points(pts, slot=0, multimask=True)
 mi = torch.clamp(low[:, 0], -32, 32).contiguous()
 for fuse in (0, 1, 0, 1):
-    if fuse: os.environ[ENV] = "1"
+    if ENV == "SABER_AMD_T2I_W1":          # default ON: A/B is "0" against unset
+        if fuse: os.environ.pop(ENV, None)
+        else: os.environ[ENV] = "0"
+    elif fuse: os.environ[ENV] = "1"
     else: os.environ.pop(ENV, None)
     for name, kw in (("first", dict(multimask=True)), ("m2m", dict(multimask=False, mask_input=mi))):
         for _ in range(2): eng.decode_points(pts, slot=0, **kw)
