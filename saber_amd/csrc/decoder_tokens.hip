@@ -22,15 +22,25 @@
 struct TokCtx { int tid, lane, wave, fi, fg; char* Q; char* B0; char* B1; char* F0; char* F1; char* F2; char* H; };
 
 // acc[i][m][r] = sum_k W[n0 + 16 (wave NTW + i) + 4 fg + r][k] * A[row 16 m + fi][k]  (W rows beyond nrows are clamped: their results are not used)
+// Wpk (optional) = launch_pack_w_kstep's copy [K / 32][Npk][4 chunks, XOR-permuted by row][8] of the matrix whose row `row_off` is W's row 0: a
+// 16 x 32 fragment is then one contiguous KB (eight full lines) instead of sixteen half lines of sixteen rows.
+__device__ __forceinline__ int tk_perm(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }          // gemm_rowln.hip rl_perm
 template <int NTW, int MT>
-__device__ __forceinline__ void wgemm(const TokCtx& c, const char* A, int K, const bf16_t* W, int ldw, int n0, int nrows, f32x4 (&acc)[NTW][MT]) {
+__device__ __forceinline__ void wgemm(const TokCtx& c, const char* A, int K, const bf16_t* W, int ldw, int n0, int nrows, f32x4 (&acc)[NTW][MT],
+                                      const bf16_t* Wpk = nullptr, int Npk = 0, int row_off = 0) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16_t* wr[NTW];
+    int64_t kstride = 32;                   // elements from one K-step's fragment to the next
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) wr[i] = W + (int64_t)min(n0 + 16 * (c.wave * NTW + i) + c.fi, nrows - 1) * ldw + 8 * c.fg;
+    for (int i = 0; i < NTW; ++i) {
+        const int n = min(n0 + 16 * (c.wave * NTW + i) + c.fi, nrows - 1);
+        if (Wpk) wr[i] = Wpk + (int64_t)(row_off + n) * 32 + ((c.fg ^ tk_perm(row_off + n)) << 3);
+        else wr[i] = W + (int64_t)n * ldw + 8 * c.fg;
+    }
+    if (Wpk) kstride = (int64_t)Npk * 32;
 #pragma unroll 8
     for (int ks = 0; ks < K / 32; ++ks) {
         op16x8 b[MT];
@@ -38,9 +48,41 @@ __device__ __forceinline__ void wgemm(const TokCtx& c, const char* A, int K, con
         for (int m = 0; m < MT; ++m) b[m] = *reinterpret_cast<const op16x8*>(A + (16 * m + c.fi) * TK_AS + (32 * ks + 8 * c.fg) * 2);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            const op16x8 a = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(wr[i] + 32 * ks));
+            const op16x8 a = __builtin_bit_cast(op16x8, *reinterpret_cast<const uint4*>(wr[i] + ks * kstride));
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[i][m] = MFMA_16x16x32(a, b[m], acc[i][m], 0, 0, 0);
+        }
+    }
+}
+
+// The same product with the weight fragments of the whole call (K = 256: 8 k-steps x 2 column tiles = 64 registers) REQUESTED AHEAD: wfrag_load
+// is issued one call early (the MLP walks 16 dependent 128-KB weight panels per segment, each behind a workgroup barrier: fetched inside the
+// call, every panel paid an L2 round trip with nothing to overlap it - round 5).  Same MFMA order as wgemm: bit-identical results.
+__device__ __forceinline__ void wfrag_load(const TokCtx& c, const bf16_t* Wpk, int N, int n0, int ks0, uint4 (&w)[2][8]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + 16 * (c.wave * 2 + i) + c.fi;
+        const bf16_t* wr = Wpk + ((int64_t)ks0 * N + n) * 32 + ((c.fg ^ tk_perm(n)) << 3);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w[i][ks] = *reinterpret_cast<const uint4*>(wr + (int64_t)ks * N * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // the requests stay HERE (ahead of the previous panel's MFMAs), not next to their use
+}
+__device__ __forceinline__ void wgemm_pre(const TokCtx& c, const char* A, const uint4 (&w)[2][8], f32x4 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        op16x8 b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) b[m] = *reinterpret_cast<const op16x8*>(A + (16 * m + c.fi) * TK_AS + (32 * ks + 8 * c.fg) * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const op16x8 a = __builtin_bit_cast(op16x8, w[i][ks]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[i][m] = MFMA_16x16x32(a, b[m], acc[i][m], 0, 0, 0);
         }
     }
 }
@@ -72,7 +114,7 @@ __device__ __forceinline__ void ln_rows(const TokCtx& c, TokLn ln, float eps) {
 // Q (+)= A . W^T + bias for N = 256 (residual: add to Q, else overwrite)
 __device__ __forceinline__ void proj_to_q(const TokCtx& c, const char* A, int K, TokLin L, bool residual) {
     f32x4 acc[2][2];
-    wgemm<2, 2>(c, A, K, L.w, L.ldw, 0, 256, acc);
+    wgemm<2, 2>(c, A, K, L.w, L.ldw, 0, 256, acc, L.wpk, L.npk, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
@@ -89,7 +131,7 @@ __device__ __forceinline__ void proj_to_q(const TokCtx& c, const char* A, int K,
 // F[row][0..127] = A . W[n0 .. n0+127]^T + bias (fp32 scratch, 128 columns)
 __device__ __forceinline__ void proj_to_f(const TokCtx& c, const char* A, int K, TokLin L, int n0, char* F) {
     f32x4 acc[1][2];
-    wgemm<1, 2>(c, A, K, L.w, L.ldw, n0, L.n, acc);
+    wgemm<1, 2>(c, A, K, L.w, L.ldw, n0, L.n, acc, L.wpk, L.npk, 0);
 #pragma unroll
     for (int i = 0; i < 1; ++i) {
         const int n = 16 * (c.wave + i) + 4 * c.fg;
@@ -208,9 +250,13 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc2[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        uint4 w1f[2][8], w2f[2][8];
+        wfrag_load(c, s.mlp1_pk, 2048, 0, 0, w1f);
+#pragma unroll 1
         for (int ch = 0; ch < 8; ++ch) {            // hidden columns 256 ch .. 256 ch + 255
             f32x4 acc[2][2];
-            wgemm<2, 2>(c, c.B0, 256, s.mlp1.w, s.mlp1.ldw, 256 * ch, 2048, acc);
+            wfrag_load(c, s.mlp2_pk, 256, 0, 8 * ch, w2f);       // this chunk's second panel, under the first one's MFMAs
+            wgemm_pre(c, c.B0, w1f, acc);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
@@ -220,9 +266,10 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
                     *reinterpret_cast<uint2*>(c.H + (16 * m + c.fi) * TK_AS + n * 2) =
                         make_uint2(pack_op16(fmaxf(acc[i][m][0] + b.x, 0.f), fmaxf(acc[i][m][1] + b.y, 0.f)), pack_op16(fmaxf(acc[i][m][2] + b.z, 0.f), fmaxf(acc[i][m][3] + b.w, 0.f)));
             }
+            if (ch + 1 < 8) wfrag_load(c, s.mlp1_pk, 2048, 256 * (ch + 1), 0, w1f);      // the next chunk's first panel
             __syncthreads();
             f32x4 part[2][2];
-            wgemm<2, 2>(c, c.H, 256, s.mlp2.w + 256 * ch, s.mlp2.ldw, 0, 256, part);
+            wgemm_pre(c, c.H, w2f, part);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -341,7 +388,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
     // ---------------- (5) heads on the final tokens: [obj, iou, mask 0..3, point, pad]
     if (s.do_heads) {
         // three-layer MLP on ONE token per prompt: rows 0..3 of a 16-row operand tile (the other rows are zero)
-        auto mlp3 = [&](const TokLin* L, int64_t w_off0, int64_t w_off2, int b_off0, int b_off2, int token, int n_out, int sigmoid, float* out, int ldo, int o_off) {
+        auto mlp3 = [&](const TokLin* L, int64_t w_off0, int64_t w_off2, int r_off0, int r_off2, int b_off0, int b_off2, int token, int n_out, int sigmoid, float* out, int ldo, int o_off) {
             for (int idx = c.tid; idx < 16 * 64; idx += TK_T) {
                 const int r = idx >> 6, c4 = (idx & 63) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -353,7 +400,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
                 const char* in = l == 0 ? c.B0 : c.B1;
                 char* outb = l == 0 ? c.B1 : c.H;
                 f32x4 acc[2][1];
-                wgemm<2, 1>(c, in, 256, L[l].w + w_off0, L[l].ldw, 0, 256, acc);
+                wgemm<2, 1>(c, in, 256, L[l].w + w_off0, L[l].ldw, 0, 256, acc, L[l].wpk, L[l].npk, r_off0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int n = 16 * (c.wave * 2 + i) + 4 * c.fg;
@@ -365,7 +412,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
             }
             if (c.wave * 16 < n_out) {       // n_out <= 32: waves 0 (and 1)
                 f32x4 acc[1][1];
-                wgemm<1, 1>(c, c.H, 256, L[2].w + w_off2, L[2].ldw, 0, n_out, acc);
+                wgemm<1, 1>(c, c.H, 256, L[2].w + w_off2, L[2].ldw, 0, n_out, acc, L[2].wpk, L[2].npk, r_off2);
                 if (c.fi < np) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -380,16 +427,17 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
             }
             __syncthreads();
         };
-        mlp3(s.iou, 0, 0, 0, 0, 1, 4, 1, s.iou4, 4, 0);
-        if (s.obj_out) mlp3(s.obj, 0, 0, 0, 0, 0, 1, 0, s.obj_out, 1, 0);
+        mlp3(s.iou, 0, 0, 0, 0, 0, 0, 1, 4, 1, s.iou4, 4, 0);
+        if (s.obj_out) mlp3(s.obj, 0, 0, 0, 0, 0, 0, 0, 1, 0, s.obj_out, 1, 0);
         for (int k = 0; k < 4; ++k)
-            mlp3(s.hyper, (int64_t)k * 256 * s.hyper[0].ldw, (int64_t)k * 32 * s.hyper[2].ldw, 256 * k, 32 * k, 2 + k, 32, 0, s.hyper_out, 128, 32 * k);
+            mlp3(s.hyper, (int64_t)k * 256 * s.hyper[0].ldw, (int64_t)k * 32 * s.hyper[2].ldw, 256 * k, 32 * k, 256 * k, 32 * k, 2 + k, 32, 0, s.hyper_out, 128, 32 * k);
     }
 }
 
 #define TK_LDS (TK_R * 256 * 4 + 3 * TK_R * TK_AS + 3 * TK_R * TK_FS * 4)
 const char* launch_dec_tokens(const TokSeg& s, hipStream_t st) {
     if (s.P <= 0) return nullptr;
+    if (s.do_mlp && (!s.mlp1_pk || !s.mlp2_pk)) return "dec_tokens: the MLP needs the K-step-packed copies of its two weights (launch_pack_w_kstep)";
     hipLaunchKernelGGL(dec_tokens_kernel, dim3((s.P + TK_G - 1) / TK_G), dim3(TK_T), TK_LDS, st, s);
     return nullptr;
 }

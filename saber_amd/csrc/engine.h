@@ -14,7 +14,7 @@ struct BlockSpec { int din, dout, heads, window, q_stride; };
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
-struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; const float* wf = nullptr;
+struct LinW { const bf16_t* w = nullptr; const float* b = nullptr; int out = 0, in = 0, ldw = 0; const bf16_t* wpk = nullptr; int wpk_n = 0; const float* wf = nullptr;
               const uint8_t* w8 = nullptr; const uint8_t* sw8 = nullptr; int kp8 = 0, sw_rows = 0; };   // w8 / sw8: MXFP8 copy (e4m3 [out][kp8] + e8m0 [kp8 / 128][sw_rows][4], gemm_fp8.hip), weight format SABER_WEIGHTS_MXFP8 only   // wf: dense fp32 [out][in] copy, kept only when the exact-precision mode was requested before finalize (exact.hip)   // wpk: K-step-packed copy (gemm_rowln.hip)  // rows zero-padded to ldw = ceil(in/64)*64
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
 

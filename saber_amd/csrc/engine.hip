@@ -623,6 +623,15 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
     // ---- mask decoder
     {
         const std::string d = "sam_mask_decoder.";
+        // dec_tokens_kernel streams its weights through registers, one 16 x 32 fragment per wave-load: in the K-step-packed copy a fragment is one
+        // contiguous KB (eight full lines) instead of sixteen half lines of sixteen rows (round 5: segments 154 / 130 -> 129 / 102 us for the MLP alone)
+        auto pack_for_tokens = [&](LinW* lw, int rows) -> int {
+            bf16_t* dpk = nullptr;
+            TRY(eng_alloc(e, &dpk, gemm_rowln_packed_elems(rows, lw->in)));
+            if (const char* m = launch_pack_w_kstep(lw->w, lw->ldw, rows, lw->in, dpk, nullptr)) return eng_fail(e, SABER_ERR_INVALID, m);
+            lw->wpk = dpk; lw->wpk_n = rows;
+            return SABER_OK;
+        };
         for (int l = 0; l < 2; ++l) {
             const std::string L = d + "transformer.layers." + std::to_string(l) + ".";
             DecLayerW& w = e->dl[l];
@@ -632,11 +641,19 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
             w.n2 = F.ln(L + "norm2", 256);
             w.mlp1 = F.lin(L + "mlp.layers.0", 2048, 256);
             w.mlp2 = F.lin(L + "mlp.layers.1", 256, 2048);
+            if (F.status != SABER_OK) return F.status;
+            // dec_tokens_kernel streams these two through registers, one 16 x 32 fragment per wave-load: in the K-step-packed copy a fragment is
+            // one contiguous KB (eight full lines) instead of sixteen half lines of sixteen rows
+            for (LinW* lw : {&w.mlp1, &w.mlp2}) TRY(pack_for_tokens(lw, lw->out));
             w.n3 = F.ln(L + "norm3", 256);
             w.n4 = F.ln(L + "norm4", 256);
             w.i2t = F.attn(L + "cross_attn_image_to_token", 128, "q");
+            if (F.status != SABER_OK) return F.status;
+            for (LinW* lw : {&w.self_attn.q, &w.self_attn.k, &w.self_attn.v, &w.self_attn.o, &w.t2i.q, &w.t2i.o, &w.i2t.k, &w.i2t.v}) TRY(pack_for_tokens(lw, lw->out));
         }
         e->final_attn = F.attn(d + "transformer.final_attn_token_to_image", 128, "k");
+        if (F.status != SABER_OK) return F.status;
+        for (LinW* lw : {&e->final_attn.q, &e->final_attn.o}) TRY(pack_for_tokens(lw, lw->out));
         e->final_ln = F.ln(d + "transformer.norm_final_attn", 256);
         // ConvTranspose2d(k2,s2) as a GEMM: N index = (ky*2+kx)*Cout + co
         auto convT = [&](const std::string& prefix, int cin, int cout, LinW* out) {
@@ -688,6 +705,12 @@ extern "C" int saber_engine_finalize(saber_engine* e) {
         for (int l = 0; l < 3; ++l) {
             e->iou_head[l] = F.lin(d + "iou_prediction_head.layers." + std::to_string(l), iou_out[l], 256);
             e->obj_head[l] = F.lin(d + "pred_obj_score_head.layers." + std::to_string(l), obj_out[l], 256);
+        }
+        if (F.status != SABER_OK) return F.status;
+        for (int l = 0; l < 3; ++l) {
+            TRY(pack_for_tokens(&e->hyper[l], 4 * e->hyper[l].out));          // the four hypernetwork MLPs stacked along the rows
+            TRY(pack_for_tokens(&e->iou_head[l], e->iou_head[l].out));
+            TRY(pack_for_tokens(&e->obj_head[l], e->obj_head[l].out));
         }
     }
     if (F.status != SABER_OK) return F.status;
@@ -1271,7 +1294,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
     static const bool no_tokfuse = getenv("SABER_AMD_NO_TOKFUSE") != nullptr;      // development A/B switch: the ~58 separate token-side launches
     if (!no_tokfuse) {
         // token side as four fused segments (decoder_tokens.hip) around the five image-side kernels
-        auto lin = [](const LinW& l) { TokLin t; t.w = l.w; t.b = l.b; t.ldw = l.ldw; t.n = l.out; return t; };
+        auto lin = [](const LinW& l) { TokLin t; t.w = l.w; t.b = l.b; t.ldw = l.ldw; t.n = l.out; t.wpk = l.wpk; t.npk = l.wpk_n; return t; };
         auto lnw = [](const LnW& l) { TokLn t; t.g = l.g; t.b = l.b; return t; };
         auto base = [&]() { TokSeg g; g.P = P; g.queries = e->queries; g.tok_pe = e->tok_pe; g.kscale = kScale; return g; };
         auto with_t2i = [&](TokSeg& g, const AttnW& a) { g.do_t2i = 1; g.t2i_q = lin(a.q); g.t2i_kT = a.img_wT; g.tq_out = e->tq; g.fold_q = e->fold_q; };
@@ -1280,7 +1303,7 @@ static int decode_chunk(saber_engine* e, int slot0, int per_slot, int p_base, co
         };
         auto with_att_out = [&](TokSeg& g, const AttnW& a, const LnW& ln) { g.t_att = e->t_att; g.att_o = lin(a.o); g.att_ln = lnw(ln); g.att_eps = 1e-5f; };
         auto with_mlp_i2t = [&](TokSeg& g, const DecLayerW& w) {
-            g.do_mlp = 1; g.mlp1 = lin(w.mlp1); g.mlp2 = lin(w.mlp2); g.ln3 = lnw(w.n3);
+            g.do_mlp = 1; g.mlp1 = lin(w.mlp1); g.mlp2 = lin(w.mlp2); g.mlp1_pk = w.mlp1.wpk; g.mlp2_pk = w.mlp2.wpk; g.ln3 = lnw(w.n3);
             g.i2t_k = lin(w.i2t.k); g.i2t_v = lin(w.i2t.v); g.i2t_qT = w.i2t.img_wT; g.i2t_qb = w.i2t.q.b; g.i2t_o = w.i2t.o.w;
             g.tk_out = e->tk; g.fold_k = e->fold_k; g.fold_cb = e->fold_cb; g.fold_v = e->fold_v;
         };

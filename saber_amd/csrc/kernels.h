@@ -121,7 +121,8 @@ struct XBuild { const float* embb = nullptr; XMap map{0, 1, 0}; const bf16_t* h2
 
 // ------------------------------------------------------------------ decoder_tokens.hip
 // One segment of the token side of the two-way transformer (everything between two image-side kernels) as one launch; see the file header.
-struct TokLin { const bf16_t* w = nullptr; const float* b = nullptr; int ldw = 0; int n = 0; };
+struct TokLin { const bf16_t* w = nullptr; const float* b = nullptr; int ldw = 0; int n = 0;
+                const bf16_t* wpk = nullptr; int npk = 0; };      // wpk: optional launch_pack_w_kstep copy of the npk rows of w (a 16 x 32 fragment = one contiguous KB)
 struct TokLn { const float* g = nullptr; const float* b = nullptr; };
 struct TokSeg {
     int P = 0;
@@ -132,6 +133,7 @@ struct TokSeg {
     // (2) queries = LN3(queries + mlp(queries)); image -> tokens operands of this layer
     int do_mlp = 0;
     TokLin mlp1, mlp2; TokLn ln3;
+    const bf16_t* mlp1_pk = nullptr; const bf16_t* mlp2_pk = nullptr;     // launch_pack_w_kstep copies of mlp1.w [2048][256] / mlp2.w [256][2048] (required with do_mlp)
     TokLin i2t_k, i2t_v; const bf16_t* i2t_qT = nullptr; const float* i2t_qb = nullptr; const bf16_t* i2t_o = nullptr;
     float* tk_out = nullptr; bf16_t* fold_k = nullptr; float* fold_cb = nullptr; bf16_t* fold_v = nullptr;
     // (3) self attention of the tokens + LN1
