@@ -445,15 +445,32 @@ def launch_ranks(a):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's peer buffers need it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0 = procs[0].communicate()[0]
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=120 if rc == 0 else 10)
-        except subprocess.TimeoutExpired:
-            p.kill()                     # the exact PID this function started
-            p.wait()
+    # rank 0's stdout is drained by a thread while the parent polls every rank: a rank that dies (no such device, a failed assertion) must not
+    # leave the others waiting in a rendezvous or a collective until some outer timeout - they are ended (the exact PIDs started above)
+    import threading
+    import time
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            time.sleep(2.0)              # let the others notice by themselves first
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
         rc = rc or p.returncode
+    reader.join(timeout=10)
+    out0 = buf[0] if buf else ""
     sys.stdout.write(out0)
     sys.stdout.flush()
     sys.exit(1 if rc else 0)
