@@ -214,7 +214,10 @@ __device__ __forceinline__ void fold_cols(const TokCtx& c, const char* F, const 
     }
 }
 
-__global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
+__global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s, unsigned long long* __restrict__ stamps) {
+    // development: s_memtime at the phase boundaries (tools/tok_stamps.py), wave 0 of every workgroup; nullptr in production
+    unsigned long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = stamps ? __builtin_amdgcn_s_memtime() : 0;
+#define TK_STAMP(k) do { if (stamps) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); tst[k] += _n - tprev; tprev = _n; } } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TokCtx c;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.fi = c.lane & 15; c.fg = c.lane >> 4;
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         const int r = idx >> 6, c4 = (idx & 63) * 4;
         *reinterpret_cast<float4*>(c.Q + (r * 256 + c4) * 4) = r < rows ? *reinterpret_cast<const float4*>(s.queries + (row0 + r) * 256 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    TK_STAMP(0);
     // ---------------- (1) output projection of the tokens -> image attention that has just run
     if (s.t_att) {
         for (int idx = c.tid; idx < TK_R * 16; idx += TK_T) {
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         ln_rows(c, s.att_ln, s.att_eps);
     }
     __syncthreads();
+    TK_STAMP(1);
     // ---------------- (2) MLP, LN3, operands of the image -> tokens attention
     if (s.do_mlp) {
         to_operand(c, c.B0, nullptr, rows);
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         __syncthreads();
         ln_rows(c, s.ln3, 1e-5f);
         __syncthreads();
+        TK_STAMP(2);
         // image -> tokens: k = k_proj(queries + pe), v = v_proj(queries); folded with the image side's q_proj / out_proj
         to_operand(c, c.B0, pe, rows);
         to_operand(c, c.B1, nullptr, rows);
@@ -308,10 +314,12 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
             for (int j = 0; j < 16; ++j) acc += a[j] * s.i2t_qb[16 * h + j];
             s.fold_cb[(int64_t)(p0 + pi) * 64 + 8 * h + t] = acc * s.kscale;
         }
+        TK_STAMP(3);
         fold_rows(c, c.F0, s.i2t_qT, s.kscale, s.fold_k, p0, s.P);
         fold_cols(c, c.F1, s.i2t_o, 128, s.fold_v, p0, s.P);
         __syncthreads();
     }
+    TK_STAMP(4);
     // ---------------- (3) self attention of the tokens
     if (s.do_self) {
         if (!s.do_mlp) {      // (after (2) B0 = bf16(queries + pe) and B1 = bf16(queries) are already in place)
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         ln_rows(c, s.ln1, 1e-5f);
         __syncthreads();
     }
+    TK_STAMP(5);
     // ---------------- (4) operands of the next tokens -> image attention: q = q_proj(queries + pe), folded with the image side's k_proj
     if (s.do_t2i) {
         to_operand(c, c.B0, pe, rows);
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         }
         fold_rows(c, c.F0, s.t2i_kT, s.kscale, s.fold_q, p0, s.P);
     }
+    TK_STAMP(6);
     // the residual stream goes back (the next segment, or saber_get_decoder_tokens, reads it)
     __syncthreads();
     for (int idx = c.tid; idx < rows * 64; idx += TK_T) {
@@ -432,13 +442,26 @@ __global__ __launch_bounds__(TK_T) void dec_tokens_kernel(TokSeg s) {
         for (int k = 0; k < 4; ++k)
             mlp3(s.hyper, (int64_t)k * 256 * s.hyper[0].ldw, (int64_t)k * 32 * s.hyper[2].ldw, 256 * k, 32 * k, 256 * k, 32 * k, 2 + k, 32, 0, s.hyper_out, 128, 32 * k);
     }
+    TK_STAMP(7);
+    if (stamps && c.tid == 0)
+        for (int k = 0; k < 8; ++k) stamps[(int64_t)blockIdx.x * 8 + k] = tst[k];
+#undef TK_STAMP
 }
 
 #define TK_LDS (TK_R * 256 * 4 + 3 * TK_R * TK_AS + 3 * TK_R * TK_FS * 4)
 const char* launch_dec_tokens(const TokSeg& s, hipStream_t st) {
     if (s.P <= 0) return nullptr;
     if (s.do_mlp && (!s.mlp1_pk || !s.mlp2_pk)) return "dec_tokens: the MLP needs the K-step-packed copies of its two weights (launch_pack_w_kstep)";
-    hipLaunchKernelGGL(dec_tokens_kernel, dim3((s.P + TK_G - 1) / TK_G), dim3(TK_T), TK_LDS, st, s);
+    // development (tools/tok_stamps.py): with a stamp buffer set, the segment whose index in the decode (call count mod 4) equals
+    // SABER_AMD_TOK_STAMP_SEG writes its stamps at element 500 000 of the buffer (dec_t2i / dec_i2t write theirs from element 0)
+    unsigned long long* stamps = nullptr;
+    if (g_saber_stamp_buf) {
+        static int calls = 0;
+        const char* e = getenv("SABER_AMD_TOK_STAMP_SEG");
+        if (e && (calls & 3) == atoi(e)) stamps = g_saber_stamp_buf + 500000;
+        ++calls;
+    }
+    hipLaunchKernelGGL(dec_tokens_kernel, dim3((s.P + TK_G - 1) / TK_G), dim3(TK_T), TK_LDS, st, s, stamps);
     return nullptr;
 }
 const char* decoder_tokens_init_device() {
