@@ -699,12 +699,10 @@ void dec_t2i_w1_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, in
             constexpr int g = decltype(G)::value;
             u32x2_d (&lo)[4] = vl[g & 1];
             u32x2_d (&hi)[4] = vh[g & 1];
-            if constexpr (g + 1 < 4) {
-                request_v(4 * (g + 1), vl[(g + 1) & 1], vh[(g + 1) & 1]);
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
-            }
+            // (this group was requested one group earlier; the next one is requested only now: LGKM_CNT is a 4-bit counter, and 16 reads in
+            // flight would make every counted wait meaningless)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+            if constexpr (g + 1 < 4) request_v(4 * (g + 1), vl[(g + 1) & 1], vh[(g + 1) & 1]);
             t4_for(T4_SEQ(4), [&](auto J) {
                 constexpr int j = decltype(J)::value;
                 const op16x8 vfr = cat4_d(__builtin_bit_cast(op16x4, lo[j]), __builtin_bit_cast(op16x4, hi[j]));
@@ -805,10 +803,10 @@ void dec_t2i_w1_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, in
 }
 
 // dec_t2i_w1_kernel is the route for split == 1 (-16 % against dec_t2i_kernel<8> in the engine, profiles/r05_t2i_w1_*); SABER_AMD_T2I_W1=0 (read per
-// call) or debug flag 0x200000 selects the 8-wave kernel for A/Bs, debug flag 0x100000 forces the new one.
+// call) or debug flag 0x20000000 selects the 8-wave kernel for A/Bs, debug flag 0x10000000 forces the new one.
 static bool t2i_w1_route() {
-    if (g_saber_debug_flags & 0x100000) return true;
-    if (g_saber_debug_flags & 0x200000) return false;
+    if (g_saber_debug_flags & 0x10000000) return true;
+    if (g_saber_debug_flags & 0x20000000) return false;
     const char* e = getenv("SABER_AMD_T2I_W1");
     return !(e && e[0] == '0');
 }
@@ -1144,6 +1142,257 @@ __global__ __launch_bounds__(256 * RT, BUILD ? 2 : 1) void dec_i2t_kernel(const 
         for (int k = 0; k < 6; ++k) stamps[((int64_t)blockIdx.x * (4 * RT) + wave) * 6 + k] = ts[k];
 }
 
+// ------------------------------------------------------------------------------------------------ image -> tokens, one wave per SIMD (round 5)
+// dec_i2t_kernel splits a 16-row tile over four waves (score quarters, then channel quarters): the softmax weights and the LayerNorm
+// statistics cross the waves through LDS and the tile costs a workgroup barrier; each wave re-reads the whole X tile.  Here a WAVE owns a
+// tile: all 64 score columns (the folded K operand of the prompt: 32 fragments) and all 256 output channels (the folded V operand: 32
+// fragments) - 256 registers of MFMA A operands, held in the AccVGPRs (gfx950 MFMAs read A / B from either file) and named in the
+// instruction strings.  The softmax weights never leave the registers: the P fragment of k-step j is the lane's own score registers of the
+// quarters 2 j and 2 j + 1 (k = 8 fg + e  <->  column 16 (2 j + (e >> 2)) + 4 fg + (e & 3)), and the V fragments are gathered in that order
+// when they are loaded; the LayerNorm statistics are in-wave reductions.  No barrier, no cross-wave traffic: wave w streams tiles w, w + 4, ...
+// through a private two-stage ring (global -> LDS directly) and transposes its finished tile through 16 KB of private LDS into full 512-B
+// rows.  The wave's VALU work (softmax, residual, LayerNorm: ~450 instructions per tile) does not overlap its own MFMAs (section 8.2), but
+// four independent waves keep four SIMDs busy all the time, where the four-wave form waits 36 % of its cycles.
+#define I4_XST (16 * ROW_B)                       // X tile
+#define I4_STAGE (I4_XST + 16 * I2T_PEQ_ROWB)     // + PEQ tile: 12 KB
+#define I4_RING (2 * I4_STAGE)
+#define I4_SCR (16 * 512)                         // fp32 transpose scratch: 16 rows x 128 channels (a tile leaves in two channel halves)
+#define I4_CONST 8192                             // the prompt's small operands: b_o [256] fp32 | score bias [64] fp32 | positional fragments [4][64 lanes][16 B]
+#define I4_WAVE (I4_RING + I4_SCR + I4_CONST)     // 40 KB per wave
+#define I4_LDS (4 * I4_WAVE)                      // 160 KB
+#define I4_KF(q, ks) ((((q) * 8 + (ks)) * 4))                 // AccVGPR of the folded-K fragment (quarter q, k-step ks)
+#define I4_VF(dt, j) (128 + (((dt) * 2 + (j)) * 4))           // AccVGPR of the folded-V fragment (channel tile dt, k-step j)
+template <int N> __device__ __forceinline__ void i4_load_a16(const void* p) {
+    asm volatile("global_load_dwordx4 a[%0:%1], %2, off" : : "n"(N), "n"(N + 3), "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void i4_load_a8(const void* p) {
+    asm volatile("global_load_dwordx2 a[%0:%1], %2, off" : : "n"(N), "n"(N + 1), "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void i4_mfma_a(f32x4& acc, const op16x8& b) {          // acc += A(a[N..N+3]) . b
+    asm volatile(T4_MFMA_OP " %0, a[%1:%2], %3, %0" : "+v"(acc) : "n"(N), "n"(N + 3), "v"(b));
+}
+template <bool SHARED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void dec_i2t_w1_kernel(const bf16_t* __restrict__ X, int64_t x_bs, int x_div, int x_off, const bf16_t* __restrict__ peq,
+                       const bf16_t* __restrict__ Kt, const float* __restrict__ tk, float kscale, const float* __restrict__ cb,
+                       const bf16_t* __restrict__ VtT, const float* __restrict__ bo,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, bf16_t* __restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.x;
+    const bf16_t* Xp = X + (int64_t)((p + x_off) / x_div) * x_bs;
+    bf16_t* Xo = Xout + (int64_t)p * 4096 * DC;
+    constexpr int NT = 4096 / 16 / 4;                 // tiles per wave
+    char* ring = smem + wave * I4_WAVE;
+    const uint32_t ring_a = (uint32_t)(uintptr_t)(lptr_d)ring;
+    const uint32_t scr_a = ring_a + I4_RING;
+    const uint32_t cst_a = scr_a + I4_SCR;
+
+    // ---- the prompt's folded operands -> AccVGPRs.  The file is taken: the compiler must not place anything of its own there - neither
+    // MFMA results (there is no compiler-visible MFMA in this kernel) nor VGPR spills (it spills to free AccVGPRs first: the kernel has to
+    // stay clear of 256 VGPRs, which is why b_o, the score bias and the positional fragments live in LDS and not in 96 registers).
+    asm volatile("" ::: T4_ALL_AGPRS);
+    t4_for(T4_SEQ(4), [&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        t4_for(T4_SEQ(8), [&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
+            i4_load_a16<I4_KF(q, ks)>(Kt + ((int64_t)p * 64 + 16 * q + fi) * DC + 32 * ks + 8 * fg);
+        });
+    });
+    t4_for(T4_SEQ(16), [&](auto D) {
+        constexpr int dt = decltype(D)::value;
+        const bf16_t* vr = VtT + ((int64_t)p * 256 + 16 * dt + fi) * 64 + 4 * fg;
+        // k-step j: elements 0..3 = columns 32 j + 4 fg .. + 3 (quarter 2 j), elements 4..7 = columns 32 j + 16 + 4 fg .. + 3 (quarter 2 j + 1)
+        i4_load_a8<I4_VF(dt, 0)>(vr);          i4_load_a8<I4_VF(dt, 0) + 2>(vr + 16);
+        i4_load_a8<I4_VF(dt, 1)>(vr + 32);     i4_load_a8<I4_VF(dt, 1) + 2>(vr + 48);
+    });
+    // b_o, the score bias, and the positional operand (block-diagonal: the 8 tokens of heads 2 q, 2 q + 1 against their 16 PEQ channels
+    // each) -> the wave's constants in LDS (written and read by this wave only)
+    {
+        float* cst = reinterpret_cast<float*>(ring + I4_RING + I4_SCR);
+        *reinterpret_cast<float4*>(cst + 4 * lane) = *reinterpret_cast<const float4*>(bo + 4 * lane);
+        if (lane < 16) *reinterpret_cast<float4*>(cst + 256 + 4 * lane) = *reinterpret_cast<const float4*>(cb + (int64_t)p * 64 + 4 * lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int hsel = fg >> 1;
+            const float* kp = tk + ((int64_t)p * 8 + (fi & 7)) * 128 + 16 * (2 * q + hsel) + 8 * (fg & 1);
+            const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
+            const float z = ((fi >> 3) == hsel) ? kscale : 0.f;
+            const op16x8 kq = pack8_d(a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z);
+            *reinterpret_cast<op16x8*>(reinterpret_cast<char*>(cst) + 2048 + q * 1024 + lane * 16) = kq;
+        }
+    }
+    // LayerNorm gain / bias of the lane's channels in the ROW-MAJOR (store) layout: channels 128 h + 4 (lane & 31) .. + 3 of half h
+    const int k32 = lane & 31;
+    float gr[2][4], br[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + 128 * h + 4 * k32), b0 = *reinterpret_cast<const float4*>(beta + 128 * h + 4 * k32);
+        gr[h][0] = g0.x; gr[h][1] = g0.y; gr[h][2] = g0.z; gr[h][3] = g0.w;
+        br[h][0] = b0.x; br[h][1] = b0.y; br[h][2] = b0.z; br[h][3] = b0.w;
+    }
+
+    // ---- LDS-DMA of a tile: 8 X pieces (2 rows of 512 B) + 4 PEQ pieces (4 rows of 256 B), source-side swizzle (dec_i2t_kernel's images)
+    const int hrow = lane >> 5, lsw = k32 ^ hrow;
+    const int prow = lane >> 4;
+    auto issue = [&](int n) {                       // the wave's n-th tile
+        const int row0 = (wave + 4 * n) * 16;
+        char* dst = ring + (n & 1) * I4_STAGE;
+        const bf16_t* src = Xp + (int64_t)(row0 + hrow) * DC;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_d)(src + (2 * i) * DC + ((lsw ^ ((2 * i) & 15)) << 3)), (lptr_d)(dst + i * 1024), 16, 0, SHARED ? 0 : I2T_X_AUX);
+        const bf16_t* psrc = peq + (int64_t)(row0 + prow) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_d)(psrc + (4 * i) * 128 + (((lane & 15) ^ (4 * i + prow)) << 3)), (lptr_d)(dst + I4_XST + i * 1024), 16, 0, 0);
+    };
+    uint32_t xoff[4];                 // X fragment (row fi, chunk 4 ks + fg): ks and ks + 4 differ by 256 bytes
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xoff[ks] = fi * ROW_B + (((4 * ks + fg) ^ fi) << 4);
+    const uint32_t roff0 = fi * ROW_B + (fg & 1) * 8;       // residual: row fi, channels 16 dt + 4 fg .. + 3 = chunk 2 dt + (fg >> 1), half fg & 1
+    const int rch = fg >> 1;
+    // transpose scratch: fp32 [16 rows][32 chunks of 16 B] (one channel half), chunk c of row r at ((c ^ r) << 4)
+    const uint32_t swr = scr_a + fi * 512;                  // write: row fi, chunk 4 (dt & 7) + fg
+    const uint32_t srd = scr_a + hrow * 512;                // read: row 2 i + hrow, chunk k32
+
+    issue(0); issue(1);
+    asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");       // the 96 operand loads, the constants (the two tiles' 24 pieces may stay in flight)
+    // queue of a wave at the top of step n >= 2, behind the pieces of tile n: S(n - 2) 16, D(n + 1) 12, S(n - 1) 16 = 44 (S = a tile's 16
+    // stores, D = its 12 LDS-DMA pieces).  ONE loop body (wave-uniform branches pick the wait): peeled copies of the step kept a dozen
+    // loop-invariant addresses alive, and the compiler parked them in "free" AccVGPRs - on top of the folded K operand.
+#pragma unroll 1
+    for (int n = 0; n < NT; ++n) {
+        if (n == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (n >= 2 && n < NT - 2) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t xs = ring_a + (n & 1) * I4_STAGE;
+        // ---- scores: s[q] = cb + PEQ part + sum over 8 k-steps of (folded K quarter q) . (X fragment)
+        // (LGKM_CNT is a 4-bit counter: never more than 15 LDS operations in flight before a wait - with 16 or 20 the counted waits below
+        // let the first MFMAs through before their operands had landed: NaN rows, a wrong first channel tile)
+        op16x8 xf[8], pf4[4], kq4[4];
+        f32x4 s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1" : "=v"(s[q]) : "v"(cst_a + 1024 + (16 * q + 4 * fg) * 4) : "memory");
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[ks]) : "v"(xs + xoff[ks & 3] + (ks >> 2) * 256) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]), "+v"(xf[6]), "+v"(xf[7]),
+                     "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(pf4[q]) : "v"(xs + I4_XST + fi * I2T_PEQ_ROWB + (((4 * q + fg) ^ fi) << 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kq4[q]) : "v"(cst_a + 2048 + q * 1024 + lane * 16) : "memory");
+        }
+        t4_for(T4_SEQ(8), [&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
+            i4_mfma_a<I4_KF(0, ks)>(s[0], xf[ks]); i4_mfma_a<I4_KF(1, ks)>(s[1], xf[ks]);
+            i4_mfma_a<I4_KF(2, ks)>(s[2], xf[ks]); i4_mfma_a<I4_KF(3, ks)>(s[3], xf[ks]);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pf4[0]), "+v"(pf4[1]), "+v"(pf4[2]), "+v"(pf4[3]), "+v"(kq4[0]), "+v"(kq4[1]), "+v"(kq4[2]), "+v"(kq4[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T4_MFMA_V(s[q], kq4[q], pf4[q]);
+        // y starts as b_o (the C operand of the first PV product): the first eight channel tiles requested here, under the last score MFMAs
+        f32x4 y[16];
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) asm volatile("ds_read_b128 %0, %1" : "=v"(y[dt]) : "v"(cst_a + (16 * dt + 4 * fg) * 4) : "memory");
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));          // the last score MFMAs -> VALU
+        // ---- softmax over the 8 tokens of each head: a quarter's 16 columns = heads 2 q (fg 0, 1) and 2 q + 1 (fg 2, 3)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float mx = fmaxf(fmaxf(s[q][0], s[q][1]), fmaxf(s[q][2], s[q][3]));
+            mx = xor16_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[q][r] = __builtin_amdgcn_exp2f(s[q][r] - mx); sum += s[q][r]; }
+            sum = xor16_sum(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[q][r] *= inv;
+        }
+        const op16x8 p0 = pack8_d(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
+        const op16x8 p1 = pack8_d(s[2][0], s[2][1], s[2][2], s[2][3], s[3][0], s[3][1], s[3][2], s[3][3]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+#pragma unroll
+        for (int dt = 8; dt < 16; ++dt) asm volatile("ds_read_b128 %0, %1" : "=v"(y[dt]) : "v"(cst_a + (16 * dt + 4 * fg) * 4) : "memory");
+        // ---- y = b_o + (folded V) . P; the residual rows (the last reads of this stage) are requested under the second k-step's products
+        t4_for(T4_SEQ(8), [&](auto D) { i4_mfma_a<I4_VF(decltype(D)::value, 0)>(y[decltype(D)::value], p0); });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]), "+v"(y[12]), "+v"(y[13]), "+v"(y[14]), "+v"(y[15]));
+        u32x2_d res[16];
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+            asm volatile("ds_read_b64 %0, %1" : "=v"(res[dt]) : "v"(xs + roff0 + (((2 * dt + rch) ^ fi) << 4)) : "memory");
+        t4_for(T4_SEQ(8), [&](auto D) { i4_mfma_a<I4_VF(decltype(D)::value + 8, 0)>(y[decltype(D)::value + 8], p0); });
+        t4_for(T4_SEQ(8), [&](auto D) { i4_mfma_a<I4_VF(decltype(D)::value, 1)>(y[decltype(D)::value], p1); });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]));
+#pragma unroll
+        for (int dt = 8; dt < 16; ++dt)
+            asm volatile("ds_read_b64 %0, %1" : "=v"(res[dt]) : "v"(xs + roff0 + (((2 * dt + rch) ^ fi) << 4)) : "memory");
+        t4_for(T4_SEQ(8), [&](auto D) { i4_mfma_a<I4_VF(decltype(D)::value + 8, 1)>(y[decltype(D)::value + 8], p1); });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]) : : "memory");
+        // every read of this stage has returned: refill it with the tile after next
+        if (n + 2 < NT) issue(n + 2);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]),
+                     "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]), "+v"(y[12]), "+v"(y[13]), "+v"(y[14]), "+v"(y[15]) : : "memory");
+        // ---- residual + LayerNorm statistics of row fi (64 channels in the lane, the other 192 in the lanes fi + 16, + 32, + 48)
+        f32x2 sum2 = (f32x2){0.f, 0.f}, sq2 = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) {
+            const uint32_t xlo = res[dt][0], xhi = res[dt][1];
+            y[dt][0] += op16_lo(xlo); y[dt][1] += op16_hi(xlo); y[dt][2] += op16_lo(xhi); y[dt][3] += op16_hi(xhi);
+            const f32x2 a = (f32x2){y[dt][0], y[dt][1]}, b = (f32x2){y[dt][2], y[dt][3]};
+            sum2 += a; sum2 += b;
+            sq2 = __builtin_elementwise_fma(a, a, sq2);
+            sq2 = __builtin_elementwise_fma(b, b, sq2);
+        }
+        float sum = sum2.x + sum2.y, sq = sq2.x + sq2.y;
+        sum = xor32_sum(xor16_sum(sum)); sq = xor32_sum(xor16_sum(sq));
+        const float mean = sum * (1.0f / DC);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(sq * (1.0f / DC) - mean * mean, 0.f) + eps);
+        // ---- (y - mean) rstd -> scratch (fp32), back as rows, gain / bias, 16-bit, 256-B runs; one channel half at a time.  The eight row
+        // reads of a half are requested together (one LDS round trip, not eight), and the second half is written while the first is stored.
+        bf16_t* orow = Xo + (int64_t)((wave + 4 * n) * 16 + hrow) * DC + 4 * k32;
+        auto put_half = [&](int h) {
+#pragma unroll
+            for (int d8 = 0; d8 < 8; ++d8) {
+                const int dt = 8 * h + d8;
+                const f32x4 t = (f32x4){(y[dt][0] - mean) * rstd, (y[dt][1] - mean) * rstd, (y[dt][2] - mean) * rstd, (y[dt][3] - mean) * rstd};
+                asm volatile("ds_write_b128 %0, %1" : : "v"(swr + (((4 * d8 + fg) ^ fi) << 4)), "v"(t) : "memory");
+            }
+        };
+        f32x4 a[8];
+        auto get_half = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the writes
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(srd + i * 1024 + ((k32 ^ (2 * i + hrow)) << 4)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : : "memory");
+        };
+        auto store_half = [&](int h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u32x2_d o;
+                o[0] = pack_op16(a[i][0] * gr[h][0] + br[h][0], a[i][1] * gr[h][1] + br[h][1]);
+                o[1] = pack_op16(a[i][2] * gr[h][2] + br[h][2], a[i][3] * gr[h][3] + br[h][3]);
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x2_d*>(orow + (int64_t)(2 * i) * DC + 128 * h));
+            }
+        };
+        put_half(0);
+        get_half();
+        put_half(1);            // (the scratch is free again: every read of half 0 has returned)
+        store_half(0);
+        get_half();
+        store_half(1);
+    }
+}
+
+// dec_i2t_w1_kernel is the route for whole-prompt launches (P >= 512, no XBuild); SABER_AMD_I2T_W1=0 (read per call) or debug flag 0x40000000
+// selects the four-wave kernel for A/Bs.
+static bool i2t_w1_route() {
+    if (g_saber_debug_flags & 0x40000000) return false;
+    const char* e = getenv("SABER_AMD_I2T_W1");
+    return !(e && e[0] == '0');
+}
 const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf16_t* Kt, const float* tk, float kscale, const float* cb, const bf16_t* VtT,
                            const float* bo, const float* gamma, const float* beta, float eps, bf16_t* Xout, int P, hipStream_t s, const XBuild* build) {
     if (P <= 0) return nullptr;
@@ -1158,8 +1407,13 @@ const char* launch_dec_i2t(const bf16_t* X, XMap xm, const bf16_t* peq, const bf
     }
     int nsplit = 1;
     while (P * nsplit < 512 && nsplit < 8) nsplit *= 2;   // small crops: split a prompt's tiles over several blocks
-    if (g_saber_debug_flags >> 20) nsplit = g_saber_debug_flags >> 20;      // (bits 8-19 belong to the GEMM kernels)
+    if ((g_saber_debug_flags >> 20) & 0xff) nsplit = (g_saber_debug_flags >> 20) & 0xff;      // (bits 8-19 belong to the GEMM kernels, 28-30 to the kernel routes below)
     if (xm.div <= 0) return "dec_i2t: XMap.div must be positive";
+    if (nsplit == 1 && !g_saber_stamp_buf && !(g_saber_debug_flags & 1) && i2t_w1_route()) {
+        if (xm.div > 1) hipLaunchKernelGGL((dec_i2t_w1_kernel<true>), dim3(P), dim3(256), I4_LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout);
+        else hipLaunchKernelGGL((dec_i2t_w1_kernel<false>), dim3(P), dim3(256), I4_LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout);
+        return nullptr;
+    }
     if (g_saber_debug_flags & 1)
         hipLaunchKernelGGL((dec_i2t_kernel<2, false, false>), dim3(P * nsplit), dim3(512), I2TCfg<2>::LDS, s, X, xm.stride, xm.div, xm.off, peq, Kt, tk, kscale, cb, VtT, bo, gamma, beta, eps, Xout, nsplit, 0, g_saber_stamp_buf, nf, nb, nf);
     else
@@ -1920,6 +2174,8 @@ const char* decoder_fused_init_device() {
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<1>::LDS + I2TCfg<1>::W3_B);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, I2TCfg<2>::LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_upscale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_w1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, I4_LDS);
+    if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_i2t_w1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, I4_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
     if (st == hipSuccess) st = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_t2i_w1_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);

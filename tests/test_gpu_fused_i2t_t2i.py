@@ -50,7 +50,7 @@ def test_fused_equals_separate_launches(precision):
 
 @pytest.mark.parametrize("shared", [False, True])
 def test_t2i_one_wave_per_simd_kernel_against_fp64(shared):
-    """`dec_t2i_w1_kernel` (the route for whole-key-range launches; debug flag 0x200000 / SABER_AMD_T2I_W1=0 select the 8-wave kernel): the tokens -> image attention with a wave per key quarter and all
+    """`dec_t2i_w1_kernel` (the route for whole-key-range launches; debug flag 0x20000000 / SABER_AMD_T2I_W1=0 select the 8-wave kernel): the tokens -> image attention with a wave per key quarter and all
     four query tiles per wave - against the same fp64 restatement tests/test_gpu_kernels.py::test_dec_t2i uses, and run-to-run identical
     (it orders its LDS-DMA ring by counted waits alone)."""
     import ctypes as C
@@ -69,7 +69,7 @@ def test_t2i_one_wave_per_simd_kernel_against_fp64(shared):
     part = torch.zeros(P * 64 * 256, device="cuda")
     ml = torch.zeros(P * 64 * 2, device="cuda")
     outs = []
-    lib.saber_k_set_debug(0x100000)
+    lib.saber_k_set_debug(0x10000000)
     try:
         for _ in range(3):
             out = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
@@ -79,7 +79,7 @@ def test_t2i_one_wave_per_simd_kernel_against_fp64(shared):
     finally:
         lib.saber_k_set_debug(0)
     ref8 = torch.zeros(P, 8, 128, device="cuda", dtype=torch.bfloat16)
-    lib.saber_k_set_debug(0x200000)
+    lib.saber_k_set_debug(0x20000000)
     kcall(lib, lib.saber_k_dec_t2i(ptr(X), 0 if shared else 4096 * 256, ptr(pek), ptr(Qt), ptr(tq), qscale, ptr(part), ptr(ml), P, 1, ptr(Wv), ptr(bv), ptr(ref8), None))
     torch.cuda.synchronize()
     lib.saber_k_set_debug(0)
@@ -123,3 +123,61 @@ def test_decode_with_t2i_w1_equals_default():
     finally:
         os.environ.pop("SABER_AMD_T2I_W1", None)
         eng.close()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_i2t_one_wave_per_simd_kernel(shared):
+    """`dec_i2t_w1_kernel` (the route for whole-prompt launches: P >= 512; debug flag 0x40000000 / SABER_AMD_I2T_W1=0 select the four-wave
+    kernel): a wave owns a 16-row tile - all 64 score columns, all 256 channels, softmax weights and LayerNorm statistics in registers.
+    Against the fp64 formula of tests/test_gpu_kernels.py::test_dec_i2t on the first prompts, against the four-wave kernel on all of
+    them (same operands, same roundings: one 16-bit ulp at most apart), in place (X = Xout: layer 1 of the decoder), run-to-run identical."""
+    import torch.nn.functional as F
+    from saber_amd import _lib
+    from tests.test_gpu_kernels import _dec_inputs, _blockdiag_pe_scores, kcall, ptr
+    lib = _lib.load()
+    assert lib.saber_k_init(0) == 0
+    P = 520
+    g, r, X, pe = _dec_inputs(1 if shared else P, 23)
+    Kt = r(P, 64, 256, scale=0.08).to(torch.bfloat16)
+    peq = r(4096, 128, scale=1.0).to(torch.bfloat16)
+    tk = r(P * 8, 128, scale=1.0)
+    kscale = 0.3
+    cb = r(P, 64)
+    VtT = r(P, 256, 64, scale=0.5).to(torch.bfloat16)
+    bo, gamma, beta = r(256), 1.0 + 0.1 * r(256), 0.1 * r(256)
+
+    def run(flag, inplace=False):
+        lib.saber_k_set_debug(flag)
+        try:
+            if inplace:
+                out = X.clone()
+                src = out
+            else:
+                out = torch.zeros(P, 4096, 256, device="cuda", dtype=torch.bfloat16)
+                src = X
+            kcall(lib, lib.saber_k_dec_i2t(ptr(src), 0 if shared else 4096 * 256, ptr(peq), ptr(Kt), ptr(tk), kscale, ptr(cb), ptr(VtT), ptr(bo), ptr(gamma),
+                                           ptr(beta), 1e-5, ptr(out), P, None))
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib.saber_k_set_debug(0)
+
+    w1 = run(0)
+    ref4 = run(0x40000000)
+    assert torch.equal(w1, run(0)), "run-to-run"
+    d = (w1.float() - ref4.float()).abs()
+    print(f"dec_i2t_w1 vs the four-wave kernel (shared={shared}): max |diff| {d.max().item():.3e}, differing elements {(d > 0).float().mean().item():.2e}")
+    assert d.max().item() <= 0.04 and (d > 0).float().mean().item() < 0.05
+    if not shared:
+        assert torch.equal(w1, run(0, inplace=True)), "in place"
+    n = 3
+    Xd = (X.double().expand(P, -1, -1))[:n]
+    tkb = (tk * kscale).to(torch.bfloat16).view(P, 8, 128)[:n]
+    S = Xd @ Kt[:n].double().transpose(1, 2) + _blockdiag_pe_scores(tkb, peq, 1.0).transpose(1, 2) + cb[:n].double()[:, None, :]
+    Pm = torch.softmax(S.view(n, 4096, 8, 8) * np.log(2.0), dim=-1).view(n, 4096, 64)
+    Y = Pm.to(torch.bfloat16).double() @ VtT[:n].double().transpose(1, 2)
+    ref = F.layer_norm(Xd + Y + bo.double(), (256,), gamma.double(), beta.double(), 1e-5)
+    err = (w1[:n].double() - ref).abs().max().item()
+    rms = (w1[:n].double() - ref).pow(2).mean().sqrt().item()
+    print(f"dec_i2t_w1 vs fp64: max {err:.3e}, rms {rms:.3e}")
+    assert err < 0.04 and rms < 4e-3

@@ -1,5 +1,5 @@
 """A/B of an opt-in decoder kernel on the decode of P prompts: python tools/fuse_ab.py [P] [ENV]  (ENV = SABER_AMD_FUSE_I2T_T2I (default) or
-SABER_AMD_T2I_W1; per-class profile, ms per decode)"""
+SABER_AMD_T2I_W1 / SABER_AMD_I2T_W1 (default on: A/B is =0 against unset); per-class profile, ms per decode)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ pts = torch.rand(P, 2, device="cuda") * 1024
 low, iou, _ = eng.decode_points(pts, slot=0, multimask=True)
 mi = torch.clamp(low[:, 0], -32, 32).contiguous()
 for fuse in (0, 1, 0, 1):
-    if ENV == "SABER_AMD_T2I_W1":          # default ON: A/B is "0" against unset
+    if ENV in ("SABER_AMD_T2I_W1", "SABER_AMD_I2T_W1"):          # default ON: A/B is "0" against unset
         if fuse: os.environ.pop(ENV, None)
         else: os.environ[ENV] = "0"
     elif fuse: os.environ[ENV] = "1"

@@ -15,7 +15,7 @@ Wv = bf(torch.randn(128, 256, device="cuda", generator=g) / 16); bv = torch.rand
 o2 = torch.empty(P, 8, 128, device="cuda", dtype=torch.bfloat16)
 part = torch.empty(P * 64 * 256, device="cuda"); ml = torch.empty(P * 64 * 2, device="cuda")
 call = lambda: lib.saber_k_dec_t2i(ptr(X), 4096 * 256, ptr(pp), ptr(Qt), ptr(tproj), 0.3, ptr(part), ptr(ml), P, 1, ptr(Wv), ptr(bv), ptr(o2), None)
-for flag, name in ((0x200000, "dec_t2i_kernel<8>"), (0x100000, "dec_t2i_w1_kernel")):
+for flag, name in ((0x20000000, "dec_t2i_kernel<8>"), (0x10000000, "dec_t2i_w1_kernel")):
     lib.saber_k_set_debug(flag)
     for _ in range(3): call()
     torch.cuda.synchronize()
