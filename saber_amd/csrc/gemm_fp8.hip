@@ -292,8 +292,15 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmMxParams p, unsigned l
         for (int j = 0; j < 6; ++j) MX_RD8(sws[j], sw_ad + so + 64 * j);
 #pragma unroll
         for (int i = 0; i < 4; ++i) MX_RD8(sas[i], sa_ad + so + 64 * i);
+        // LGKM_CNT is a 4-bit counter that wraps (tools/probes/lgkm_probe.hip: with 16 or 24 reads in flight a counted wait lets values through
+        // that have not landed): never more than 15 LDS operations outstanding, so the 30 reads of a K-step go out in three batches, each
+        // behind a wait that leaves room for it (the scale bytes and the first fragments have long returned by then)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { MX_RD128(wl[j], w_lo + so + 2048 * j); MX_RD128(wh[j], w_hi + so + 2048 * j); }
+        for (int j = 0; j < 2; ++j) { MX_RD128(wl[j], w_lo + so + 2048 * j); MX_RD128(wh[j], w_hi + so + 2048 * j); }
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+#pragma unroll
+        for (int j = 2; j < 6; ++j) { MX_RD128(wl[j], w_lo + so + 2048 * j); MX_RD128(wh[j], w_hi + so + 2048 * j); }
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i) { MX_RD128(al[i], a_lo + so + 2048 * i); MX_RD128(ah[i], a_hi + so + 2048 * i); }
         MX_STAMP(2);
@@ -478,8 +485,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mx4_kernel(GemmMxParams p, unsign
         for (int j = 0; j < 6; ++j) MX_RD8(sws[j], sw_ad + so + 64 * j);
 #pragma unroll
         for (int i = 0; i < 3; ++i) MX_RD8(sas[i], sa_ad + so + 64 * i);
+        // (never more than 15 LDS operations outstanding: see the 4-tile kernel above)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { MX_RD128(wl[j], w_lo + so + 2048 * j); MX_RD128(wh[j], w_hi + so + 2048 * j); }
+        for (int j = 0; j < 3; ++j) { MX_RD128(wl[j], w_lo + so + 2048 * j); MX_RD128(wh[j], w_hi + so + 2048 * j); }
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+#pragma unroll
+        for (int j = 3; j < 6; ++j) { MX_RD128(wl[j], w_lo + so + 2048 * j); MX_RD128(wh[j], w_hi + so + 2048 * j); }
+        asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 3; ++i) { MX_RD128(al[i], a_lo + so + 2048 * i); MX_RD128(ah[i], a_hi + so + 2048 * i); }
         MX_STAMP(2);
